@@ -1,0 +1,185 @@
+/*
+ * g2g.h -- C ABI of the MI355X-native group-to-group alignment DP (libg2g.so).
+ *
+ * Drop-in boundary for ONE hot path of ogotoh/prrn_aln: the group-to-group affine / double-affine gap
+ * DP that align2() dispatches to (reference src/maln2.cc:1875 -> alignC<recd_t> src/fwd2c.h:671 ->
+ * Fwd2c<recd_t>::forwardB src/fwd2c.h:359 + Vmf::traceback src/vmf.cc:105 + stdskl src/gaps.cc:139).
+ * Plain pointers and sizes only; no C++/torch types.  Every entry point names the reference interface
+ * it replaces.  All scores are IEEE-754 doubles (the prrn build: -DDVAL=1, reference src/cmn.h:40-50).
+ *
+ * Two levels:
+ *   level 1 ("operator")  g2g_group / g2g_pwdm / g2g_align2      <-> mSeq / PwdM / align2()
+ *   level 0 ("engine")    g2g_problem / g2g_forward_batch        <-> Fwd2c<recd_t>(seqs,pwd).forwardB()+traceback()
+ * Level 1 builds a g2g_problem on the host (mode selection, thickness, profile vectors, gap profiles:
+ * SURVEY.md §8 rows a7-a9) and hands it to level 0, which runs on the GPU.  There is no CPU fallback:
+ * if no HIP device is usable every compute entry point returns G2G_ERR_NODEVICE.
+ */
+#ifndef G2G_H_
+#define G2G_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G2G_ABI_VERSION 1
+
+/* error codes (negative) */
+enum {
+    G2G_OK              =  0,
+    G2G_ERR_ARG         = -1,   /* malformed argument                                            */
+    G2G_ERR_MODE        = -2,   /* alignment mode not on this path (spliced _ALS/_ALH, ether u0>0, SSHP):
+                                   the reference itself would fatal() (maln2.cc:1918) or use Fwd2h/Fwd2s */
+    G2G_ERR_NODEVICE    = -3,   /* no usable HIP device / kernel image                           */
+    G2G_ERR_DEVICE      = -4,   /* HIP runtime error (message via g2g_last_error)                */
+    G2G_ERR_NOMEM       = -5,
+    G2G_ERR_ENDS        = -6    /* skeleton ends mismatch even at sh = -100 (maln2.cc:1946-1952) */
+};
+
+/* reference enum ALN_MODE, src/aln.h:71-76 (banded "_ALB" = default because algmode.bnd = 1) */
+enum {
+    G2G_NGP_ALN = 1, G2G_HLF_ALN = 2, G2G_RHF_ALN = 3, G2G_GPF_ALN = 4, G2G_NTV_ALN = 5,
+    G2G_NGP_ALB = 6, G2G_HLF_ALB = 7, G2G_RHF_ALB = 8, G2G_GPF_ALB = 9, G2G_NTV_ALB = 10
+};
+
+/* which PwdM::sim?? column scorer (reference src/maln.h:159-173,205-209; table maln2.cc:347-399).
+   value = 10*kind + (weighted ? 1 : 0) for the member-loop scorers */
+enum {
+    G2G_SIM00 = 0, G2G_SIM11 = 11, G2G_SIM12I = 120, G2G_SIM12W = 121, G2G_SIM13 = 13,
+    G2G_SIM21I = 210, G2G_SIM21W = 211, G2G_SIM22I = 220, G2G_SIM22W = 221,
+    G2G_SIM23I = 230, G2G_SIM23W = 231, G2G_SIM31 = 31, G2G_SIM32I = 320, G2G_SIM32W = 321,
+    G2G_SIM33 = 33, G2G_SIM33N = 330
+};
+
+/* reference enum TraceBackDir, src/aln.h:47-52 (only the values Fwd2c produces) */
+enum { G2G_DEAD = 0, G2G_DIAG = 2, G2G_NEWD = 3, G2G_VERT = 4, G2G_HORI = 8, G2G_NEWV = 12, G2G_NEWH = 13 };
+
+/* reference struct SKL {int m, n;}, src/cmn.h:124 */
+typedef struct g2g_skl { int32_t m, n; } g2g_skl;
+
+/* ---- level 0: the flattened DP problem -------------------------------------------------------- */
+
+/* Static gap profile of one group: the three views Gfq::sfrq/tfrq/rfrq (reference src/gfreq.h:44-64,
+   src/gfreq.cc:247-312).  View v (0 = s, 1 = t, 2 = r): the list of position p (p = -1 .. len-1) is
+   glen[v][off[v][p+1] ...], ascending in glen and terminated by an entry with glen = -1 (the
+   terminator is part of the pool).  off[v] has len+2 entries (the last one = pool length).
+   freq of the s view is in accumulated (suffix-sum) form, as the reference stores it. */
+typedef struct g2g_gapprof {
+    int32_t        hetero;          /* Gfq::hetero: capacity of a dynamic gap-state list is hetero+1 */
+    const int32_t *off[3];
+    const int32_t *glen[3];
+    const double  *freq[3];
+} g2g_gapprof;
+
+/* One side of the DP as mSeqItr hands it out (reference src/mseq.h:206-350, src/mseq.cc:760-815). */
+typedef struct g2g_side {
+    int32_t        many;            /* members                                                    */
+    int32_t        len;             /* columns                                                    */
+    int32_t        left, right;     /* range to align, reference Seq::left/right                  */
+    int32_t        nils;            /* inex.nils                                                  */
+    int32_t        dels;            /* inex.dels (any internal/terminal gap)                      */
+    const uint8_t *seq;             /* (len+2)*many residue codes, position -1 first ([pos][member],
+                                       reference Seq::at(), nil_code=0 gap_code=1 seq.h:76-77)    */
+    const double  *weight;          /* many, or NULL                                              */
+    int32_t        nelm, felm;      /* profile vector geometry (mseq.h:53-59); 0 if not vectorised */
+    const double  *pseq;            /* (len+2)*nelm, position -1 first, or NULL                   */
+    const double  *thk;             /* (len+2)*3 {cfq,dfq,efq} at positions -1..len: SeqThk as the
+                                       iterator yields it for each position (thk_mode folded in)  */
+    int32_t        has_gfq;
+    g2g_gapprof    gfq;             /* valid iff has_gfq                                          */
+    /* NTV modes only: per position/member gap densities (mSeq::gapdensity/postgapdensity,
+       mseq.h:148-160), (len+2)*many each, position -1 first; NULL otherwise */
+    const double  *gapdens;
+    const double  *postgapdens;
+} g2g_side;
+
+typedef struct g2g_problem {
+    int32_t  alnmode;               /* G2G_*_ALB / _ALN                                            */
+    int32_t  sim2_kind;             /* G2G_SIM*                                                   */
+    int32_t  noll;                  /* PwdB::Noll: 2 affine, 3 double affine (aln2.cc:100)        */
+    int32_t  codonk1;               /* PwdB::codonk1 (aln2.cc:116-117)                            */
+    int32_t  lw, up;                /* band: WINDOW from stripe() (aln2.cc:156-174)               */
+    int32_t  crg2_kind;             /* NTV engines: which PwdM::crg?? (maln2.cc:881-1024,1454-1614):
+                                       11, 120/121 (12i/12w), 210/211, 220/221; 0 otherwise         */
+    int32_t  reserved1;
+    double   basic_gop;             /* PwdM::Basic_GOP  = -scale*v (maln2.cc:232)                 */
+    double   weighted_gop;          /* PwdM::Weighted_GOP = -v     (maln2.cc:237)                 */
+    double   u;                     /* alnprm.u, unpaired-column penalty in unp1 (maln.h:185)     */
+    double   u2divu1, v2divv1;      /* LongGEP/BasicGEP, LongGOP/BasicGOP (fwd2c.h:85-86)         */
+    const double *simmtx;           /* rows x dim substitution matrix, Simmtx::mtx (simmtx.h:49)  */
+    int32_t  simdim, simrows;
+    g2g_side a, b;
+} g2g_problem;
+
+/* result of one DP */
+typedef struct g2g_result {
+    double    score;                /* Fwd2c::forwardB return value (= *scr of align2)            */
+    int64_t   cells;                /* in-band cells visited: sum_m (n9 - n), fwd2c.h:373-374,393 */
+    int32_t   ntrace;               /* records in `trace`                                         */
+    int32_t   status;               /* G2G_OK or error for this item                              */
+    g2g_skl  *trace;                /* Vmf::traceback(-1) order: end corner first, origin last
+                                       (vmf.cc:105-120); free with g2g_free()                     */
+} g2g_result;
+
+typedef struct g2g_ctx g2g_ctx;
+
+/* Create a context bound to one HIP device (device < 0: current device).  Returns NULL on failure. */
+g2g_ctx *g2g_create(int device);
+void     g2g_destroy(g2g_ctx *ctx);
+const char *g2g_last_error(void);
+int      g2g_abi_version(void);
+/* 1 if a HIP device + gfx950 code object are usable, else 0 (never falls back to the host). */
+int      g2g_device_ok(g2g_ctx *ctx);
+
+/* Fwd2c<recd_t>(seqs, pwd, trb=true).forwardB() + traceback() for a batch of independent problems
+   (alignC<recd_t>, reference src/fwd2c.h:671-677).  res[i].trace is malloc'ed by the library. */
+int      g2g_forward_batch(g2g_ctx *ctx, int n, const g2g_problem *const *prob, g2g_result *res);
+
+/* stdskl(): sort + normalise a raw traceback into ascending unique corners (reference src/gaps.cc:139).
+   in[0..n) raw records; returns malloc'ed corners (count in *nout), caller g2g_free()s. */
+g2g_skl *g2g_stdskl(const g2g_skl *in, int n, int *nout);
+
+void     g2g_free(void *p);
+
+/* ---- level 1: the operator surface ------------------------------------------------------------- */
+
+/* subset of reference struct ALPRM (src/seq.h:27-28) + the algmode bits this path reads */
+typedef struct g2g_params {
+    double  u, v, u0, u1, tgapf, scale, gamma;
+    int32_t k1, ls, sh;
+    int32_t banded;                 /* algmode.bnd                                                */
+    int32_t molc;                   /* 1 PROTEIN, 2 DNA (cmn.h:107)                               */
+    const double *simmtx;           /* rows x dim                                                  */
+    int32_t simdim, simrows;
+    int32_t max_code;               /* SEQ_CODE::max_code of the alphabet                         */
+} g2g_params;
+
+typedef struct g2g_group g2g_group;   /* <-> mSeq  */
+typedef struct g2g_pwdm  g2g_pwdm;    /* <-> PwdM  */
+
+/* <-> aggregate()/mSeq construction (src/mgaps.cc:282) followed by exg_seq(0,0): `seq` is
+   (len)*many residue codes [pos][member] for positions 0..len-1; the library adds the sentinel
+   columns.  weight may be NULL. */
+g2g_group *g2g_group_create(g2g_ctx *ctx, const g2g_params *prm, int many, int len,
+                            const uint8_t *seq, const double *weight);
+void       g2g_group_free(g2g_group *g);
+
+/* <-> PwdM::PwdM(mSeq** seqs, const ALPRM*) (src/maln2.cc:254): selects alnmode, swaps so the
+   profile side is `a`, builds thickness / vectors / gap profiles.  *swapped receives PwdM::swp. */
+g2g_pwdm  *g2g_pwdm_create(g2g_ctx *ctx, const g2g_params *prm, g2g_group *a, g2g_group *b, int *swapped);
+void       g2g_pwdm_free(g2g_pwdm *p);
+const g2g_problem *g2g_pwdm_problem(const g2g_pwdm *p);
+
+/* <-> SKL* align2(mSeq* seqs[], PwdM* pwdm, VTYPE* scr, Gsinfo*) (src/maln2.cc:1875): forward fill,
+   traceback, stdskl, end check with the sh = -100 retry.  *skl is malloc'ed: skl[0..*nskl) corners
+   ascending (the reference's skl[1..n]); caller g2g_free()s.  Batched form = one randiv sweep. */
+int        g2g_align2(g2g_ctx *ctx, g2g_pwdm *p, double *scr, g2g_skl **skl, int *nskl);
+int        g2g_align2_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *p, double *scr,
+                            g2g_skl **skl, int *nskl, int *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G2G_H_ */

@@ -1,0 +1,121 @@
+"""ctypes mirror of include/g2g.h (the C ABI of libg2g.so).  Plumbing only."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List
+
+import numpy as np
+
+c_i32p = C.POINTER(C.c_int32)
+c_f64p = C.POINTER(C.c_double)
+c_u8p = C.POINTER(C.c_uint8)
+
+
+class Skl(C.Structure):
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32)]
+
+
+class GapProf(C.Structure):
+    _fields_ = [("hetero", C.c_int32),
+                ("off", c_i32p * 3), ("glen", c_i32p * 3), ("freq", c_f64p * 3)]
+
+
+class Side(C.Structure):
+    _fields_ = [("many", C.c_int32), ("len", C.c_int32), ("left", C.c_int32), ("right", C.c_int32),
+                ("nils", C.c_int32), ("dels", C.c_int32),
+                ("seq", c_u8p), ("weight", c_f64p),
+                ("nelm", C.c_int32), ("felm", C.c_int32),
+                ("pseq", c_f64p), ("thk", c_f64p),
+                ("has_gfq", C.c_int32), ("gfq", GapProf),
+                ("gapdens", c_f64p), ("postgapdens", c_f64p)]
+
+
+class Problem(C.Structure):
+    _fields_ = [("alnmode", C.c_int32), ("sim2_kind", C.c_int32), ("noll", C.c_int32),
+                ("codonk1", C.c_int32), ("lw", C.c_int32), ("up", C.c_int32),
+                ("crg2_kind", C.c_int32), ("reserved1", C.c_int32),
+                ("basic_gop", C.c_double), ("weighted_gop", C.c_double), ("u", C.c_double),
+                ("u2divu1", C.c_double), ("v2divv1", C.c_double),
+                ("simmtx", c_f64p), ("simdim", C.c_int32), ("simrows", C.c_int32),
+                ("a", Side), ("b", Side)]
+
+
+class Result(C.Structure):
+    _fields_ = [("score", C.c_double), ("cells", C.c_int64), ("ntrace", C.c_int32),
+                ("status", C.c_int32), ("trace", C.POINTER(Skl))]
+
+
+class Params(C.Structure):
+    _fields_ = [("u", C.c_double), ("v", C.c_double), ("u0", C.c_double), ("u1", C.c_double),
+                ("tgapf", C.c_double), ("scale", C.c_double), ("gamma", C.c_double),
+                ("k1", C.c_int32), ("ls", C.c_int32), ("sh", C.c_int32), ("banded", C.c_int32),
+                ("molc", C.c_int32),
+                ("simmtx", c_f64p), ("simdim", C.c_int32), ("simrows", C.c_int32),
+                ("max_code", C.c_int32)]
+
+
+def _ptr(arr: np.ndarray, typ):
+    return arr.ctypes.data_as(typ)
+
+
+class ProblemHolder:
+    """Owns the numpy arrays a Problem points into."""
+
+    def __init__(self):
+        self.keep: List[np.ndarray] = []
+        self.c = Problem()
+
+    def arr(self, a, dtype):
+        x = np.ascontiguousarray(a, dtype=dtype)
+        self.keep.append(x)
+        return x
+
+
+def problem_from_arrays(d: Dict[str, np.ndarray]) -> ProblemHolder:
+    """Build a g2g_problem from a dict of flattened arrays (the layout tests/refdump.py parses out of
+    the reference dump and that tests/golden/*.npz store)."""
+    h = ProblemHolder()
+    p = h.c
+    sc = lambda k: d[k].reshape(-1)[0]
+    p.alnmode = int(sc("alnmode"))
+    p.sim2_kind = int(sc("sim2_kind"))
+    p.noll = int(sc("Noll"))
+    p.codonk1 = int(sc("codonk1"))
+    p.crg2_kind = int(sc("crg2_kind")) if "crg2_kind" in d else 0
+    p.lw = int(sc("wdw_lw"))
+    p.up = int(sc("wdw_up"))
+    p.basic_gop = float(sc("Basic_GOP"))
+    p.weighted_gop = float(sc("Weighted_GOP"))
+    p.u = float(sc("alnprm_u"))
+    bgep, bgop = float(sc("BasicGEP")), float(sc("BasicGOP"))
+    # Fwd2c ctor, reference src/fwd2c.h:85-86
+    p.u2divu1 = float(sc("LongGEP")) / bgep if bgep < 0 else 0.0
+    p.v2divv1 = float(sc("LongGOP")) / bgop if bgop < 0 else 0.0
+    sm = h.arr(d["simmtx"], np.float64)
+    p.simmtx = _ptr(sm, c_f64p)
+    p.simrows, p.simdim = sm.shape
+    for pfx, side, wkey in (("a_", p.a, "wta"), ("b_", p.b, "wtb")):
+        g = lambda k: d[pfx + k]
+        side.many = int(g("many")[0]); side.len = int(g("len")[0])
+        side.left = int(g("left")[0]); side.right = int(g("right")[0])
+        side.nils = int(g("nils")[0]); side.dels = int(g("dels")[0])
+        side.seq = _ptr(h.arr(g("seq"), np.uint8), c_u8p)
+        if wkey in d:
+            side.weight = _ptr(h.arr(d[wkey], np.float64), c_f64p)
+        elif pfx + "weight" in d:
+            side.weight = _ptr(h.arr(g("weight"), np.float64), c_f64p)
+        side.nelm = int(g("nelm")[0]); side.felm = int(g("felm")[0])
+        if pfx + "pseq" in d:
+            side.pseq = _ptr(h.arr(g("pseq"), np.float64), c_f64p)
+        side.thk = _ptr(h.arr(g("thk"), np.float64), c_f64p)
+        side.has_gfq = 1 if (pfx + "hetero") in d else 0
+        if side.has_gfq:
+            side.gfq.hetero = int(g("hetero")[0])
+            for v, nm in enumerate(("sfq", "tfq", "rfq")):
+                side.gfq.off[v] = _ptr(h.arr(g(nm + "_off"), np.int32), c_i32p)
+                side.gfq.glen[v] = _ptr(h.arr(g(nm + "_glen"), np.int32), c_i32p)
+                side.gfq.freq[v] = _ptr(h.arr(g(nm + "_freq"), np.float64), c_f64p)
+        if pfx + "gapdens" in d:
+            side.gapdens = _ptr(h.arr(g("gapdens"), np.float64), c_f64p)
+            side.postgapdens = _ptr(h.arr(g("postgapdens"), np.float64), c_f64p)
+    return h
