@@ -137,6 +137,18 @@ int      g2g_device_ok(g2g_ctx *ctx);
    (alignC<recd_t>, reference src/fwd2c.h:671-677).  res[i].trace is malloc'ed by the library. */
 int      g2g_forward_batch(g2g_ctx *ctx, int n, const g2g_problem *const *prob, g2g_result *res);
 
+/* The same in three steps, for callers that keep a sweep resident in HBM (bench.py times g2g_batch_run
+   only: inputs are already in device memory when it starts).  g2g_batch_times() reports the HIP-event
+   durations of the forward and backtrack kernels of the last run, measured on the context's stream. */
+typedef struct g2g_batch g2g_batch;
+int       g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *prob, g2g_batch **out);
+int       g2g_batch_run(g2g_batch *b);
+int       g2g_batch_fetch(g2g_batch *b, g2g_result *res);
+void      g2g_batch_times(const g2g_batch *b, float *fwd_ms, float *tb_ms);
+long long g2g_batch_cells(const g2g_batch *b);
+size_t    g2g_batch_arena_bytes(const g2g_batch *b);
+void      g2g_batch_free(g2g_batch *b);
+
 /* stdskl(): sort + normalise a raw traceback into ascending unique corners (reference src/gaps.cc:139).
    in[0..n) raw records; returns malloc'ed corners (count in *nout), caller g2g_free()s. */
 g2g_skl *g2g_stdskl(const g2g_skl *in, int n, int *nout);

@@ -1,0 +1,51 @@
+"""Loader for libg2g.so.  There is no fallback: if the HIP library is missing or no MI355X is usable the
+product raises -- nothing here (or anywhere in the package) computes an alignment on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libg2g.so")
+
+_lib = None
+
+
+class G2GError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise G2GError("libg2g.so is not built (python -m prrn_aln_amd.build); there is no CPU fallback")
+    L = C.CDLL(LIB)
+    L.g2g_create.restype = C.c_void_p
+    L.g2g_create.argtypes = [C.c_int]
+    L.g2g_destroy.argtypes = [C.c_void_p]
+    L.g2g_last_error.restype = C.c_char_p
+    L.g2g_device_ok.argtypes = [C.c_void_p]
+    PP = C.POINTER(C.POINTER(_abi.Problem))
+    L.g2g_forward_batch.argtypes = [C.c_void_p, C.c_int, PP, C.POINTER(_abi.Result)]
+    L.g2g_batch_prepare.argtypes = [C.c_void_p, C.c_int, PP, C.POINTER(C.c_void_p)]
+    L.g2g_batch_run.argtypes = [C.c_void_p]
+    L.g2g_batch_fetch.argtypes = [C.c_void_p, C.POINTER(_abi.Result)]
+    L.g2g_batch_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.g2g_batch_cells.restype = C.c_longlong
+    L.g2g_batch_cells.argtypes = [C.c_void_p]
+    L.g2g_batch_arena_bytes.restype = C.c_size_t
+    L.g2g_batch_arena_bytes.argtypes = [C.c_void_p]
+    L.g2g_batch_free.argtypes = [C.c_void_p]
+    L.g2g_free.argtypes = [C.c_void_p]
+    L.g2g_stdskl.restype = C.POINTER(_abi.Skl)
+    L.g2g_stdskl.argtypes = [C.POINTER(_abi.Skl), C.c_int, C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().g2g_last_error().decode()

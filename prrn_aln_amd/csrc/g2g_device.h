@@ -1,0 +1,77 @@
+// g2g_device.h -- device-side view of one group-to-group DP (internal to libg2g.so).
+//
+// HBM layout (all per-DP regions are carved out of one arena by the host, g2g_engine.hip):
+//   inputs   : exactly the g2g_problem arrays (include/g2g.h), copied verbatim, 16-B aligned
+//   state    : the reference's diagonal-indexed row buffer hh[0..Noll) + f1/f2 (fwd2c.h:90-98) kept as
+//              structure-of-arrays over the diagonal index r = n - m, r in [lw-1, up+1]:
+//                val[X][r]  f64      dir[X][r] u8      X in {H, G, G2, F, F2}
+//                dla[X][k][r], dlb[X][k][r]  {glen,nins} pairs, ENTRY-major so that the k-th entries of
+//                neighbouring diagonals are contiguous (the anti-diagonal sweep reads them coalesced)
+//   trace    : one byte per in-band cell, anti-diagonal major: trace[(d - d0) * tstride + (m - mlo(d))]
+#ifndef G2G_DEVICE_H_
+#define G2G_DEVICE_H_
+#include <stdint.h>
+
+struct DevSide {
+    int many, len, left, right, nils, nelm, felm, hetero;
+    const uint8_t *seq;
+    const double  *weight;
+    const double  *pseq;
+    const double  *thk;
+    const int     *off[3];
+    const int     *glen[3];
+    const double  *freq[3];
+    const double  *gapdens;
+    const double  *postgapdens;
+};
+
+enum { XH = 0, XG = 1, XG2 = 2, XF = 3, XF2 = 4, NX = 5 };
+
+struct DevProb {
+    int kind;            // 0 DPunit, 1 _hf, 2 _pf, 3 _nv   (reference src/dpunit.h:31-51)
+    int noll, sim2_kind, crg2_kind, codonk1, lw, up, width;
+    double basic_gop, weighted_gop, u, u2divu1, v2divv1;
+    const double *simmtx;
+    int simdim;
+    int capa, capb;      // entries per dynamic list (hetero+1) / members (nv)
+    DevSide a, b;
+    // state, indexed [r - (lw-1)]
+    double  *val[NX];
+    uint8_t *dir[NX];
+    int2    *dla[NX];
+    int2    *dlb[NX];
+    int     *glb[NX];    // _hf: running gap length of b ; _nv: gla/glb member arrays [(an+bn)][width]
+    // trace
+    uint8_t *trace;
+    int      tstride;
+    int      d0, d1;     // first / last anti-diagonal (m + n) holding cells
+    // outputs
+    double  *score;
+    int     *ntrace;
+    int2    *otrace;     // up to tcap records {m, n}
+    int      tcap;
+    long long cells;
+};
+
+
+#if defined(__HIPCC__)
+#define G2G_HD __host__ __device__
+#else
+#define G2G_HD
+#endif
+// ---- band geometry ---------------------------------------------------------------------------
+G2G_HD inline int g2g_floordiv2(int x) { return x >= 0 ? x / 2 : -((-x + 1) / 2); }
+G2G_HD inline int g2g_ceildiv2(int x) { return x >= 0 ? (x + 1) / 2 : -((-x) / 2); }
+// rows holding a cell on anti-diagonal d = m + n, where row m spans
+// n in [max(m+lw, b.left), min(m+up+1, b.right))   (reference src/fwd2c.h:373-374)
+G2G_HD inline void diag_rows(int d, int al, int ar, int bl, int br, int lw, int up, int *mlo, int *mhi)
+{
+    int lo = al, hi = ar - 1, t;
+    t = d - br + 1;              if (t > lo) lo = t;       // n <= b.right - 1
+    t = g2g_ceildiv2(d - up);    if (t > lo) lo = t;       // n - m <= up
+    t = d - bl;                  if (t < hi) hi = t;       // n >= b.left
+    t = g2g_floordiv2(d - lw);   if (t < hi) hi = t;       // n - m >= lw
+    *mlo = lo; *mhi = hi;
+}
+
+#endif

@@ -1,0 +1,355 @@
+// g2g_engine.hip -- host side of level 0 (include/g2g.h): packs g2g_problem batches into one HBM arena,
+// launches the forward + backtrack kernels (g2g_kernels.hip) on the context's stream and fetches results.
+// No CPU fallback lives here: without a usable HIP device every entry point fails with G2G_ERR_NODEVICE.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/g2g.h"
+#include "g2g_device.h"
+#include "g2g_internal.h"
+
+#include "g2g_kernels.hip"          // one translation unit: kernels + launcher (no -fgpu-rdc needed)
+
+static thread_local std::string g_err;
+void g2g_set_error(const char *fmt, const char *a)
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, fmt, a);
+    g_err = buf;
+}
+extern "C" const char *g2g_last_error(void) { return g_err.c_str(); }
+extern "C" int g2g_abi_version(void) { return G2G_ABI_VERSION; }
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    g2g_set_error("HIP error: %s", hipGetErrorString(e_)); return G2G_ERR_DEVICE; } } while (0)
+
+struct g2g_ctx {
+    int device;
+    int ok;
+    hipStream_t stream;
+    hipEvent_t ev[4];
+};
+
+extern "C" g2g_ctx *g2g_create(int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g2g_set_error("%s", "no HIP device visible");
+        return NULL;
+    }
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= ndev) { g2g_set_error("%s", "device index out of range"); return NULL; }
+    if (hipSetDevice(device) != hipSuccess) { g2g_set_error("%s", "hipSetDevice failed"); return NULL; }
+    g2g_ctx *c = new g2g_ctx();
+    c->device = device;
+    c->ok = 0;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; g2g_set_error("%s", "stream"); return NULL; }
+    for (int i = 0; i < 4; ++i) hipEventCreate(&c->ev[i]);
+    // the code object must contain an image for this GPU (the library is built for gfx950 only)
+    hipFuncAttributes fa;
+    hipError_t e = hipFuncGetAttributes(&fa, (const void *) g2g_forward_kernel);
+    if (e != hipSuccess) {
+        g2g_set_error("no gfx950 kernel image usable on this device: %s", hipGetErrorString(e));
+        (void) hipGetLastError();
+    } else c->ok = 1;
+    return c;
+}
+
+extern "C" void g2g_destroy(g2g_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int g2g_device_ok(g2g_ctx *c) { return c && c->ok; }
+extern "C" void g2g_free(void *p) { free(p); }
+
+// ---- batch -----------------------------------------------------------------------------------
+
+struct Blob {                       // host image of the input part of the arena
+    std::vector<char> h;
+    size_t put(const void *src, size_t bytes)
+    {
+        size_t off = (h.size() + 15) & ~(size_t) 15;
+        h.resize(off + bytes);
+        if (bytes) memcpy(h.data() + off, src, bytes);
+        return off;
+    }
+};
+
+struct g2g_batch {
+    g2g_ctx *ctx;
+    int n;
+    std::vector<DevProb> dp;        // host copy with device pointers
+    std::vector<int> status;
+    std::vector<long long> cells;
+    std::vector<size_t> out_off;    // per problem: offset of {score, ntrace, otrace} block
+    std::vector<int> tcap;
+    char *d_arena;
+    size_t arena_bytes, in_bytes;
+    DevProb *d_probs;
+    float fwd_ms, tb_ms;
+};
+
+static int kind_of(int alnmode)
+{
+    switch (alnmode) {
+    case G2G_NGP_ALB: return 0;
+    case G2G_HLF_ALB: case G2G_RHF_ALB: return 1;
+    case G2G_GPF_ALB: return 2;
+    case G2G_NTV_ALB: return 3;
+    }
+    return -1;
+}
+
+static int check_problem(const g2g_problem *p)
+{
+    if (!p) return G2G_ERR_ARG;
+    int kind = kind_of(p->alnmode);
+    if (kind < 0) return G2G_ERR_MODE;           // rectangular (_ALN) and spliced engines: not on this path yet
+    if (p->noll != 2 && p->noll != 3) return G2G_ERR_ARG;
+    const g2g_side *s[2] = {&p->a, &p->b};
+    for (int k = 0; k < 2; ++k) {
+        if (s[k]->many < 1 || s[k]->len < 1 || !s[k]->seq || !s[k]->thk) return G2G_ERR_ARG;
+        if (s[k]->left < 0 || s[k]->right > s[k]->len || s[k]->left >= s[k]->right) return G2G_ERR_ARG;
+    }
+    if (p->up < p->lw) return G2G_ERR_ARG;
+    if (kind == 1 && !p->a.has_gfq) return G2G_ERR_ARG;
+    if (kind == 2 && (!p->a.has_gfq || !p->b.has_gfq)) return G2G_ERR_ARG;
+    if (kind == 3 && (!p->a.gapdens || !p->b.gapdens || !p->a.postgapdens || !p->b.postgapdens || !p->crg2_kind)) return G2G_ERR_ARG;
+    // the end corner must lie inside the band (stripe() guarantees it, aln2.cc:156-174)
+    int re = p->b.right - p->a.right, rs = p->b.left - p->a.left;
+    if (re < p->lw || re > p->up || rs < p->lw || rs > p->up) return G2G_ERR_ARG;
+    switch (p->sim2_kind) {
+    case G2G_SIM00: case G2G_SIM11: case G2G_SIM12I: case G2G_SIM21I: case G2G_SIM22I: break;
+    case G2G_SIM12W: if (!p->b.weight) return G2G_ERR_ARG; break;
+    case G2G_SIM21W: if (!p->a.weight) return G2G_ERR_ARG; break;
+    case G2G_SIM22W: if (!p->a.weight || !p->b.weight) return G2G_ERR_ARG; break;
+    case G2G_SIM13: case G2G_SIM23I: if (!p->b.pseq) return G2G_ERR_ARG; break;
+    case G2G_SIM23W: if (!p->b.pseq || !p->a.weight) return G2G_ERR_ARG; break;
+    case G2G_SIM31: case G2G_SIM32I: if (!p->a.pseq) return G2G_ERR_ARG; break;
+    case G2G_SIM32W: if (!p->a.pseq || !p->b.weight) return G2G_ERR_ARG; break;
+    case G2G_SIM33: case G2G_SIM33N: if (!p->a.pseq || !p->b.pseq) return G2G_ERR_ARG; break;
+    default: return G2G_ERR_MODE;
+    }
+    if (!p->simmtx && (p->sim2_kind == G2G_SIM11 || p->sim2_kind / 10 == 12 || p->sim2_kind / 10 == 21 || p->sim2_kind / 10 == 22))
+        return G2G_ERR_ARG;
+    return G2G_OK;
+}
+
+// offsets (relative to arena base) are stored in the pointer fields first, rebased after allocation
+template <class T> static inline T *OFF(size_t off) { return (T *) (uintptr_t) (off + 1); }   // +1: 0 stays NULL
+template <class T> static inline void rebase(T *&p, char *base) { if (p) p = (T *) (base + ((uintptr_t) p - 1)); }
+
+static void pack_side(Blob &bl, const g2g_side &s, DevSide &d, int kind, bool need_gfq)
+{
+    memset(&d, 0, sizeof d);
+    d.many = s.many; d.len = s.len; d.left = s.left; d.right = s.right; d.nils = s.nils;
+    d.nelm = s.nelm; d.felm = s.felm;
+    const size_t cols = (size_t) s.len + 2;
+    d.seq = OFF<const uint8_t>(bl.put(s.seq, cols * s.many));
+    if (s.weight) d.weight = OFF<const double>(bl.put(s.weight, sizeof(double) * s.many));
+    if (s.pseq && s.nelm > 0) d.pseq = OFF<const double>(bl.put(s.pseq, sizeof(double) * cols * s.nelm));
+    d.thk = OFF<const double>(bl.put(s.thk, sizeof(double) * cols * 3));
+    if (need_gfq) {
+        d.hetero = s.gfq.hetero;
+        for (int v = 0; v < 3; ++v) {
+            const int nlist = s.len + 2;                       // offsets for positions -1..len-1 + end
+            const int pool = s.gfq.off[v][s.len + 1];
+            d.off[v] = OFF<const int>(bl.put(s.gfq.off[v], sizeof(int) * nlist));
+            d.glen[v] = OFF<const int>(bl.put(s.gfq.glen[v], sizeof(int) * pool));
+            d.freq[v] = OFF<const double>(bl.put(s.gfq.freq[v], sizeof(double) * pool));
+        }
+    }
+    if (kind == 3) {
+        d.gapdens = OFF<const double>(bl.put(s.gapdens, sizeof(double) * cols * s.many));
+        d.postgapdens = OFF<const double>(bl.put(s.postgapdens, sizeof(double) * cols * s.many));
+    }
+}
+
+static void rebase_side(DevSide &d, char *base)
+{
+    rebase(d.seq, base); rebase(d.weight, base); rebase(d.pseq, base); rebase(d.thk, base);
+    for (int v = 0; v < 3; ++v) { rebase(d.off[v], base); rebase(d.glen[v], base); rebase(d.freq[v], base); }
+    rebase(d.gapdens, base); rebase(d.postgapdens, base);
+}
+
+extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *prob, g2g_batch **out)
+{
+    if (!ctx || n < 0 || !out) return G2G_ERR_ARG;
+    if (!ctx->ok) return G2G_ERR_NODEVICE;
+    HIPCHK(hipSetDevice(ctx->device));
+    g2g_batch *b = new g2g_batch();
+    b->ctx = ctx; b->n = n; b->d_arena = 0; b->d_probs = 0; b->fwd_ms = b->tb_ms = 0;
+    b->dp.resize(n); b->status.assign(n, G2G_OK); b->cells.assign(n, 0); b->out_off.assign(n, 0); b->tcap.assign(n, 0);
+    Blob bl;
+    size_t probs_off = bl.put(0, 0);
+    bl.h.resize(probs_off + sizeof(DevProb) * (size_t) (n > 0 ? n : 1));
+    // 1. inputs
+    for (int i = 0; i < n; ++i) {
+        DevProb &d = b->dp[i];
+        memset(&d, 0, sizeof d);
+        const g2g_problem *p = prob[i];
+        int rc = check_problem(p);
+        b->status[i] = rc;
+        if (rc) { d.kind = -1; continue; }
+        d.kind = kind_of(p->alnmode);
+        d.noll = p->noll; d.sim2_kind = p->sim2_kind; d.crg2_kind = p->crg2_kind; d.codonk1 = p->codonk1;
+        d.lw = p->lw; d.up = p->up; d.width = p->up - p->lw + 3;
+        d.basic_gop = p->basic_gop; d.weighted_gop = p->weighted_gop; d.u = p->u;
+        d.u2divu1 = p->u2divu1; d.v2divv1 = p->v2divv1;
+        d.simdim = p->simdim;
+        if (p->simmtx) d.simmtx = OFF<const double>(bl.put(p->simmtx, sizeof(double) * (size_t) p->simdim * p->simrows));
+        pack_side(bl, p->a, d.a, d.kind, d.kind == 1 || d.kind == 2);
+        pack_side(bl, p->b, d.b, d.kind, d.kind == 2);
+    }
+    b->in_bytes = (bl.h.size() + 255) & ~(size_t) 255;
+    // 2. state / trace / outputs (device only)
+    size_t off = b->in_bytes;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t) 15; return o; };
+    for (int i = 0; i < n; ++i) {
+        DevProb &d = b->dp[i];
+        if (d.kind < 0) continue;
+        const g2g_problem *p = prob[i];
+        const size_t W = d.width;
+        if (d.kind == 1) { d.capa = p->a.gfq.hetero + 1; d.capb = 0; }
+        else if (d.kind == 2) { d.capa = p->a.gfq.hetero + 1; d.capb = p->b.gfq.hetero + 1; }
+        else if (d.kind == 3) { d.capa = p->a.many; d.capb = p->b.many; }
+        for (int x = 0; x < NX; ++x) {
+            if (d.noll != 3 && (x == XG2 || x == XF2)) continue;
+            d.val[x] = OFF<double>(take(sizeof(double) * W));
+            d.dir[x] = OFF<uint8_t>(take(W));
+            if (d.kind == 1 || d.kind == 2) d.dla[x] = OFF<int2>(take(sizeof(int2) * W * d.capa));
+            if (d.kind == 2) d.dlb[x] = OFF<int2>(take(sizeof(int2) * W * d.capb));
+            if (d.kind == 1) d.glb[x] = OFF<int>(take(sizeof(int) * W));
+            if (d.kind == 3) d.glb[x] = OFF<int>(take(sizeof(int) * W * (d.capa + d.capb)));
+        }
+        // anti-diagonal extent and the widest anti-diagonal
+        const int al = p->a.left, ar = p->a.right, bl_ = p->b.left, br = p->b.right;
+        d.d0 = al + bl_; d.d1 = (ar - 1) + (br - 1);
+        int tmax = 1;
+        long long cells = 0;
+        for (int dd = d.d0; dd <= d.d1; ++dd) {
+            int mlo, mhi;
+            diag_rows(dd, al, ar, bl_, br, d.lw, d.up, &mlo, &mhi);
+            int c = mhi - mlo + 1;
+            if (c > 0) cells += c;
+            if (c > tmax) tmax = c;
+        }
+        b->cells[i] = cells; d.cells = cells;
+        d.tstride = tmax;
+        d.trace = OFF<uint8_t>(take((size_t) (d.d1 - d.d0 + 1) * tmax));
+        d.tcap = (ar - al) + (br - bl_) + 4;
+        b->tcap[i] = d.tcap;
+        b->out_off[i] = take(sizeof(double) + sizeof(int) * 2 + sizeof(int2) * (size_t) d.tcap);
+        d.score = OFF<double>(b->out_off[i]);
+        d.ntrace = OFF<int>(b->out_off[i] + sizeof(double));
+        d.otrace = OFF<int2>(b->out_off[i] + sizeof(double) + 2 * sizeof(int));
+    }
+    b->arena_bytes = off + 256;
+    hipError_t e = hipMalloc((void **) &b->d_arena, b->arena_bytes);
+    if (e != hipSuccess) { g2g_set_error("hipMalloc(arena): %s", hipGetErrorString(e)); delete b; return G2G_ERR_NOMEM; }
+    for (int i = 0; i < n; ++i) {
+        DevProb &d = b->dp[i];
+        if (d.kind < 0) continue;
+        rebase(d.simmtx, b->d_arena);
+        rebase_side(d.a, b->d_arena); rebase_side(d.b, b->d_arena);
+        for (int x = 0; x < NX; ++x) {
+            rebase(d.val[x], b->d_arena); rebase(d.dir[x], b->d_arena); rebase(d.dla[x], b->d_arena);
+            rebase(d.dlb[x], b->d_arena); rebase(d.glb[x], b->d_arena);
+        }
+        rebase(d.trace, b->d_arena); rebase(d.score, b->d_arena); rebase(d.ntrace, b->d_arena); rebase(d.otrace, b->d_arena);
+    }
+    if (n) memcpy(bl.h.data() + probs_off, b->dp.data(), sizeof(DevProb) * (size_t) n);
+    b->d_probs = (DevProb *) (b->d_arena + probs_off);
+    e = hipMemcpyAsync(b->d_arena, bl.h.data(), bl.h.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { g2g_set_error("upload: %s", hipGetErrorString(e)); hipFree(b->d_arena); delete b; return G2G_ERR_DEVICE; }
+    *out = b;
+    return G2G_OK;
+}
+
+// Compact the valid problems to the front?  No: invalid ones keep kind = -1 and the kernels skip them.
+extern "C" int g2g_batch_run(g2g_batch *b)
+{
+    if (!b) return G2G_ERR_ARG;
+    g2g_ctx *ctx = b->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (b->n == 0) return G2G_OK;
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(g2g_forward_kernel, dim3(b->n), dim3(512), 0, ctx->stream, (const DevProb *) b->d_probs);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+    hipLaunchKernelGGL(g2g_traceback_kernel, dim3((b->n + 63) / 64), dim3(64), 0, ctx->stream, (const DevProb *) b->d_probs, b->n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipEventElapsedTime(&b->fwd_ms, ctx->ev[0], ctx->ev[1]));
+    HIPCHK(hipEventElapsedTime(&b->tb_ms, ctx->ev[1], ctx->ev[2]));
+    return G2G_OK;
+}
+
+extern "C" int g2g_batch_fetch(g2g_batch *b, g2g_result *res)
+{
+    if (!b || !res) return G2G_ERR_ARG;
+    g2g_ctx *ctx = b->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    // outputs of all problems sit between the first and the last out block: fetch per problem (small)
+    for (int i = 0; i < b->n; ++i) {
+        res[i].status = b->status[i];
+        res[i].cells = b->cells[i];
+        res[i].trace = 0; res[i].ntrace = 0; res[i].score = 0;
+        if (b->status[i]) continue;
+        const size_t bytes = sizeof(double) + 2 * sizeof(int) + sizeof(int2) * (size_t) b->tcap[i];
+        std::vector<char> tmp(bytes);
+        HIPCHK(hipMemcpy(tmp.data(), b->d_arena + b->out_off[i], bytes, hipMemcpyDeviceToHost));
+        memcpy(&res[i].score, tmp.data(), sizeof(double));
+        int nt;
+        memcpy(&nt, tmp.data() + sizeof(double), sizeof(int));
+        if (nt < 2 || nt > b->tcap[i]) { res[i].status = G2G_ERR_DEVICE; continue; }
+        res[i].ntrace = nt;
+        res[i].trace = (g2g_skl *) malloc(sizeof(g2g_skl) * nt);
+        memcpy(res[i].trace, tmp.data() + sizeof(double) + 2 * sizeof(int), sizeof(g2g_skl) * nt);
+    }
+    return G2G_OK;
+}
+
+extern "C" void g2g_batch_times(const g2g_batch *b, float *fwd_ms, float *tb_ms)
+{
+    if (fwd_ms) *fwd_ms = b ? b->fwd_ms : 0;
+    if (tb_ms) *tb_ms = b ? b->tb_ms : 0;
+}
+
+extern "C" long long g2g_batch_cells(const g2g_batch *b)
+{
+    long long c = 0;
+    if (b) for (int i = 0; i < b->n; ++i) if (!b->status[i]) c += b->cells[i];
+    return c;
+}
+
+extern "C" size_t g2g_batch_arena_bytes(const g2g_batch *b) { return b ? b->arena_bytes : 0; }
+
+extern "C" void g2g_batch_free(g2g_batch *b)
+{
+    if (!b) return;
+    hipSetDevice(b->ctx->device);
+    if (b->d_arena) hipFree(b->d_arena);
+    delete b;
+}
+
+extern "C" int g2g_forward_batch(g2g_ctx *ctx, int n, const g2g_problem *const *prob, g2g_result *res)
+{
+    g2g_batch *b = 0;
+    int rc = g2g_batch_prepare(ctx, n, prob, &b);
+    if (rc) return rc;
+    rc = g2g_batch_run(b);
+    if (!rc) rc = g2g_batch_fetch(b, res);
+    g2g_batch_free(b);
+    return rc;
+}

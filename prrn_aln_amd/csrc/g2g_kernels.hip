@@ -1,0 +1,617 @@
+// g2g_kernels.hip -- gfx950 kernels of the group-to-group DP engine.
+//
+// What they compute: Fwd2c<recd_t>::forwardB (reference src/fwd2c.h:359-482, initB :138-176) with the
+// record-type specialisations of src/fwd2c.cc (DPunit :52-102, _nv :107-147, _hf :152-198, _pf :203-251)
+// and the gap-state algebra of src/gfreq.cc:493-605 -- but scheduled as an ANTI-DIAGONAL wavefront:
+// all cells with the same m + n are independent (each reads the corners (m,n), (m,n+1), (m+1,n) written
+// on the two previous anti-diagonals), one workgroup sweeps one DP, one barrier per anti-diagonal.
+// The reference's diagonal-indexed row buffer maps onto this unchanged: cell (m,n) owns index r = n - m
+// of H/G/G2/F/F2, reads r-1 and r+1 (other parity class), so no double buffering is needed.
+// The Vmf linked list (src/vmf.h) is replaced by one trace byte per cell + a backtrack kernel that
+// re-derives exactly the records Vmf::traceback(-1) would return.
+//
+// Arithmetic: IEEE doubles, reference operand order, built with -ffp-contract=off (no FMA), so scores
+// are bit-identical to the reference CPU path.  No MFMA: the recurrence is scalar.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <limits.h>
+#include "g2g_device.h"
+
+#define NEVSEL (-(DBL_MAX / 16 * 7))      /* reference src/cmn.h:57 */
+
+// TraceBackDir values Fwd2c produces (src/aln.h:47-52) and their classes (:59-61)
+enum { D_DEAD = 0, D_DIAG = 2, D_NEWD = 3, D_VERT = 4, D_HORI = 8, D_NEWV = 12, D_NEWH = 13 };
+__device__ __forceinline__ bool isdiag(int d) { return d == D_DIAG || d == D_NEWD; }
+__device__ __forceinline__ bool isvert(int d) { return d == D_VERT || d == D_NEWV; }
+__device__ __forceinline__ bool ishori(int d) { return d == D_HORI || d == D_NEWH; }
+
+// trace byte: bits 0-3 final H.dir, bit 4 G extended (else opened from H), bit 5 G2 ext, bit 6 F ext,
+// bit 7 F2 ext.  H came from the "2" (long-gap) record iff ... see T_SEL2 (stored in a second nibble
+// would not fit, so dir is compressed to 3 bits):
+enum { T_DIRMASK = 7, T_SEL2 = 8, T_GEXT = 16, T_G2EXT = 32, T_FEXT = 64, T_F2EXT = 128 };
+__device__ __forceinline__ int dir2code(int d)
+{   // DIAG 1, NEWD 2, VERT 3, NEWV 4, HORI 5, NEWH 6
+    return d == D_DIAG ? 1 : d == D_NEWD ? 2 : d == D_VERT ? 3 : d == D_NEWV ? 4 : d == D_HORI ? 5 : d == D_NEWH ? 6 : 0;
+}
+
+// ---- views ------------------------------------------------------------------------------------
+struct SList { const int *glen; const double *freq; };            // one static GFREQ list
+__device__ __forceinline__ SList gfq_at(const DevSide &s, int view, int pos)
+{
+    int o = s.off[view][pos + 1];
+    SList l; l.glen = s.glen[view] + o; l.freq = s.freq[view] + o;
+    return l;
+}
+struct DList {                                                    // one dynamic IDELTA list
+    int2 *p; int s;
+    __device__ __forceinline__ int glen(int k) const { return p[(size_t) k * s].x; }
+    __device__ __forceinline__ int nins(int k) const { return p[(size_t) k * s].y; }
+    __device__ __forceinline__ void set(int k, int g, int n) const { p[(size_t) k * s] = make_int2(g, n); }
+};
+struct Rec { int x, i; };                                         // buffer X, slot i = r - (lw - 1)
+
+__device__ __forceinline__ DList dla_of(const DevProb &P, Rec r) { DList d; d.p = P.dla[r.x] + r.i; d.s = P.width; return d; }
+__device__ __forceinline__ DList dlb_of(const DevProb &P, Rec r) { DList d; d.p = P.dlb[r.x] + r.i; d.s = P.width; return d; }
+__device__ __forceinline__ double &val_of(const DevProb &P, Rec r) { return P.val[r.x][r.i]; }
+__device__ __forceinline__ int dir_of(const DevProb &P, Rec r) { return P.dir[r.x][r.i]; }
+
+__device__ __forceinline__ const double *thk_at(const DevSide &s, int pos) { return s.thk + (size_t)(pos + 1) * 3; }
+__device__ __forceinline__ const uint8_t *res_at(const DevSide &s, int pos) { return s.seq + (size_t)(pos + 1) * s.many; }
+__device__ __forceinline__ const double *vss_at(const DevSide &s, int pos) { return s.pseq + (size_t)(pos + 1) * s.nelm; }
+
+// ---- gap-state algebra (reference src/gfreq.cc) -------------------------------------------------
+// GapLenSD, gfreq.h:67
+__device__ __forceinline__ int gaplen_sd(int g, const DList dl)
+{
+    int k = 0;
+    while (g >= dl.glen(k + 1)) ++k;
+    return g + dl.nins(k);
+}
+// newgap(cf, dlc, df, dld), gfreq.cc:507-521
+__device__ double newgap4(const SList cf, const DList dlc, const SList df, const DList dld)
+{
+    double g = 0;
+    int ci = 0;
+    for (int di = 0; df.glen[di] >= 0; ++di) {
+        int j = gaplen_sd(df.glen[di], dld);
+        for ( ; cf.glen[ci] >= 0; ++ci) {
+            int i = gaplen_sd(cf.glen[ci], dlc);
+            if (i >= j) break;
+        }
+        if (cf.glen[ci] < 0) break;
+        g += cf.freq[ci] * df.freq[di];
+    }
+    return g;
+}
+// newgap(cf, dlc, j), gfreq.cc:523-532
+__device__ double newgap_cj(const SList cf, const DList dlc, int j)
+{
+    for (int ci = 0; cf.glen[ci] >= 0; ++ci) {
+        int i = gaplen_sd(cf.glen[ci], dlc);
+        if (i >= j) return cf.freq[ci];
+    }
+    return 0;
+}
+// newgap(df, i, dld), gfreq.cc:534-545
+__device__ double newgap_di(const SList df, int i, const DList dld)
+{
+    double g = 0;
+    int k = 0;
+    for (int di = 0; df.glen[di] >= 0; ++di) {
+        while (df.glen[di] >= dld.glen(k + 1)) ++k;
+        if (i < df.glen[di] + dld.nins(k)) break;
+        g += df.freq[di];
+    }
+    return g;
+}
+// cleardelta / copydelta, gfreq.cc:551-563
+__device__ __forceinline__ void cleardelta(const DList d) { d.set(0, 0, 0); d.set(1, INT_MAX, 0); }
+__device__ void copydelta(const DList dst, const DList src)
+{
+    int k = 0;
+    do { dst.set(k, src.glen(k), src.nins(k)); ++k; } while (src.glen(k) < INT_MAX);
+    dst.set(k, src.glen(k), src.nins(k));
+}
+// newdelta(dlt, df, dln, 1), gfreq.cc:570-587; dst may be the same list as src (in-place, as the
+// reference does for update(h, h, ...)): every store trails the loads it could affect
+__device__ void newdelta(const DList dst, const SList df, const DList src)
+{
+    int kd = 0, ks = 0;
+    int tg = 0, tn = 0;                                   // tmp = ZeroDelta
+    for (int di = 0; df.glen[di] >= 0; ++di) {
+        int g = df.glen[di];
+        if (g >= src.glen(ks)) {
+            while (g >= src.glen(ks + 1)) ++ks;
+            int sn = src.nins(ks);
+            if (sn > tn) {
+                dst.set(kd++, tg, tn);
+                tn = sn;
+                tg = g + 1;
+            }
+        }
+    }
+    dst.set(kd++, tg, tn);
+    dst.set(kd, INT_MAX, 0);
+}
+// incdelta(dlt, dln, 1), gfreq.cc:598-605
+__device__ void incdelta2(const DList dst, const DList src)
+{
+    int k = 0;
+    do { dst.set(k, src.glen(k), src.nins(k) + 1); ++k; } while (src.glen(k) < INT_MAX);
+    dst.set(k, src.glen(k), src.nins(k));
+}
+
+// ---- column scorers: PwdM::sim?? (src/maln.h:160-172, src/maln2.cc:534-623,1230-1296) -----------
+__device__ double sim2(const DevProb &P, int m, int n)
+{
+    const DevSide &a = P.a, &b = P.b;
+    const uint8_t *ar = res_at(a, m), *br = res_at(b, n);
+    const double *mtx = P.simmtx;
+    const int dim = P.simdim;
+    double s = 0;
+    switch (P.sim2_kind) {
+    case 0: return 0;
+    case 11: return mtx[(size_t) ar[0] * dim + br[0]];
+    case 120: for (int j = 0; j < b.many; ++j) s += mtx[(size_t) ar[0] * dim + br[j]]; return s;
+    case 121: for (int j = 0; j < b.many; ++j) s += mtx[(size_t) ar[0] * dim + br[j]] * b.weight[j]; return s;
+    case 13: return vss_at(b, n)[b.felm + ar[0]];
+    case 210: for (int i = 0; i < a.many; ++i) s += mtx[(size_t) br[0] * dim + ar[i]]; return s;
+    case 211: for (int i = 0; i < a.many; ++i) s += mtx[(size_t) br[0] * dim + ar[i]] * a.weight[i]; return s;
+    case 220:
+        for (int i = 0; i < a.many; ++i)
+            for (int j = 0; j < b.many; ++j) s += mtx[(size_t) ar[i] * dim + br[j]];
+        return s;
+    case 221:
+        for (int i = 0; i < a.many; ++i) {
+            double st = 0;
+            for (int j = 0; j < b.many; ++j) st += mtx[(size_t) ar[i] * dim + br[j]] * b.weight[j];
+            s += st * a.weight[i];
+        }
+        return s;
+    case 230: { const double *vb = vss_at(b, n) + b.felm;
+        for (int i = 0; i < a.many; ++i) s += vb[ar[i]]; return s; }
+    case 231: { const double *vb = vss_at(b, n) + b.felm;
+        for (int i = 0; i < a.many; ++i) s += vb[ar[i]] * a.weight[i]; return s; }
+    case 31: return vss_at(a, m)[a.felm + br[0]];
+    case 320: { const double *va = vss_at(a, m) + a.felm;
+        for (int j = 0; j < b.many; ++j) s += va[br[j]]; return s; }
+    case 321: { const double *va = vss_at(a, m) + a.felm;
+        for (int j = 0; j < b.many; ++j) s += va[br[j]] * b.weight[j]; return s; }
+    case 33: { const double *va = vss_at(a, m) + a.felm, *vb = vss_at(b, n);
+        for (int j = 0; j < b.felm; ++j) s += va[j] * vb[j]; return s; }
+    case 330: { const double *va = vss_at(a, m) + a.felm, *vb = vss_at(b, n);
+        const int dc[6] = {0, 1, 2, 3, 5, 9};                        // decompact, mseq.h:41
+        for (int j = 0; j < b.felm; ++j) s += va[dc[j]] * vb[j]; return s; }
+    }
+    return 0;
+}
+
+// unp1, maln.h:185-187
+__device__ __forceinline__ double unpa(const DevProb &P, int m, int n) { return thk_at(P.a, m)[0] * thk_at(P.b, n)[2] * -P.u; }
+__device__ __forceinline__ double unpb(const DevProb &P, int n, int m) { return thk_at(P.b, n)[0] * thk_at(P.a, m)[2] * -P.u; }
+
+// ---- naive engine gap-open cost: PwdM::crg?? (maln2.cc:881-1024, 1454-1614) ---------------------
+__device__ double crg2(const DevProb &P, const int *gla, const int *glb, int st, int m, int n, int d3)
+{   // gla[i*st], glb[j*st]: member running gap lengths of the record
+    const DevSide &a = P.a, &b = P.b;
+    const uint8_t *as = res_at(a, m), *bs = res_at(b, n);
+    const double *agd = a.gapdens + (size_t)(m + 1) * a.many, *apg = a.postgapdens + (size_t)(m + 1) * a.many;
+    const double *bgd = b.gapdens + (size_t)(n + 1) * b.many, *bpg = b.postgapdens + (size_t)(n + 1) * b.many;
+    const double *wa = a.weight, *wb = b.weight;
+    const int an = a.many, bn = b.many;
+#define GLA(i) gla[(size_t)(i) * st]
+#define GLB(j) glb[(size_t)(j) * st]
+#define NG(c) ((c) > 1)
+    double g = 0;
+    switch (P.crg2_kind) {
+    case 11:
+        if (d3 == 0) {
+            if (NG(as[0]) && bgd[0] > 0 && GLA(0) >= GLB(0)) return bgd[0] * P.basic_gop;
+            if (NG(bs[0]) && agd[0] > 0 && GLB(0) >= GLA(0)) return agd[0] * P.basic_gop;
+        } else if (d3 > 0) {
+            if (bpg[0] > 0 && GLA(0) >= GLB(0)) return bpg[0] * P.basic_gop;
+        } else {
+            if (apg[0] > 0 && GLB(0) >= GLA(0)) return apg[0] * P.basic_gop;
+        }
+        return 0;
+    case 120: case 121: {
+        const bool w = P.crg2_kind & 1;
+        if (d3 == 0) {
+            if (NG(as[0])) {
+                for (int j = 0; j < bn; ++j) if (bgd[j] > 0 && GLA(0) >= GLB(j)) g += w ? wb[j] * bgd[j] : bgd[j];
+            } else if (agd[0] > 0) {
+                for (int j = 0; j < bn; ++j) if (NG(bs[j]) && GLB(j) >= GLA(0)) g += w ? wb[j] * agd[0] : agd[0];
+            }
+        } else if (d3 > 0) {
+            if (NG(as[0]))
+                for (int j = 0; j < bn; ++j) if (bpg[j] > 0 && GLA(0) >= GLB(j)) g += w ? wb[j] * bpg[j] : bpg[j];
+        } else if (apg[0] > 0) {
+            for (int j = 0; j < bn; ++j) if (NG(bs[j]) && GLB(j) >= GLA(0)) g += w ? wb[j] * apg[0] : apg[0];
+        }
+        return g * P.basic_gop;
+    }
+    case 210: case 211: {
+        const bool w = P.crg2_kind & 1;
+        if (d3 == 0) {
+            if (NG(bs[0])) {
+                for (int i = 0; i < an; ++i) if (agd[i] > 0 && GLB(0) >= GLA(i)) g += w ? wa[i] * agd[i] : agd[i];
+            } else if (bgd[0] > 0) {
+                for (int i = 0; i < an; ++i) if (NG(as[i]) && GLA(i) >= GLB(0)) g += w ? wa[i] * bgd[0] : bgd[0];
+            }
+        } else if (d3 < 0) {
+            if (NG(bs[0]))
+                for (int i = 0; i < an; ++i) if (apg[i] > 0 && GLB(0) >= GLA(i)) g += w ? wa[i] * apg[i] : apg[i];
+        } else if (!w || (bs[0] && bs[1])) {                 // crg21w :1518 tests `*bs && bs[1]`
+            if (bpg[0] > 0)
+                for (int i = 0; i < an; ++i) if (NG(as[i]) && GLA(i) >= GLB(0)) g += w ? wa[i] * bpg[0] : bpg[0];
+        }
+        return g * P.basic_gop;
+    }
+    case 220:
+        if (d3 == 0) {
+            for (int i = 0; i < an; ++i) {
+                if (NG(as[i])) {
+                    for (int j = 0; j < bn; ++j) if (bgd[j] > 0 && GLA(i) >= GLB(j)) g += bgd[j];
+                } else if (agd[i] > 0) {
+                    for (int j = 0; j < bn; ++j) if (NG(bs[j]) && GLB(j) >= GLA(i)) g += agd[i];
+                }
+            }
+        } else if (d3 > 0) {
+            for (int i = 0; i < an; ++i)
+                if (NG(as[i]))
+                    for (int j = 0; j < bn; ++j) if (bpg[j] > 0 && GLA(i) >= GLB(j)) g += bpg[j];
+        } else {
+            for (int j = 0; j < bn; ++j)
+                if (NG(bs[j]))
+                    for (int i = 0; i < an; ++i) if (apg[i] > 0 && GLB(j) >= GLA(i)) g += apg[i];
+        }
+        return g * P.basic_gop;
+    case 221:
+        if (d3 == 0) {
+            for (int i = 0; i < an; ++i) {
+                double s = 0;
+                if (NG(as[i])) {
+                    for (int j = 0; j < bn; ++j) if (bgd[j] > 0 && GLA(i) >= GLB(j)) s += wb[j] * bgd[j];
+                } else if (agd[i] > 0) {
+                    for (int j = 0; j < bn; ++j) if (NG(bs[j]) && GLB(j) >= GLA(i)) s += wb[j] * agd[i];
+                }
+                g += s * wa[i];
+            }
+        } else if (d3 > 0) {
+            for (int i = 0; i < an; ++i)
+                if (NG(as[i])) {
+                    double s = 0;
+                    for (int j = 0; j < bn; ++j) if (bpg[j] > 0 && GLA(i) >= GLB(j)) s += wb[j] * bpg[j];
+                    g += s * wa[i];
+                }
+        } else {
+            for (int j = 0; j < bn; ++j)
+                if (NG(bs[j])) {
+                    double s = 0;
+                    for (int i = 0; i < an; ++i) if (apg[i] > 0 && GLB(j) >= GLA(i)) s += wa[i] * apg[i];
+                    g += s * wb[j];
+                }
+        }
+        return g * P.basic_gop;
+    }
+#undef GLA
+#undef GLB
+#undef NG
+    return 0;
+}
+
+// ---- Fwd2c<recd_t>::gapopen (src/fwd2c.cc:52-91, :107-111, :152-160, :203-212) ------------------
+template <int KIND>
+__device__ double gapopen(const DevProb &P, Rec rc, int m, int n, int d3)
+{
+    if (KIND == 0) {                                    // DPunit, no DiThk (quick mode is off-path)
+        double axb = 0;
+        const int dr = dir_of(P, rc);
+        if (d3 > 0) { if (!isvert(dr)) axb = thk_at(P.a, m)[0] * thk_at(P.b, n)[2]; }
+        else if (d3 < 0) { if (!ishori(dr)) axb = thk_at(P.b, n)[0] * thk_at(P.a, m)[2]; }
+        else return 0;
+        return P.basic_gop * axb;                       // vgop, maln.h:320
+    } else if (KIND == 1) {                             // _hf: newgap1 / newgap2, maln.h:296-308
+        const DList dla = dla_of(P, rc);
+        const int glb = P.glb[rc.x][rc.i];
+        if (d3 > 0) {
+            const SList acf = gfq_at(P.a, 0, m);
+            if (acf.glen[0] < 0) return 0;
+            if (acf.glen[1] >= 0) return P.weighted_gop * newgap_cj(acf, dla, glb);
+            return (dla.nins(0) + acf.glen[0] >= glb) ? (P.weighted_gop * acf.freq[0]) : 0;
+        } else {
+            const SList adf = gfq_at(P.a, d3 == 0 ? 1 : 2, m);
+            if (adf.glen[0] < 0) return 0;
+            if (adf.glen[1] >= 0) return P.weighted_gop * newgap_di(adf, glb, dla);
+            return (glb >= dla.nins(0) + adf.glen[0]) ? (P.weighted_gop * adf.freq[0]) : 0;
+        }
+    } else if (KIND == 2) {                             // _pf: newgap3, maln.h:316-319
+        const DList dla = dla_of(P, rc), dlb = dlb_of(P, rc);
+        if (d3 == 0)
+            return newgap4(gfq_at(P.a, 0, m), dla, gfq_at(P.b, 1, n), dlb) * P.basic_gop
+                 + newgap4(gfq_at(P.b, 0, n), dlb, gfq_at(P.a, 1, m), dla) * P.basic_gop;
+        else if (d3 > 0)
+            return newgap4(gfq_at(P.a, 0, m), dla, gfq_at(P.b, 2, n), dlb) * P.basic_gop;
+        else
+            return newgap4(gfq_at(P.b, 0, n), dlb, gfq_at(P.a, 2, m), dla) * P.basic_gop;
+    } else {                                            // _nv
+        const int *gl = P.glb[rc.x] + rc.i;
+        return crg2(P, gl, gl + (size_t) P.a.many * P.width, P.width, m, n, d3);
+    }
+}
+
+// ---- Fwd2c<recd_t>::update (src/fwd2c.cc:94-102, :114-128, :163-181, :215-233) ------------------
+template <int KIND>
+__device__ void update(const DevProb &P, Rec dst, Rec src, int m, int n, double gpn, int d3)
+{
+    const int sd = dir_of(P, src);
+    int dir;
+    if (d3 > 0) dir = ishori(sd) ? D_NEWV : D_VERT;
+    else if (d3 < 0) dir = isvert(sd) ? D_NEWH : D_HORI;
+    else dir = isdiag(sd) ? D_DIAG : D_NEWD;
+    if (KIND == 1) {
+        if (d3 == 0) { newdelta(dla_of(P, dst), gfq_at(P.a, 1, m), dla_of(P, src)); P.glb[dst.x][dst.i] = 0; }
+        else if (d3 > 0) {
+            int g = P.glb[src.x][src.i] + 1;
+            newdelta(dla_of(P, dst), gfq_at(P.a, 1, m), dla_of(P, src));
+            P.glb[dst.x][dst.i] = g;
+        } else { incdelta2(dla_of(P, dst), dla_of(P, src)); P.glb[dst.x][dst.i] = 0; }
+    } else if (KIND == 2) {
+        if (d3 == 0) {
+            newdelta(dla_of(P, dst), gfq_at(P.a, 1, m), dla_of(P, src));
+            newdelta(dlb_of(P, dst), gfq_at(P.b, 1, n), dlb_of(P, src));
+        } else if (d3 > 0) {
+            newdelta(dla_of(P, dst), gfq_at(P.a, 1, m), dla_of(P, src));
+            incdelta2(dlb_of(P, dst), dlb_of(P, src));
+        } else {
+            newdelta(dlb_of(P, dst), gfq_at(P.b, 1, n), dlb_of(P, src));
+            incdelta2(dla_of(P, dst), dla_of(P, src));
+        }
+    } else if (KIND == 3) {                             // elongap, mgaps.cc:442-451
+        const int st = P.width, an = P.a.many, bn = P.b.many;
+        int *dg = P.glb[dst.x] + dst.i;
+        const int *sg = P.glb[src.x] + src.i;
+        const uint8_t *as = res_at(P.a, m), *bs = res_at(P.b, n);
+        for (int i = 0; i < an; ++i) {
+            int pr = sg[(size_t) i * st];
+            dg[(size_t) i * st] = (d3 >= 0) ? ((as[i] <= 1) ? pr + 1 : 0) : pr + 1;
+        }
+        for (int j = 0; j < bn; ++j) {
+            int pr = sg[(size_t)(an + j) * st];
+            dg[(size_t)(an + j) * st] = (d3 <= 0) ? ((bs[j] <= 1) ? pr + 1 : 0) : pr + 1;
+        }
+    }
+    const double v = val_of(P, src) + gpn;
+    P.dir[dst.x][dst.i] = (uint8_t) dir;
+    val_of(P, dst) = v;
+}
+
+// dpunit.cc: reset() -> black record ; copy()
+template <int KIND>
+__device__ void rec_reset(const DevProb &P, Rec r)
+{
+    val_of(P, r) = NEVSEL;
+    P.dir[r.x][r.i] = 0;
+    if (KIND == 1) { P.glb[r.x][r.i] = 0; cleardelta(dla_of(P, r)); }
+    else if (KIND == 2) { cleardelta(dla_of(P, r)); cleardelta(dlb_of(P, r)); }
+    else if (KIND == 3) {
+        const int tot = P.a.many + P.b.many;
+        for (int k = 0; k < tot; ++k) P.glb[r.x][r.i + (size_t) k * P.width] = 0;
+    }
+}
+template <int KIND>
+__device__ void rec_copy(const DevProb &P, Rec dst, Rec src)
+{
+    val_of(P, dst) = val_of(P, src);
+    P.dir[dst.x][dst.i] = P.dir[src.x][src.i];
+    if (KIND == 1) { copydelta(dla_of(P, dst), dla_of(P, src)); P.glb[dst.x][dst.i] = P.glb[src.x][src.i]; }
+    else if (KIND == 2) { copydelta(dla_of(P, dst), dla_of(P, src)); copydelta(dlb_of(P, dst), dlb_of(P, src)); }
+    else if (KIND == 3) {
+        const int tot = P.a.many + P.b.many;
+        for (int k = 0; k < tot; ++k) P.glb[dst.x][dst.i + (size_t) k * P.width] = P.glb[src.x][src.i + (size_t) k * P.width];
+    }
+}
+
+// ---- Fwd2c::initB, src/fwd2c.h:138-176 : the two boundary chains (sequential by nature) ----------
+template <int KIND>
+__device__ void init_top(const DevProb &P)
+{
+    const DevSide &a = P.a, &b = P.b;
+    int n = b.left, r = n - a.left, rr = b.right - a.left;
+    const int ai = a.left - 1;
+    if (P.up < rr) rr = P.up;
+    for ( ; ++r <= rr; ) {
+        const int bi = n;                       // bsi points at column n before ++n (fwd2c.h:151-159)
+        ++n;
+        Rec h = {XH, r - (P.lw - 1)}, hp = {XH, r - 1 - (P.lw - 1)};
+        const double pub = unpb(P, bi, ai);
+        double gnp = gapopen<KIND>(P, hp, ai, bi, -1);
+        gnp = (n - b.left < P.codonk1) ? gnp + pub : (P.v2divv1 * gnp + P.u2divu1 * pub);
+        update<KIND>(P, h, hp, ai, bi, gnp, -1);
+    }
+}
+template <int KIND>
+__device__ void init_left(const DevProb &P)
+{
+    const DevSide &a = P.a, &b = P.b;
+    int m = a.left, r = b.left - a.left, rr = b.left - a.right;
+    int ai = a.left - 1;
+    const int bi = b.left - 1;
+    if (P.lw > rr) rr = P.lw;
+    while (--r >= rr) {
+        ++m; ++ai;
+        Rec h = {XH, r - (P.lw - 1)}, hp = {XH, r + 1 - (P.lw - 1)};
+        const double pua = unpa(P, ai, bi);
+        double gnp = gapopen<KIND>(P, hp, ai, bi, 1);
+        gnp = (m - a.left < P.codonk1) ? gnp + pua : (P.v2divv1 * gnp + P.u2divu1 * pua);
+        update<KIND>(P, h, hp, ai, bi, gnp, 1);
+    }
+}
+
+// ---- one DP cell: the body of the n-loop of forwardB, src/fwd2c.h:393-471 ------------------------
+template <int KIND, bool NOLL3>
+__device__ void cell(const DevProb &P, int m, int n, uint8_t *tr)
+{
+    const DevSide &a = P.a, &b = P.b;
+    const int i = (n - m) - (P.lw - 1);
+    const Rec h = {XH, i}, hu = {XH, i + 1}, hl = {XH, i - 1};
+    const Rec g = {XG, i}, gu = {XG, i + 1}, g2 = {XG2, i}, g2u = {XG2, i + 1};
+    const Rec f = {XF, i}, fl = {XF, i - 1}, f2 = {XF2, i}, f2l = {XF2, i - 1};
+    int bits = 0;
+    // diagonal
+    const double dab = sim2(P, m, n);
+    double gop = gapopen<KIND>(P, h, m, n, 0);
+    update<KIND>(P, h, h, m, n, dab + gop, 0);
+    Rec mx = g;
+    int sel2 = 0;
+    if (m > a.left) {
+        // vertical; pua is evaluated once per row at the row's first column unless a.inex.nils
+        // (fwd2c.h:380,402)
+        int nf = m + P.lw; if (nf < b.left) nf = b.left;
+        const double pua = unpa(P, m, a.nils ? n : nf);
+        double gnp = gapopen<KIND>(P, gu, m, n, 1);
+        gop = gapopen<KIND>(P, hu, m, n, 1);
+        const bool hu_nv = !isvert(dir_of(P, hu));
+        if (hu_nv && (val_of(P, hu) + gop > val_of(P, gu) + gnp)) update<KIND>(P, g, hu, m, n, gop, 1);
+        else { update<KIND>(P, g, gu, m, n, gnp, 1); bits |= T_GEXT; }
+        val_of(P, g) += pua;
+        if (NOLL3) {
+            gnp = P.v2divv1 * gapopen<KIND>(P, g2u, m, n, 1);
+            gop = P.v2divv1 * gop;
+            if (hu_nv && (val_of(P, hu) + gop > val_of(P, g2u) + gnp)) update<KIND>(P, g2, hu, m, n, gop, 1);
+            else { update<KIND>(P, g2, g2u, m, n, gnp, 1); bits |= T_G2EXT; }
+            val_of(P, g2) += P.u2divu1 * pua;
+            if (val_of(P, g2) > val_of(P, mx)) { mx = g2; sel2 = 1; }
+        }
+    }
+    if (n > b.left) {
+        // horizontal: F(m, n-1) lives at diagonal index r-1 (the reference carries it in the scalar f1)
+        const double pub = unpb(P, n, m);
+        double gnp = gapopen<KIND>(P, fl, m, n, -1);
+        gop = gapopen<KIND>(P, hl, m, n, -1);
+        const bool hl_nh = !ishori(dir_of(P, hl));
+        if (hl_nh && (val_of(P, hl) + gop > val_of(P, fl) + gnp)) update<KIND>(P, f, hl, m, n, gop, -1);
+        else { update<KIND>(P, f, fl, m, n, gnp, -1); bits |= T_FEXT; }
+        val_of(P, f) += pub;
+        if (val_of(P, f) >= val_of(P, mx)) { mx = f; sel2 = 0; }
+        if (NOLL3) {
+            gnp = P.v2divv1 * gapopen<KIND>(P, f2l, m, n, -1);
+            gop = P.v2divv1 * gop;
+            if (hl_nh && (val_of(P, hl) + gop > val_of(P, f2l) + gnp)) update<KIND>(P, f2, hl, m, n, gop, -1);
+            else { update<KIND>(P, f2, f2l, m, n, gnp, -1); bits |= T_F2EXT; }
+            val_of(P, f2) += P.u2divu1 * pub;
+            if (val_of(P, f2) >= val_of(P, mx)) { mx = f2; sel2 = 1; }
+        }
+    }
+    // diagonal wins ties (fwd2c.h:453)
+    if (val_of(P, mx) > val_of(P, h)) { rec_copy<KIND>(P, h, mx); if (sel2) bits |= T_SEL2; }
+    *tr = (uint8_t)(bits | dir2code(dir_of(P, h)));
+}
+
+template <int KIND, bool NOLL3>
+__device__ void run_forward(const DevProb &P)
+{
+    const DevSide &a = P.a, &b = P.b;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // initializeC: every record black (fwd2c.cc:33-40,131-147,184-198,236-251)
+    for (int i = tid; i < P.width; i += nt) {
+        for (int x = 0; x < NX; ++x) {
+            if (!NOLL3 && (x == XG2 || x == XF2)) continue;
+            Rec r = {x, i};
+            rec_reset<KIND>(P, r);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {                                     // origin, fwd2c.h:145-149
+        Rec h = {XH, (b.left - a.left) - (P.lw - 1)};
+        val_of(P, h) = 0; P.dir[XH][h.i] = D_DIAG;
+    }
+    __syncthreads();
+    if (tid == 0) init_top<KIND>(P);
+    if (tid == 64 % nt && nt > 64) init_left<KIND>(P);
+    if (nt <= 64 && tid == 0) init_left<KIND>(P);
+    __syncthreads();
+    for (int d = P.d0; d <= P.d1; ++d) {
+        int mlo, mhi;
+        diag_rows(d, a.left, a.right, b.left, b.right, P.lw, P.up, &mlo, &mhi);
+        uint8_t *trow = P.trace + (size_t)(d - P.d0) * P.tstride;
+        for (int m = mlo + tid; m <= mhi; m += nt) cell<KIND, NOLL3>(P, m, d - m, trow + (m - mlo));
+        __syncthreads();
+    }
+    if (tid == 0) {
+        Rec e = {XH, (b.right - a.right) - (P.lw - 1)};
+        *P.score = val_of(P, e);
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(512)
+g2g_forward_kernel(const DevProb *probs)
+{
+    const DevProb &P = probs[blockIdx.x];
+    if (P.kind < 0) return;                             // rejected by the host-side argument check
+    if (P.noll == 3) {
+        switch (P.kind) {
+        case 0: run_forward<0, true>(P); break;
+        case 1: run_forward<1, true>(P); break;
+        case 2: run_forward<2, true>(P); break;
+        default: run_forward<3, true>(P); break;
+        }
+    } else {
+        switch (P.kind) {
+        case 0: run_forward<0, false>(P); break;
+        case 1: run_forward<1, false>(P); break;
+        case 2: run_forward<2, false>(P); break;
+        default: run_forward<3, false>(P); break;
+        }
+    }
+}
+
+// ---- backtrack: rebuild what Vmf::traceback(-1) returns (src/vmf.cc:105-120) --------------------
+// The reference appends a record {m, n, ptr} whenever the final H of a cell has dir NEWD/NEWV/NEWH
+// (fwd2c.h:465-467) and chains records through `ptr`, which update()/copy() propagate from the source
+// record.  Walking the trace bytes from the end corner visits exactly the H-level cells of that chain.
+__device__ __forceinline__ uint8_t trace_at(const DevProb &P, int m, int n)
+{
+    int mlo, mhi;
+    const int d = m + n;
+    diag_rows(d, P.a.left, P.a.right, P.b.left, P.b.right, P.lw, P.up, &mlo, &mhi);
+    return P.trace[(size_t)(d - P.d0) * P.tstride + (m - mlo)];
+}
+
+extern "C" __global__ void g2g_traceback_kernel(const DevProb *probs, int nprob)
+{
+    const int ip = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= nprob) return;
+    const DevProb &P = probs[ip];
+    if (P.kind < 0) return;
+    const DevSide &a = P.a, &b = P.b;
+    int cnt = 0;
+    int2 *out = P.otrace;
+    out[cnt++] = make_int2(a.right, b.right);           // fwd2c.h:476
+    int m = a.right - 1, n = b.right - 1;
+    const int guard = 4 * (a.right - a.left + b.right - b.left) + 16;
+    for (int it = 0; it < guard; ++it) {
+        if (m < a.left || n < b.left) break;            // reached an initB boundary corner: ptr = origin
+        const uint8_t t = trace_at(P, m, n);
+        const int dc = t & T_DIRMASK;
+        if ((dc == 2 || dc == 4 || dc == 6) && cnt < P.tcap - 1) out[cnt++] = make_int2(m, n);
+        if (dc == 1 || dc == 2) { --m; --n; }
+        else if (dc == 3 || dc == 4) {                  // H copied G or G2: walk the vertical run
+            const int ext = (t & T_SEL2) ? T_G2EXT : T_GEXT;
+            for (;;) {
+                const uint8_t u = trace_at(P, m, n);
+                --m;
+                if (!(u & ext) || m < a.left) break;
+            }
+        } else if (dc == 5 || dc == 6) {
+            const int ext = (t & T_SEL2) ? T_F2EXT : T_FEXT;
+            for (;;) {
+                const uint8_t u = trace_at(P, m, n);
+                --n;
+                if (!(u & ext) || n < b.left) break;
+            }
+        } else break;                                   // never written: corrupt
+    }
+    out[cnt++] = make_int2(a.left, b.left);             // origin record, fwd2c.h:144
+    *P.ntrace = cnt;
+}

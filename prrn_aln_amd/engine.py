@@ -1,0 +1,132 @@
+"""Thin Python glue over level 0 of the C ABI (include/g2g.h): run batches of flattened DP problems on
+the GPU.  All compute happens in libg2g.so (HIP); this module only marshals."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from . import _abi
+from ._lib import G2GError, last_error, lib
+
+
+class Context:
+    def __init__(self, device: int = -1):
+        L = lib()
+        self._h = L.g2g_create(device)
+        if not self._h:
+            raise G2GError("g2g_create failed: " + last_error())
+        if not L.g2g_device_ok(self._h):
+            msg = last_error()
+            L.g2g_destroy(self._h)
+            self._h = None
+            raise G2GError("no usable MI355X / gfx950 kernel image: " + msg)
+
+    def close(self):
+        if self._h:
+            lib().g2g_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _pp(holders: Sequence[_abi.ProblemHolder]):
+        n = len(holders)
+        arr = (C.POINTER(_abi.Problem) * n)()
+        for i, h in enumerate(holders):
+            arr[i] = C.pointer(h.c)
+        return arr
+
+    @staticmethod
+    def _results(res, n) -> List[Tuple[float, int, np.ndarray, int]]:
+        L = lib()
+        out = []
+        for i in range(n):
+            r = res[i]
+            tr = np.zeros((r.ntrace, 2), np.int32)
+            if r.ntrace and r.trace:
+                buf = np.ctypeslib.as_array(C.cast(r.trace, C.POINTER(C.c_int32)), shape=(r.ntrace * 2,))
+                tr[:] = buf.reshape(-1, 2)
+                L.g2g_free(r.trace)
+            out.append((r.score, r.cells, tr, r.status))
+        return out
+
+    def forward_batch(self, holders: Sequence[_abi.ProblemHolder]):
+        """alignC<recd_t> for every problem: [(score, cells, raw traceback (end->start), status)]."""
+        L = lib()
+        n = len(holders)
+        res = (_abi.Result * n)()
+        rc = L.g2g_forward_batch(self._h, n, self._pp(holders), res)
+        if rc:
+            raise G2GError("g2g_forward_batch rc=%d: %s" % (rc, last_error()))
+        return self._results(res, n)
+
+    def prepare(self, holders: Sequence[_abi.ProblemHolder]) -> "Batch":
+        L = lib()
+        h = C.c_void_p()
+        rc = L.g2g_batch_prepare(self._h, len(holders), self._pp(holders), C.byref(h))
+        if rc:
+            raise G2GError("g2g_batch_prepare rc=%d: %s" % (rc, last_error()))
+        return Batch(self, h, len(holders))
+
+
+class Batch:
+    """A sweep resident in HBM (inputs uploaded once); run() launches the kernels."""
+
+    def __init__(self, ctx: Context, h, n: int):
+        self.ctx, self._h, self.n = ctx, h, n
+
+    def run(self):
+        rc = lib().g2g_batch_run(self._h)
+        if rc:
+            raise G2GError("g2g_batch_run rc=%d: %s" % (rc, last_error()))
+
+    def times_ms(self) -> Tuple[float, float]:
+        a, b = C.c_float(0), C.c_float(0)
+        lib().g2g_batch_times(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def cells(self) -> int:
+        return lib().g2g_batch_cells(self._h)
+
+    def arena_bytes(self) -> int:
+        return lib().g2g_batch_arena_bytes(self._h)
+
+    def fetch(self):
+        res = (_abi.Result * self.n)()
+        rc = lib().g2g_batch_fetch(self._h, res)
+        if rc:
+            raise G2GError("g2g_batch_fetch rc=%d: %s" % (rc, last_error()))
+        return Context._results(res, self.n)
+
+    def free(self):
+        if self._h:
+            lib().g2g_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def stdskl(trace: np.ndarray) -> np.ndarray:
+    """stdskl() of the C ABI (host code in libg2g.so), reference src/gaps.cc:139."""
+    L = lib()
+    n = len(trace)
+    buf = (_abi.Skl * max(n, 1))()
+    for i in range(n):
+        buf[i].m = int(trace[i, 0]); buf[i].n = int(trace[i, 1])
+    nout = C.c_int(0)
+    p = L.g2g_stdskl(buf, n, C.byref(nout))
+    out = np.zeros((nout.value, 2), np.int32)
+    for i in range(nout.value):
+        out[i, 0] = p[i].m; out[i, 1] = p[i].n
+    L.g2g_free(p)
+    return out
