@@ -43,9 +43,24 @@ def lib():
     L.g2g_free.argtypes = [C.c_void_p]
     L.g2g_stdskl.restype = C.POINTER(_abi.Skl)
     L.g2g_stdskl.argtypes = [C.POINTER(_abi.Skl), C.c_int, C.POINTER(C.c_int)]
+    bind_level1(L)
     _lib = L
     return L
 
 
 def last_error() -> str:
     return lib().g2g_last_error().decode()
+
+
+def bind_level1(L):
+    L.g2g_group_create.restype = C.c_void_p
+    L.g2g_group_create.argtypes = [C.c_void_p, C.POINTER(_abi.Params), C.c_int, C.c_int, _abi.c_u8p, _abi.c_f64p]
+    L.g2g_group_free.argtypes = [C.c_void_p]
+    L.g2g_pwdm_create.restype = C.c_void_p
+    L.g2g_pwdm_create.argtypes = [C.c_void_p, C.POINTER(_abi.Params), C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    L.g2g_pwdm_free.argtypes = [C.c_void_p]
+    L.g2g_pwdm_problem.restype = C.POINTER(_abi.Problem)
+    L.g2g_pwdm_problem.argtypes = [C.c_void_p]
+    L.g2g_align2.argtypes = [C.c_void_p, C.c_void_p, _abi.c_f64p, C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int)]
+    L.g2g_align2_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), _abi.c_f64p,
+                                   C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int), C.POINTER(C.c_int)]

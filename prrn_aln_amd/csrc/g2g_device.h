@@ -25,7 +25,8 @@ struct DevSide {
     const double  *postgapdens;
 };
 
-enum { XH = 0, XG = 1, XG2 = 2, XF = 3, XF2 = 4, NX = 5 };
+// XBT / XBL: running records of the top / left boundary chains (2 ping-pong slots each)
+enum { XH = 0, XG = 1, XG2 = 2, XF = 3, XF2 = 4, XBT = 5, XBL = 6, NX = 7 };
 
 struct DevProb {
     int kind;            // 0 DPunit, 1 _hf, 2 _pf, 3 _nv   (reference src/dpunit.h:31-51)

@@ -283,7 +283,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
     HIPCHK(hipSetDevice(ctx->device));
     if (b->n == 0) return G2G_OK;
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL(g2g_forward_kernel, dim3(b->n), dim3(512), 0, ctx->stream, (const DevProb *) b->d_probs);
+    hipLaunchKernelGGL(g2g_forward_kernel, dim3(b->n), dim3(G2G_FWD_THREADS), 0, ctx->stream, (const DevProb *) b->d_probs);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     hipLaunchKernelGGL(g2g_traceback_kernel, dim3((b->n + 63) / 64), dim3(64), 0, ctx->stream, (const DevProb *) b->d_probs, b->n);

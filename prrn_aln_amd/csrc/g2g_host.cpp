@@ -1,10 +1,651 @@
-// g2g_host.cpp -- host-side pieces of the operator (no device code): stdskl.
-// (The level-1 builders -- mode selection, thickness, profile vectors, gap profiles -- land here too.)
+// g2g_host.cpp -- host side of level 1 (include/g2g.h): the operator surface mSeq / PwdM / align2().
+//
+// Everything the reference does on the CPU *around* the DP for one align2() call is restated here in
+// C++: residue/terminal-gap normalisation, column thickness, frequency and
+// profile vectors, static gap profiles, alignment-mode / scorer selection, the band, stdskl and the
+// end check with its sh = -100 retry.  The DP itself (row a1-a5) is NOT here: g2g_align2*() hand the
+// flattened problem to the GPU engine (g2g_engine.hip) and there is no host fallback.
+//
+// Residue codes are the reference's (src/cmn.h:111-114, src/seq.h:76-77): nil 0, gap 1, then
+// protein AMB 2, ALA 3 ... VAL 22, ASX 23, GLX 24; nucleotide A 2, C 3, G 5, T 9 (IUPAC bit codes + 1).
+#include <limits.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <vector>
 #include "../../include/g2g.h"
 #include "g2g_internal.h"
+
+namespace {
+
+enum { NIL_CODE = 0, GAP_CODE = 1 };
+enum { MOLC_PROTEIN = 1, MOLC_DNA = 2 };
+enum { RAWSEQ = 0, VECTOR = 1, VECPRO = 3 };                 // src/cmn.h:109
+enum { ASN = 5, ASP = 6, GLN = 8, GLU = 9, ASX = 23, GLX = 24 };   // src/cmn.h:112-113
+const int LARGEN = INT_MAX / 4 * 3;                          // src/aln.h:37
+const int NOL = 3;                                           // src/aln.h:29
+const int thr_gfq_21 = 8, thr_gfq_22 = 14;                   // src/maln.h:35-36
+
+inline bool IsGap(uint8_t c) { return c <= GAP_CODE; }
+
+struct Gfreq { int glen; double freq; int nres; };           // src/gfreq.h:25
+const Gfreq zerogfq = {0, 0, 0}, delmgfq = {-1, 0, 0};
+inline bool neogfq(const Gfreq &g) { return g.glen >= 0; }
+
+struct GapProfile {                                          // <-> class Gfq, src/gfreq.h:44-64
+    int hetero;
+    std::vector<int32_t> off[3], glen[3];
+    std::vector<double> freq[3];
+};
+
+}   // namespace
+
+// <-> mSeq (src/mseq.h:86-200) reduced to what the group-to-group DP reads
+struct g2g_group {
+    int many, len, left, right;
+    int molc, max_code;
+    int dels, nils, exgl, exgr;
+    bool has_weight;
+    double tgapf;
+    std::vector<uint8_t> seq;            // (len + 2) * many, position -1 first
+    std::vector<double> weight;
+    // derived lazily, like the reference (mkthick / convseq / Gfq on first use)
+    bool thk_done;
+    double sumwt;
+    int thk_len;
+    bool has_internalres;
+    std::vector<int> internal_pos;       // position of mSeq::internalres[i]
+    std::vector<double> thk;             // (thk_len + 2) * 3, index -1 first
+    int vect, nelm, felm, simdim_used;
+    std::vector<double> pseq;            // (len + 2) * nelm
+    GapProfile *gfq;
+    // flattened views handed to the engine
+    std::vector<double> thk_pos;         // (len + 2) * 3
+    std::vector<double> gapdens, postgapdens;
+
+    uint8_t at(int pos, int i) const { return seq[(size_t) (pos + 1) * many + i]; }
+    uint8_t &at(int pos, int i) { return seq[(size_t) (pos + 1) * many + i]; }
+    double *T(int j) { return &thk[(size_t) (j + 1) * 3]; }
+    ~g2g_group() { delete gfq; }
+};
+
+namespace {
+
+// mSeq::gapdensity / postgapdensity, src/mseq.h:148-160 (pointer order == position order per member)
+double gapdensity(const g2g_group &g, int pos, int i)
+{
+    const uint8_t c = g.at(pos, i);
+    if (c > GAP_CODE) return 0;
+    if (c == GAP_CODE || !g.has_internalres) return 1;
+    if (pos < g.internal_pos[i]) return g.exgl ? 0 : g.tgapf;
+    return g.exgr ? 0 : g.tgapf;
+}
+double postgapdensity(const g2g_group &g, int pos, int i)
+{
+    if (!g.has_internalres) return 1;    // the reference would dereference NULL only for nil codes, which then do not exist
+    if (g.at(pos, i) == NIL_CODE && pos < g.internal_pos[i]) return g.exgl ? 0 : g.tgapf;
+    if (g.at(pos + 1, i) == NIL_CODE && pos >= g.internal_pos[i]) return g.exgr ? 0 : g.tgapf;
+    return 1;
+}
+
+// Seq::exg_seq(gl, gr), src/seq.cc:858-888 (algmode.qck == 0)
+void exg_seq(g2g_group &g, int gl, int gr)
+{
+    g.exgl = gl ? 1 : 0;
+    g.exgr = gr ? 1 : 0;
+    gl = gl || g.tgapf < 1;
+    gr = gr || g.tgapf < 1;
+    const uint8_t codel = gl ? NIL_CODE : GAP_CODE, coder = gr ? NIL_CODE : GAP_CODE;
+    for (int i = 0; i < g.many; ++i) { g.at(-1, i) = codel; g.at(g.len, i) = coder; }
+    g.nils = gl || gr;
+    for (int i = 0; i < g.many; ++i) {
+        int s = 0;
+        for ( ; s < g.len; ++s) {
+            if (IsGap(g.at(s, i))) g.at(s, i) = codel; else break;
+        }
+        if (s >= g.len && (gl || !gr)) continue;
+        for (s = g.len - 1; s > 0; --s) {
+            if (IsGap(g.at(s, i))) g.at(s, i) = coder; else break;
+        }
+    }
+}
+
+// mSeq::mkthick, src/mseq.cc:149-354 (quick mode / DiThk is off this path)
+void mkthick(g2g_group &g)
+{
+    if (g.thk_done) return;
+    g.thk_done = true;
+    const int many = g.many, len = g.len;
+    const bool vwt1 = g.has_weight && many > 1;              // weight && unit_mode(), inex.prof == 0
+    if (vwt1 && g.sumwt == 0) { for (int i = 0; i < many; ++i) g.sumwt += g.weight[i]; }
+    else if (g.sumwt == 0) g.sumwt = many;
+    const double sumwt = g.sumwt;
+    double wt1 = 1;
+    const double ltgapf = g.exgl ? 0 : g.tgapf, rtgapf = g.exgr ? 0 : g.tgapf;
+    g.has_internalres = g.dels || g.nils;
+    if (g.has_internalres) g.internal_pos.assign(many, 0);
+    const int thk_len = g.thk_len = g.dels ? len : (g.has_internalres ? 2 : 0);
+    g.thk.assign((size_t) (thk_len + 2) * 3, 0.);
+    if (thk_len == 0) {
+        double *t = g.T(-1); t[0] = sumwt; t[1] = 0; t[2] = sumwt;
+        t = g.T(0); t[0] = sumwt; t[1] = 0; t[2] = sumwt;
+        return;
+    }
+    { double *t = g.T(-1); t[0] = 0; t[1] = t[2] = sumwt * ltgapf; }
+    { double *t = g.T(thk_len); t[0] = t[2] = 0; t[1] = sumwt * rtgapf; }
+    std::vector<char> egap(many);
+    int fpos = 0, rk = 0;
+    if (ltgapf < 1.) {                                        // right-most left end gap
+        std::fill(egap.begin(), egap.end(), 1);
+        while (fpos < len) {
+            double w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+            int c = 0;
+            for (int i = 0; i < many; ++i) {
+                if (vwt1) wt1 = g.weight[i];
+                const uint8_t ch = g.at(fpos, i);
+                if (ch == NIL_CODE) { w0 += wt1; ++c; }
+                else {
+                    if (egap[i]) { egap[i] = 0; g.internal_pos[i] = fpos; w3 += wt1; }
+                    if (ch == GAP_CODE) w1 += wt1; else w2 += wt1;
+                }
+            }
+            double *t = g.T(rk);
+            t[0] = w2; t[1] = w1 + w0 * ltgapf; t[2] = w1 + w2 + w0 * ltgapf;
+            ++rk; ++fpos;
+            (void) w3;
+            if (c == 0) break;
+        }
+    } else if (g.has_internalres) {
+        for (int i = 0; i < many; ++i) g.internal_pos[i] = 0;
+        double *t = g.T(rk); t[0] = sumwt; t[1] = 0; t[2] = sumwt;
+    }
+    const int lk = rk;
+    int rpos = len;
+    if (rtgapf < 1.) {                                        // left-most right end gap
+        std::fill(egap.begin(), egap.end(), 1);
+        int rk2 = thk_len;
+        while (rpos > 0) {
+            double w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0;
+            int c = 0;
+            for (int i = many; --i >= 0; ) {
+                if (vwt1) wt1 = g.weight[i];
+                const uint8_t ch = g.at(rpos - 1, i);
+                if (ch == NIL_CODE) { w0 += wt1; ++c; }
+                else {
+                    if (egap[i]) { w3 += wt1; egap[i] = 0; } else w4 += wt1;
+                    if (ch == GAP_CODE) w1 += wt1; else w2 += wt1;
+                }
+            }
+            --rk2;
+            if (rk2 >= -1) { double *t = g.T(rk2); t[0] = w2; t[1] = w1 + w0 * rtgapf; t[2] = w4 + (w0 + w3) * rtgapf; }
+            --rpos;
+            if (c == 0) break;
+        }
+    }
+    if (g.dels) {
+        rk = lk;
+        while (fpos < rpos) {
+            double w1 = 0, w2 = 0;
+            for (int i = 0; i < many; ++i) {
+                if (vwt1) wt1 = g.weight[i];
+                if (g.at(fpos, i) == GAP_CODE) w1 += wt1; else w2 += wt1;
+            }
+            double *t = g.T(rk); t[0] = w2; t[1] = w1; t[2] = sumwt;
+            ++rk; ++fpos;
+        }
+    }
+}
+
+// SeqThk per position as mSeqItr yields it (src/mseq.h:222-250, src/mseq.cc:768-790)
+void flatten_thk(g2g_group &g)
+{
+    const int mode = g.dels ? 2 : (g.nils ? 1 : 0);
+    g.thk_pos.resize((size_t) (g.len + 2) * 3);
+    for (int pos = -1; pos <= g.len; ++pos) {
+        int j;
+        if (mode == 2) j = pos;
+        else if (mode == 1) j = pos < 0 ? -1 : (pos >= g.len - 1 ? 1 : 0);
+        else j = -1;
+        const double *t = g.T(j);
+        double *o = &g.thk_pos[(size_t) (pos + 1) * 3];
+        o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+    }
+}
+
+// ---- static gap profiles: Gfq::Gfq(mSeq*) + seq2gfq, src/gfreq.cc:86-114,134-228,247-312 -----------
+int ipack(Gfreq *gf, Gfreq a, int endg)
+{
+    Gfreq tmp;
+    Gfreq *kf = gf, *nf = gf;
+    do {
+        tmp = *kf++;
+        if (endg || a.nres) *nf++ = a;
+        a = tmp;
+    } while (neogfq(tmp));
+    *nf = delmgfq;
+    return (int) (nf - gf);
+}
+void accume(Gfreq *gf, Gfreq *kf)
+{
+    double s = 0;
+    while (--kf >= gf) kf->freq = s += kf->freq;
+}
+
+struct GfqBuilder {
+    g2g_group &g;
+    int grain;
+    std::vector<Gfreq> buf;
+    Gfreq *sbuf, *tbuf, *rbuf;
+    std::vector<int> lbuf;
+    explicit GfqBuilder(g2g_group &gg) : g(gg), grain(1) {}
+
+    int seq2gfq(int kk, int pos)
+    {
+        Gfreq a = zerogfq, b = delmgfq;
+        Gfreq *cf = sbuf, *df = tbuf, *rf = rbuf;
+        double w = 1;
+        int endg = 0;
+        while (neogfq(*df)) {
+            df->glen += grain;
+            cf->glen = (df++)->glen;
+            cf->nres = 0;
+            (cf++)->freq = 0;
+        }
+        *cf = *df;
+        *rf = zerogfq;
+        for (int i = 0; i < g.many; ++i) {
+            int &ln = lbuf[i];
+            if (g.has_weight) w = g.weight[i];
+            const double bu = gapdensity(g, pos - 1, i);
+            const double cu = gapdensity(g, pos, i);
+            const double ru = postgapdensity(g, pos, i);
+            const uint8_t ch = g.at(pos, i);
+            if (cu > 0) {
+                if (ln == 0) { b.glen = 0; b.freq += w * cu; ++b.nres; }      // *-
+                ln += grain;                                                    // ?-
+            } else if (ch == NIL_CODE) {
+                if (ln == 0) ++endg;                                            // *.
+                ln += grain;                                                    // ..
+            } else if (g.at(pos - 1, i) == NIL_CODE && bu == 0) {               // .*
+                if (!neogfq(*cf)) {
+                    cf[1] = *cf;
+                    cf->freq = 0; cf->nres = 0;
+                    cf->glen = ln;
+                }
+                cf->freq += w; ++cf->nres;
+                if (ru > 0) { rf->freq += w * ru; ++rf->nres; }
+                ln = 0;
+            } else {
+                if (ru > 0) { rf->freq += w * ru; ++rf->nres; }                 // ?*
+                if (ln) {                                                       // -*
+                    Gfreq *hit = 0;                                             // bsearch over tbuf[0..kk) by glen
+                    int lo = 0, hi = kk - 1;
+                    while (lo <= hi) {
+                        int mid = (lo + hi) / 2;
+                        int d = ln - tbuf[mid].glen;
+                        if (d == 0) { hit = tbuf + mid; break; }
+                        if (d < 0) hi = mid - 1; else lo = mid + 1;
+                    }
+                    if (hit) {
+                        hit->freq -= bu * w; --hit->nres;
+                        cf = sbuf + (hit - tbuf);
+                        cf->freq += w; ++cf->nres;
+                    }
+                } else { a.freq += w; ++a.nres; }                               // **
+                ln = 0;
+            }
+        }
+        kk = ipack(sbuf, a, 0);
+        accume(sbuf, sbuf + kk);
+        kk = ipack(tbuf, b, endg);
+        if (rf->nres == 0) --rf;
+        for (df = tbuf; neogfq(*df); ++df) {
+            *++rf = *df;
+            rf->glen += grain;
+        }
+        *++rf = *df;
+        return kk;
+    }
+
+    static void emit(GapProfile *gp, int v, const Gfreq *l)
+    {
+        gp->off[v].push_back((int32_t) gp->glen[v].size());
+        for ( ; ; ++l) {
+            gp->glen[v].push_back(l->glen);
+            gp->freq[v].push_back(l->freq);
+            if (!neogfq(*l)) break;
+        }
+    }
+
+    GapProfile *build()
+    {
+        // only groups with inex.dels get a gap profile (mSeq::convseq, src/mseq.cc:507)
+        GapProfile *gp = new GapProfile();
+        const double ltgapf = g.exgl ? 0 : g.tgapf;
+        int kk = g.many + 2;
+        buf.assign((size_t) 3 * kk + 3, delmgfq);
+        sbuf = buf.data(); tbuf = sbuf + kk; rbuf = tbuf + kk;
+        lbuf.assign(g.many, 0);
+        int htr = 0;
+        // position -1 (gfreq.cc:264-282)
+        emit(gp, 0, &delmgfq);
+        if (ltgapf > 0) {
+            Gfreq lead[2] = {{0, g.sumwt * ltgapf, g.many}, delmgfq};
+            sbuf[0] = rbuf[0] = lead[0];
+            emit(gp, 1, lead);
+            emit(gp, 2, lead);
+        } else {
+            emit(gp, 1, &delmgfq);
+            emit(gp, 2, &delmgfq);
+        }
+        kk = 1;
+        for (int pos = 0; pos < g.len; ++pos) {
+            kk = seq2gfq(kk, pos);
+            if (kk > htr) htr = kk;
+            emit(gp, 0, sbuf);
+            emit(gp, 1, tbuf);
+            emit(gp, 2, rbuf);
+        }
+        for (int v = 0; v < 3; ++v) gp->off[v].push_back((int32_t) gp->glen[v].size());
+        gp->hetero = htr + 1;
+        return gp;
+    }
+};
+
+// ---- frequency / profile vectors: mSeq::convseq, src/mseq.cc:447-587 -------------------------------
+const int nbits_t[16] = {0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4};        // src/mseq.h:42-43
+const int amblist[] = {2,3,2,3,5,2,5,3,5,2,3,5,9,2,9,3,9,2,3,9,5,9,2,5,9,3,5,9,2,3,5,9};   // :45-46 (A=2 C=3 G=5 T=9)
+const int ambaddr[] = {0, 0, 0, 1, 2, 4, 5, 7, 9, 12, 13, 15, 17, 20, 22, 25, 28};      // :49-50
+const int decompact[6] = {0, 1, 2, 3, 5, 9};                                       // :41
+
+void ntor(double *v, int k, double w)                        // mSeq::ntor, src/mseq.cc:366-384
+{
+    switch (k) {
+    case 0: v[NIL_CODE] += w; break;
+    case 1: v[GAP_CODE] += w; break;
+    case 2: v[2] += w; break;
+    case 3: v[3] += w; break;
+    case 5: v[4] += w; break;
+    case 9: v[5] += w; break;
+    default: {
+        if (k < 1 || k > 16) break;
+        const int m = nbits_t[k - GAP_CODE];
+        w /= m;
+        const int *j = amblist + ambaddr[k];
+        for (int n = 0; n < m; ++n) v[*j++] += w;
+        break; }
+    }
+}
+
+struct Matrix { const double *m; int dim, rows; double at(int i, int j) const { return m[(size_t) i * dim + j]; } };
+
+void convseq(g2g_group &g, int vect, const Matrix &sm)
+{
+    // (mkthick and the gap profile are made by the caller in the reference's order)
+    const int many = g.many, len = g.len;
+    if (g.vect == RAWSEQ) {
+        if (vect == RAWSEQ) return;
+        g.felm = (g.molc == MOLC_PROTEIN) ? ASX : 6;          // prepseq, src/mseq.cc:485-502 (simmtx not set yet)
+        g.nelm = g.felm + 1;
+        const int eth = g.nelm - 1;
+        g.pseq.assign((size_t) (len + 2) * g.nelm, 0.);
+        std::vector<double> wtb(many);
+        for (int i = 0; i < many; ++i) wtb[i] = g.has_weight ? g.weight[i] : 1;
+        for (int pos = -1; pos <= len; ++pos) {
+            double *v = &g.pseq[(size_t) (pos + 1) * g.nelm];
+            if (g.molc == MOLC_PROTEIN) {                     // aas2cvec :455-476
+                for (int i = 0; i < many; ++i) {
+                    const int k = g.at(pos, i);
+                    const double wt = wtb[i];
+                    if (k == ASX) { v[ASN] += wt / 2; v[ASP] += wt / 2; }
+                    else if (k == GLX) { v[GLN] += wt / 2; v[GLU] += wt / 2; }
+                    else if (k < g.nelm) v[k] += wt;
+                }
+            } else {                                          // nuc2cvec :447-453
+                for (int i = 0; i < many; ++i) ntor(v, g.at(pos, i), wtb[i]);
+            }
+            double e = 0;
+            for (int i = 0; i < many; ++i)
+                if (g.at(pos, i) == GAP_CODE) e += g.has_weight ? g.weight[i] : 1;
+            v[eth] = e;
+        }
+        g.vect = VECTOR;
+    }
+    if (g.vect == vect) return;
+    if (vect == VECPRO && sm.m) {
+        const int felm = g.felm, nnelm = felm + sm.dim + 1, eth = nnelm - 1;
+        std::vector<double> np((size_t) (len + 2) * nnelm, 0.);
+        for (int pos = -1; pos <= len; ++pos) {
+            const double *w = &g.pseq[(size_t) (pos + 1) * g.nelm];
+            double *nst = &np[(size_t) (pos + 1) * nnelm];
+            double *v = nst + felm;
+            for (int j = 0; j < felm; ++j) nst[j] = w[j];
+            if (g.molc != MOLC_PROTEIN) {                     // profile_n :392-411
+                v[NIL_CODE] = 0;
+                for (int i = 1; i < felm; ++i) {
+                    const int k = decompact[i];
+                    v[k] = 0;
+                    for (int j = 1; j < felm; ++j) v[k] += sm.at(k, decompact[j]) * w[j];
+                }
+                for (int i = 3 + 1; i < g.max_code; ++i) {    // `C` = 3
+                    const int m = nbits_t[i - GAP_CODE];
+                    if (m == 1) continue;
+                    v[i] = 0;
+                    const int *j = amblist + ambaddr[i];
+                    for (int n = 0; n < m; ++n) v[i] += v[*j++];
+                    v[i] /= m;
+                }
+            } else if (sm.dim == sm.rows) {                   // profile_p :413-424
+                v[NIL_CODE] = 0;
+                for (int i = 1; i < felm; ++i) {
+                    v[i] = 0;
+                    for (int j = 1; j < felm; ++j) v[i] += sm.at(i, j) * w[j];
+                }
+                v[ASX] = (v[ASN] + v[ASP]) / 2;
+                v[GLX] = (v[GLN] + v[GLU]) / 2;
+            } else {                                          // profile :426-435
+                v[NIL_CODE] = 0;
+                for (int i = 1; i < sm.dim; ++i) {
+                    v[i] = 0;
+                    for (int j = 1; j < felm; ++j) v[i] += sm.at(i, j) * w[j];
+                }
+            }
+            nst[eth] = w[felm];
+        }
+        g.pseq.swap(np);
+        g.nelm = nnelm;
+        g.vect = VECPRO;
+    }
+}
+
+void ensure_gfq(g2g_group &g)
+{
+    if (g.dels && !g.gfq) { GfqBuilder b(g); g.gfq = b.build(); }
+}
+
+}   // namespace
+
+// <-> PwdM (src/maln.h:144-329, ctor src/maln2.cc:254-491) + PwdB (src/aln.h:228, src/aln2.cc:97-138)
+struct g2g_pwdm {
+    g2g_group *a, *b;
+    g2g_params prm;
+    int swp;
+    int alnmode, a_mode, b_mode, aprof, bprof;
+    g2g_problem prob;
+};
+
+namespace {
+
+void fill_side(g2g_group &g, g2g_side &s, bool ntv)
+{
+    memset(&s, 0, sizeof s);
+    s.many = g.many; s.len = g.len; s.left = g.left; s.right = g.right;
+    s.nils = g.nils; s.dels = g.dels;
+    s.seq = g.seq.data();
+    s.weight = 0;
+    s.nelm = g.vect ? g.nelm : 0; s.felm = g.vect ? g.felm : 0;
+    s.pseq = g.vect ? g.pseq.data() : 0;
+    flatten_thk(g);
+    s.thk = g.thk_pos.data();
+    s.has_gfq = (g.gfq && g.dels) ? 1 : 0;
+    if (s.has_gfq) {
+        s.gfq.hetero = g.gfq->hetero;
+        for (int v = 0; v < 3; ++v) {
+            s.gfq.off[v] = g.gfq->off[v].data();
+            s.gfq.glen[v] = g.gfq->glen[v].data();
+            s.gfq.freq[v] = g.gfq->freq[v].data();
+        }
+    }
+    if (ntv) {
+        const size_t n = (size_t) (g.len + 2) * g.many;
+        g.gapdens.assign(n, 0.); g.postgapdens.assign(n, 0.);
+        for (int pos = -1; pos < g.len; ++pos)
+            for (int i = 0; i < g.many; ++i) {
+                g.gapdens[(size_t) (pos + 1) * g.many + i] = gapdensity(g, pos, i);
+                g.postgapdens[(size_t) (pos + 1) * g.many + i] = postgapdensity(g, pos, i);
+            }
+        s.gapdens = g.gapdens.data(); s.postgapdens = g.postgapdens.data();
+    }
+}
+
+// stripe(), src/aln2.cc:156-174
+void stripe(const g2g_group &a, const g2g_group &b, int sh, int *lw, int *up)
+{
+    if (sh < 0) {
+        int shorter = std::min(a.right - a.left, b.right - b.left);
+        sh = -sh * shorter / 100;
+    }
+    int u = b.right - a.right, l = b.left - a.left;
+    if (u < l) std::swap(u, l);
+    u += sh; l -= sh;
+    int p;
+    if ((p = b.right - a.left) < u) u = p;
+    if ((p = b.left - a.right) > l) l = p;
+    *lw = l; *up = u;
+}
+
+}   // namespace
+
+extern "C" g2g_group *g2g_group_create(g2g_ctx *, const g2g_params *prm, int many, int len,
+                                       const uint8_t *seq, const double *weight)
+{
+    if (!prm || many < 1 || len < 1 || !seq) { g2g_set_error("%s", "g2g_group_create: bad argument"); return NULL; }
+    g2g_group *g = new g2g_group();
+    g->many = many; g->len = len; g->left = 0; g->right = len;
+    g->molc = prm->molc; g->max_code = prm->max_code;
+    g->tgapf = prm->tgapf;
+    g->seq.assign((size_t) (len + 2) * many, GAP_CODE);
+    memcpy(&g->seq[many], seq, (size_t) len * many);
+    g->has_weight = weight != 0;
+    if (weight) g->weight.assign(weight, weight + many);
+    g->dels = 0;                                             // Seq::test_gap_amb, src/seq.cc:890-906
+    for (size_t k = 0; k < (size_t) len * many; ++k) if (IsGap(seq[k])) { g->dels = 1; break; }
+    g->thk_done = false; g->sumwt = 0; g->thk_len = 0; g->has_internalres = false;
+    g->vect = RAWSEQ; g->nelm = g->felm = 0; g->gfq = 0; g->nils = 0; g->exgl = g->exgr = 0;
+    exg_seq(*g, 0, 0);                                       // Prrn::gather / aln_main: global, both ends
+    return g;
+}
+
+extern "C" void g2g_group_free(g2g_group *g) { delete g; }
+
+extern "C" g2g_pwdm *g2g_pwdm_create(g2g_ctx *, const g2g_params *prm, g2g_group *ga, g2g_group *gb, int *swapped)
+{
+    if (!prm || !ga || !gb) { g2g_set_error("%s", "g2g_pwdm_create: bad argument"); return NULL; }
+    if (prm->u0 > 0) { g2g_set_error("%s", "ether scorers (u0 > 0) are not on this path"); return NULL; }
+    g2g_pwdm *P = new g2g_pwdm();
+    P->prm = *prm;
+    g2g_group *sq[2] = {ga, gb};
+    const Matrix sm = {prm->simmtx, prm->simdim, prm->simrows};
+    // --- PwdB (before any swap) ---
+    const float f_scale = (float) prm->scale, f_u = (float) prm->u, f_v = (float) prm->v, f_u1 = (float) prm->u1;
+    const int DvsP = (ga->molc == MOLC_PROTEIN) + 2 * (gb->molc == MOLC_PROTEIN);
+    const int Noll = std::max(2, std::min(NOL, (int) prm->ls));
+    const double VabB = (double) (f_scale * ga->many * gb->many);          // axbscale, src/seq.h:1468 (float arithmetic)
+    const double BasicGOP = (double) (-f_v * VabB), BasicGEP = (double) (-f_u * VabB), LongGEP = (double) (-f_u1 * VabB);
+    const double diffu = LongGEP - BasicGEP;
+    const double LongGOP = BasicGOP - diffu * prm->k1;
+    const int step = (DvsP == 3) ? 1 : 3;
+    const int codonk1 = prm->ls == 3 ? step * prm->k1 : LARGEN;
+    // --- PwdM::selAlnMode, src/maln2.cc:81-154 ---
+    int aprof = 0, bprof = 0, abgfq = 0;
+    {   // advised_sim2 :43-60
+        const int i = sq[0]->many < sq[1]->many, j = 1 - i;
+        const int ni = sq[i]->many, nj = sq[j]->many, nt = 2 * nj + ni;
+        if (nt >= thr_gfq_21) {
+            bool apf = nt >= thr_gfq_22 || nj == 1;
+            bool bpf = nj > sq[j]->max_code;
+            if (i) std::swap(apf, bpf);
+            aprof = apf; bprof = bpf;
+            abgfq = 1;
+        }
+    }
+    const bool agfq = sq[0]->dels, bgfq = sq[1]->dels;
+    int alnmode;
+    if (!agfq && !bgfq) alnmode = G2G_NGP_ALN;
+    else if (!abgfq) alnmode = G2G_NTV_ALN;                  // htr == 0: no DNA x protein on this path
+    else if (!agfq) alnmode = G2G_RHF_ALN;
+    else if (!bgfq) alnmode = G2G_HLF_ALN;
+    else alnmode = G2G_GPF_ALN;
+    if (prm->banded) alnmode += G2G_NTV_ALN;
+    int swp;
+    switch (alnmode) {
+    case G2G_HLF_ALN: case G2G_HLF_ALB: swp = 0; break;
+    case G2G_RHF_ALN: case G2G_RHF_ALB: swp = 1; break;
+    case G2G_GPF_ALN: case G2G_GPF_ALB: swp = !aprof && bprof; break;
+    case G2G_NTV_ALN: swp = (sq[0]->right - sq[0]->left) < (sq[1]->right - sq[1]->left); break;
+    default: swp = 0; break;                                 // a->inex.intr: no spliced input here
+    }
+    if (swp) { std::swap(sq[0], sq[1]); std::swap(aprof, bprof); }
+    g2g_group &a = *sq[0], &b = *sq[1];
+    // exg_seq(lcl & 1, lcl & 2): algmode.lcl == 0 (global) -> already done at creation
+    // mSeq::convseq begins with mkthick + gap profile (src/mseq.cc:506-507)
+    mkthick(a); ensure_gfq(a);
+    if (aprof) { convseq(a, VECTOR, sm); convseq(a, VECPRO, sm); }
+    mkthick(b); ensure_gfq(b);
+    if (bprof) { convseq(b, VECTOR, sm); if (!aprof) convseq(b, VECPRO, sm); }
+    // --- rest of the PwdM ctor :266-285 ---
+    const double *wta = a.has_weight ? a.weight.data() : 0, *wtb = b.has_weight ? b.weight.data() : 0;
+    if (wta && !wtb && !bprof) { b.weight.assign(b.many, 1.); b.has_weight = true; wtb = b.weight.data(); }
+    if (wtb && !wta && !aprof) { a.weight.assign(a.many, 1.); a.has_weight = true; wta = a.weight.data(); }
+    const bool wwt = wta && wtb;
+    const int a_mode = aprof ? 2 : a.many > 1, b_mode = bprof ? 2 : b.many > 1;
+    int sim2 = -1, crg2 = 0;
+    switch (3 * a_mode + b_mode) {                           // :347-399 (u0 == 0 branch)
+    case 0: sim2 = G2G_SIM11; crg2 = 11; break;
+    case 1: if (wtb) { sim2 = G2G_SIM12W; crg2 = 121; } else { sim2 = G2G_SIM12I; crg2 = 120; } break;
+    case 2: sim2 = G2G_SIM13; break;
+    case 3: if (wta) { sim2 = G2G_SIM21W; crg2 = 211; } else { sim2 = G2G_SIM21I; crg2 = 210; } break;
+    case 4: if (wwt) { sim2 = G2G_SIM22W; crg2 = 221; } else { sim2 = G2G_SIM22I; crg2 = 220; } break;
+    case 5: sim2 = wta ? G2G_SIM23W : G2G_SIM23I; break;
+    case 6: sim2 = G2G_SIM31; break;
+    case 7: sim2 = wtb ? G2G_SIM32W : G2G_SIM32I; break;
+    case 8: sim2 = (DvsP == 0) ? G2G_SIM33N : G2G_SIM33; break;
+    }
+    P->a = &a; P->b = &b; P->swp = swp; P->alnmode = alnmode;
+    P->a_mode = a_mode; P->b_mode = b_mode; P->aprof = aprof; P->bprof = bprof;
+    // --- flatten ---
+    g2g_problem &q = P->prob;
+    memset(&q, 0, sizeof q);
+    q.alnmode = alnmode; q.sim2_kind = sim2;
+    const bool ntv = alnmode == G2G_NTV_ALB || alnmode == G2G_NTV_ALN;
+    q.crg2_kind = ntv ? crg2 : 0;
+    q.noll = Noll; q.codonk1 = codonk1;
+    q.basic_gop = (double) (-f_scale * f_v);                 // resetuab, src/maln2.cc:227-243 (float arithmetic)
+    q.weighted_gop = (double) -f_v;
+    q.u = (double) f_u;
+    q.u2divu1 = BasicGEP < 0 ? LongGEP / BasicGEP : 0;       // Fwd2c ctor, src/fwd2c.h:85-86
+    q.v2divv1 = BasicGOP < 0 ? LongGOP / BasicGOP : 0;
+    q.simmtx = prm->simmtx; q.simdim = prm->simdim; q.simrows = prm->simrows;
+    fill_side(a, q.a, ntv);
+    fill_side(b, q.b, ntv);
+    q.a.weight = wta; q.b.weight = wtb;
+    stripe(a, b, prm->sh, &q.lw, &q.up);
+    if (swapped) *swapped = swp;
+    return P;
+}
+
+extern "C" void g2g_pwdm_free(g2g_pwdm *p) { delete p; }
+extern "C" const g2g_problem *g2g_pwdm_problem(const g2g_pwdm *p) { return p ? &p->prob : 0; }
 
 // <-> stdskl(SKL**), reference src/gaps.cc:139-174: order the raw traceback by (m, n), drop repeats and
 // inconsistent steps, and make every diagonal/gap junction explicit.  Output: ascending corners
@@ -44,4 +685,52 @@ extern "C" g2g_skl *g2g_stdskl(const g2g_skl *in, int num, int *nout)
     free(org);
     *nout = w;
     return std_;
+}
+
+// <-> align2(), src/maln2.cc:1875-1973 for the Fwd2c modes: forward + traceback on the GPU, stdskl,
+// end check; on a mismatch the band is reopened to sh = -100 and the DP repeated (:1946-1952).
+extern "C" int g2g_align2_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *pw, double *scr,
+                                g2g_skl **skl, int *nskl, int *status)
+{
+    if (!ctx || n < 0 || (n && (!pw || !scr || !skl || !nskl))) return G2G_ERR_ARG;
+    std::vector<int> todo(n), st(n, G2G_OK);
+    for (int i = 0; i < n; ++i) { todo[i] = i; skl[i] = 0; nskl[i] = 0; scr[i] = 0; }
+    for (int pass = 0; pass < 2 && !todo.empty(); ++pass) {
+        std::vector<const g2g_problem *> pp;
+        for (int i : todo) pp.push_back(&pw[i]->prob);
+        std::vector<g2g_result> rr(pp.size());
+        int rc = g2g_forward_batch(ctx, (int) pp.size(), pp.data(), rr.data());
+        if (rc) return rc;
+        std::vector<int> again;
+        for (size_t k = 0; k < todo.size(); ++k) {
+            const int i = todo[k];
+            g2g_pwdm *P = pw[i];
+            if (rr[k].status) { st[i] = rr[k].status; continue; }
+            int ns = 0;
+            g2g_skl *s = g2g_stdskl(rr[k].trace, rr[k].ntrace, &ns);
+            g2g_free(rr[k].trace);
+            const g2g_group &a = *P->a, &b = *P->b;
+            if (ns < 1 || s[0].m != a.left || s[ns - 1].m != a.right || s[0].n != b.left || s[ns - 1].n != b.right) {
+                g2g_free(s);
+                if (pass == 0) {                              // pwdm->alnprm.sh = -100; goto retry
+                    P->prm.sh = -100;
+                    stripe(a, b, -100, &P->prob.lw, &P->prob.up);
+                    again.push_back(i);
+                } else st[i] = G2G_ERR_ENDS;
+                continue;
+            }
+            scr[i] = rr[k].score; skl[i] = s; nskl[i] = ns;
+        }
+        todo.swap(again);
+    }
+    int worst = G2G_OK;
+    for (int i = 0; i < n; ++i) { if (status) status[i] = st[i]; if (st[i] && !worst) worst = st[i]; }
+    return status ? G2G_OK : worst;
+}
+
+extern "C" int g2g_align2(g2g_ctx *ctx, g2g_pwdm *p, double *scr, g2g_skl **skl, int *nskl)
+{
+    if (!p) return G2G_ERR_ARG;
+    g2g_pwdm *pp[1] = {p};
+    return g2g_align2_batch(ctx, 1, pp, scr, skl, nskl, 0);
 }

@@ -18,6 +18,9 @@
 #include "g2g_device.h"
 
 #define NEVSEL (-(DBL_MAX / 16 * 7))      /* reference src/cmn.h:57 */
+#ifndef G2G_FWD_THREADS
+#define G2G_FWD_THREADS 256
+#endif
 
 // TraceBackDir values Fwd2c produces (src/aln.h:47-52) and their classes (:59-61)
 enum { D_DEAD = 0, D_DIAG = 2, D_NEWD = 3, D_VERT = 4, D_HORI = 8, D_NEWV = 12, D_NEWH = 13 };
@@ -412,40 +415,37 @@ __device__ void rec_copy(const DevProb &P, Rec dst, Rec src)
     }
 }
 
-// ---- Fwd2c::initB, src/fwd2c.h:138-176 : the two boundary chains (sequential by nature) ----------
+// ---- Fwd2c::initB, src/fwd2c.h:138-176 : the two boundary chains -----------------------------------
+// The chains are sequential by nature (corner k needs corner k-1) but each corner is only needed one
+// anti-diagonal before its first reader, so they are folded into the sweep: during step d one thread
+// advances the top chain to corner (a.left, d+1-a.left), another the left chain to corner
+// (d+1-b.left, b.left).  The running chain records live in their own slots (XBT / XBL, ping-pong),
+// because the H slot a corner is copied to is consumed in place by the diagonal update of its reader.
 template <int KIND>
-__device__ void init_top(const DevProb &P)
+__device__ void top_step(const DevProb &P, int n)           // corner (a.left, n), b.left < n <= a.left + rr
 {
     const DevSide &a = P.a, &b = P.b;
-    int n = b.left, r = n - a.left, rr = b.right - a.left;
-    const int ai = a.left - 1;
-    if (P.up < rr) rr = P.up;
-    for ( ; ++r <= rr; ) {
-        const int bi = n;                       // bsi points at column n before ++n (fwd2c.h:151-159)
-        ++n;
-        Rec h = {XH, r - (P.lw - 1)}, hp = {XH, r - 1 - (P.lw - 1)};
-        const double pub = unpb(P, bi, ai);
-        double gnp = gapopen<KIND>(P, hp, ai, bi, -1);
-        gnp = (n - b.left < P.codonk1) ? gnp + pub : (P.v2divv1 * gnp + P.u2divu1 * pub);
-        update<KIND>(P, h, hp, ai, bi, gnp, -1);
-    }
+    const int ai = a.left - 1, bi = n - 1;                   // bsi sits on column n-1 (fwd2c.h:151-159)
+    const int k = n - b.left;
+    const Rec cur = {XBT, k & 1}, prv = {XBT, (k - 1) & 1}, h = {XH, (n - a.left) - (P.lw - 1)};
+    const double pub = unpb(P, bi, ai);
+    double gnp = gapopen<KIND>(P, prv, ai, bi, -1);
+    gnp = (n - b.left < P.codonk1) ? gnp + pub : (P.v2divv1 * gnp + P.u2divu1 * pub);
+    update<KIND>(P, cur, prv, ai, bi, gnp, -1);
+    rec_copy<KIND>(P, h, cur);
 }
 template <int KIND>
-__device__ void init_left(const DevProb &P)
+__device__ void left_step(const DevProb &P, int m)          // corner (m, b.left), a.left < m <= b.left - rr
 {
     const DevSide &a = P.a, &b = P.b;
-    int m = a.left, r = b.left - a.left, rr = b.left - a.right;
-    int ai = a.left - 1;
-    const int bi = b.left - 1;
-    if (P.lw > rr) rr = P.lw;
-    while (--r >= rr) {
-        ++m; ++ai;
-        Rec h = {XH, r - (P.lw - 1)}, hp = {XH, r + 1 - (P.lw - 1)};
-        const double pua = unpa(P, ai, bi);
-        double gnp = gapopen<KIND>(P, hp, ai, bi, 1);
-        gnp = (m - a.left < P.codonk1) ? gnp + pua : (P.v2divv1 * gnp + P.u2divu1 * pua);
-        update<KIND>(P, h, hp, ai, bi, gnp, 1);
-    }
+    const int ai = m - 1, bi = b.left - 1;
+    const int k = m - a.left;
+    const Rec cur = {XBL, k & 1}, prv = {XBL, (k - 1) & 1}, h = {XH, (b.left - m) - (P.lw - 1)};
+    const double pua = unpa(P, ai, bi);
+    double gnp = gapopen<KIND>(P, prv, ai, bi, 1);
+    gnp = (m - a.left < P.codonk1) ? gnp + pua : (P.v2divv1 * gnp + P.u2divu1 * pua);
+    update<KIND>(P, cur, prv, ai, bi, gnp, 1);
+    rec_copy<KIND>(P, h, cur);
 }
 
 // ---- one DP cell: the body of the n-loop of forwardB, src/fwd2c.h:393-471 ------------------------
@@ -521,21 +521,31 @@ __device__ void run_forward(const DevProb &P)
             rec_reset<KIND>(P, r);
         }
     }
+    if (tid < 4) {                                      // chain slots
+        Rec r = {tid < 2 ? XBT : XBL, tid & 1};
+        rec_reset<KIND>(P, r);
+    }
     __syncthreads();
     if (tid == 0) {                                     // origin, fwd2c.h:145-149
         Rec h = {XH, (b.left - a.left) - (P.lw - 1)};
         val_of(P, h) = 0; P.dir[XH][h.i] = D_DIAG;
+        val_of(P, Rec{XBT, 0}) = 0; P.dir[XBT][0] = D_DIAG;
+        val_of(P, Rec{XBL, 0}) = 0; P.dir[XBL][0] = D_DIAG;
     }
     __syncthreads();
-    if (tid == 0) init_top<KIND>(P);
-    if (tid == 64 % nt && nt > 64) init_left<KIND>(P);
-    if (nt <= 64 && tid == 0) init_left<KIND>(P);
-    __syncthreads();
+    int rrt = b.right - a.left; if (P.up < rrt) rrt = P.up;          // last top-chain diagonal
+    int rrl = b.left - a.right; if (P.lw > rrl) rrl = P.lw;          // last left-chain diagonal
+    const int n_top_last = a.left + rrt, m_left_last = b.left - rrl;
     for (int d = P.d0; d <= P.d1; ++d) {
         int mlo, mhi;
         diag_rows(d, a.left, a.right, b.left, b.right, P.lw, P.up, &mlo, &mhi);
         uint8_t *trow = P.trace + (size_t)(d - P.d0) * P.tstride;
         for (int m = mlo + tid; m <= mhi; m += nt) cell<KIND, NOLL3>(P, m, d - m, trow + (m - mlo));
+        // boundary corners first read on anti-diagonal d + 1 (given to the threads with the fewest cells)
+        const int cnt = mhi >= mlo ? mhi - mlo + 1 : 0;
+        const int nb = d + 1 - a.left, mb = d + 1 - b.left;
+        if (tid == (cnt + nt - 1) % nt && nb > b.left && nb <= n_top_last) top_step<KIND>(P, nb);
+        if (tid == (cnt + nt - 2) % nt && mb > a.left && mb <= m_left_last) left_step<KIND>(P, mb);
         __syncthreads();
     }
     if (tid == 0) {
@@ -544,7 +554,7 @@ __device__ void run_forward(const DevProb &P)
     }
 }
 
-extern "C" __global__ void __launch_bounds__(512)
+extern "C" __global__ void __launch_bounds__(G2G_FWD_THREADS)
 g2g_forward_kernel(const DevProb *probs)
 {
     const DevProb &P = probs[blockIdx.x];

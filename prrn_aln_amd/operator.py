@@ -1,0 +1,150 @@
+"""Python mirror of the reference's operator surface for this path -- mSeq / PwdM / align2() -- on top of
+level 1 of the C ABI (include/g2g.h).  Names and argument meaning follow the reference
+(src/maln.h:276,342-344); the work is done by libg2g.so (host builders in C++, DP on the GPU)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _abi
+from ._lib import G2GError, last_error, lib
+
+PROTEIN, DNA = 1, 2
+
+# residue codes, reference src/cmn.h:111-114: NIL,UNP,AMB,ALA,ARG,ASN,ASP,CYS,GLN,GLU,GLY,HIS,ILE,LEU,
+# LYS,MET,PHE,PRO,SER,THR,TRP,TYR,VAL,ASX,GLX ; nucleotides ___,_,A,C,M,G,R,S,V,T,...
+_AA = {c: i + 3 for i, c in enumerate("ARNDCQEGHILKMFPSTWYV")}
+_AA.update({"B": 23, "Z": 24, "X": 2, "-": 1, ".": 1})
+_NT = {"A": 2, "C": 3, "M": 4, "G": 5, "R": 6, "S": 7, "V": 8, "T": 9, "U": 9, "W": 10, "Y": 11, "H": 12,
+       "K": 13, "D": 14, "B": 15, "N": 16, "-": 1, ".": 1}
+
+
+def encode(rows: Sequence[str], molc: int) -> np.ndarray:
+    """Aligned rows -> (len, many) uint8 residue codes ([pos][member], the layout of Seq::seq_)."""
+    tab = np.full(256, 2 if molc == PROTEIN else 16, np.uint8)
+    for k, v in (_AA if molc == PROTEIN else _NT).items():
+        tab[ord(k)] = v
+        tab[ord(k.lower())] = v
+    arr = np.frombuffer("".join(rows).encode(), np.uint8).reshape(len(rows), -1)
+    return np.ascontiguousarray(tab[arr].T)
+
+
+@dataclass
+class AlnParam:
+    """Subset of the reference's ALPRM (src/seq.h:27-28) with prrn's effective defaults
+    (PAM150 matrix, u=2, v=9, u1=0.6, k1=7, sh=-60, tgapf=1)."""
+    u: float = 2.0
+    v: float = 9.0
+    u0: float = 0.0
+    u1: float = 0.6
+    tgapf: float = 1.0
+    scale: float = 1.0
+    gamma: float = 0.5
+    k1: int = 7
+    ls: int = 1
+    sh: int = -60
+    banded: int = 1
+    molc: int = PROTEIN
+    simmtx: Optional[np.ndarray] = None
+    max_code: int = 25
+
+    def to_c(self) -> Tuple[_abi.Params, np.ndarray]:
+        sm = default_simmtx(self.molc) if self.simmtx is None else np.ascontiguousarray(self.simmtx, np.float64)
+        f32 = lambda x: float(np.float32(x))      # ALPRM fields are floats in the reference
+        p = _abi.Params()
+        p.u, p.v, p.u0, p.u1 = f32(self.u), f32(self.v), f32(self.u0), f32(self.u1)
+        p.tgapf, p.scale, p.gamma = f32(self.tgapf), f32(self.scale), f32(self.gamma)
+        p.k1, p.ls, p.sh, p.banded, p.molc = self.k1, self.ls, self.sh, self.banded, self.molc
+        p.simmtx = sm.ctypes.data_as(_abi.c_f64p)
+        p.simrows, p.simdim = sm.shape
+        p.max_code = self.max_code
+        return p, sm
+
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def default_simmtx(molc: int) -> np.ndarray:
+    """The substitution matrix prrn effectively uses (data dumped from the reference's Simmtx::mtx:
+    PAM150 for proteins, the +2/-2 style nucleotide matrix for DNA)."""
+    return np.load(os.path.join(_DATA, "simmtx_protein.npy" if molc == PROTEIN else "simmtx_dna.npy"))
+
+
+class mSeq:
+    """<-> reference class mSeq (src/mseq.h:86): one group = aligned members + optional weights."""
+
+    def __init__(self, rows_or_codes, alp: AlnParam, weight: Optional[Sequence[float]] = None):
+        L = lib()
+        codes = rows_or_codes if isinstance(rows_or_codes, np.ndarray) else encode(rows_or_codes, alp.molc)
+        codes = np.ascontiguousarray(codes, np.uint8)
+        self.len, self.many = codes.shape
+        self._prm, self._sm = alp.to_c()
+        w = None if weight is None else np.ascontiguousarray(weight, np.float64)
+        self._h = L.g2g_group_create(None, C.byref(self._prm), self.many, self.len,
+                                     codes.ctypes.data_as(_abi.c_u8p),
+                                     None if w is None else w.ctypes.data_as(_abi.c_f64p))
+        if not self._h:
+            raise G2GError(last_error())
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().g2g_group_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class PwdM:
+    """<-> reference class PwdM (src/maln.h:144, ctor src/maln2.cc:254): picks alnmode and scorer, swaps
+    the pair so that the profile side is `a` (self.swp), builds thickness / vectors / gap profiles."""
+
+    def __init__(self, seqs: Sequence[mSeq], alp: AlnParam):
+        L = lib()
+        self.seqs = list(seqs)
+        self._prm, self._sm = alp.to_c()
+        swp = C.c_int(0)
+        self._h = L.g2g_pwdm_create(None, C.byref(self._prm), seqs[0]._h, seqs[1]._h, C.byref(swp))
+        if not self._h:
+            raise G2GError(last_error())
+        self.swp = bool(swp.value)
+        self.problem = L.g2g_pwdm_problem(self._h).contents
+        self.alnmode = self.problem.alnmode
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().g2g_pwdm_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def align2_batch(ctx, pwds: Sequence[PwdM]):
+    """<-> align2(seqs, pwdm, &scr, GsI) for every PwdM of a sweep: [(scr, skl (n,2) int32, status)]."""
+    L = lib()
+    n = len(pwds)
+    hs = (C.c_void_p * n)(*[p._h for p in pwds])
+    scr = (C.c_double * n)()
+    skl = (C.POINTER(_abi.Skl) * n)()
+    nskl = (C.c_int * n)()
+    st = (C.c_int * n)()
+    rc = L.g2g_align2_batch(ctx._h, n, hs, scr, skl, nskl, st)
+    if rc:
+        raise G2GError("g2g_align2_batch rc=%d: %s" % (rc, last_error()))
+    out = []
+    for i in range(n):
+        s = np.zeros((nskl[i], 2), np.int32)
+        if nskl[i]:
+            s[:] = np.ctypeslib.as_array(C.cast(skl[i], C.POINTER(C.c_int32)), shape=(nskl[i] * 2,)).reshape(-1, 2)
+            L.g2g_free(skl[i])
+        out.append((scr[i], s, st[i]))
+    return out
+
+
+def align2(ctx, pwd: PwdM):
+    return align2_batch(ctx, [pwd])[0]
