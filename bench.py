@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- DP cells/s of the group-to-group DP hot path on one refinement sweep.
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): a synthetic family of 256 proteins
+x 1024 aa (prrn_aln_amd/synth.py, seed 1; true alignment as the start MSA), one full randiv sweep = the
+2N-3 = 509 tree-branch divisions, each re-aligned group-vs-rest by align2()'s DP (Fwd2c::forwardB +
+traceback, reference src/fwd2c.h:359,671).  A "step" = one pass over all 509 DPs.  Inputs (profiles, gap
+profiles, bands) are built on the host and uploaded BEFORE the timed region; the timed region is kernels +
+result fetch (+ the all-gather of result slots for N > 1).  Divisions are dealt round-robin by size to the
+ranks; total work is fixed, so scaling is "strong".
+
+    python bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = in-band cells x 33 B (A = 2*Noll*8 + 1)
+/ forward-kernel time measured with HIP events on the stream the kernel runs on.  `cpu_baseline` = the
+reference's own alignC<recd_t> (oracle/_ref, kind "reference") or, when that is absent, the C restatement
+(oracle/, kind "port"), one host core, on a bounded sample of the same divisions."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_CELL = {2: 33, 3: 49}          # 2*Noll*sizeof(double) + 1 direction byte
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(sw, budget_s):
+    """Reference (or port) CPU path on a bounded sample, 1 core.  Returns dict for the JSON line."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    order = list(sw.order)
+    # spread over the size range: every k-th division of the size-ordered list
+    pick = order[:: max(1, len(order) // 24)]
+    cells = 0
+    secs = 0.0
+    used = []
+    try:
+        import refdump
+        if not refdump.available():
+            raise ImportError("oracle/_ref not built")
+        from prrn_aln_amd.sweep import division_groups
+        R = refdump.RefLib(molc=sw.alp.molc, ls=sw.alp.ls if sw.alp.ls != 1 else 0)
+        inv = {v: k for k, v in __import__("prrn_aln_amd.operator", fromlist=["_AA"])._AA.items() if k.isupper() or k == "-"}
+        kind = "reference"
+        for k in pick:
+            side = sw.branches[k]
+            a, b, ia, ib = division_groups(sw.codes, side)
+            rows = lambda arr: ["".join(inv.get(int(c), "X") for c in arr[:, j]) for j in range(arr.shape[1])]
+            wa = None if sw.weights is None else [float(sw.weights[i]) for i in ia]
+            wb = None if sw.weights is None else [float(sw.weights[i]) for i in ib]
+            ga = R.group(["a%d" % i for i in ia], rows(a), wa)
+            gb = R.group(["b%d" % i for i in ib], rows(b), wb)
+            sec, c, mode, scr = R.forward_timed(ga, gb)
+            R.free(ga); R.free(gb)
+            cells += c; secs += sec; used.append(int(k))
+            if secs > budget_s:
+                break
+    except Exception as e:            # no reference build on this box: time the C restatement instead
+        import ctypes as C
+        import oraclelib
+        from prrn_aln_amd import _abi
+        L = oraclelib.load()
+        kind = "port"
+        cells, secs, used = 0, 0.0, []
+        for k in pick:
+            q = sw.pwds[k].problem
+            res = _abi.Result()
+            t = time.perf_counter()
+            L.g2g_oracle_forward(C.byref(q), C.byref(res))
+            secs += time.perf_counter() - t
+            L.g2g_oracle_free(res.trace)
+            cells += res.cells; used.append(int(k))
+            if secs > budget_s:
+                break
+    return {"value": cells / secs if secs else 0.0, "unit": "cells/s", "cores": 1, "kind": kind,
+            "sample": "%d of %d divisions spread over the size range (%.3g cells, %.1f s): forward fill + traceback only"
+                      % (len(used), len(sw), cells, secs)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nseq", type=int, default=256)
+    ap.add_argument("--length", type=int, default=1024)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--limit", type=int, default=0, help="use only the first LIMIT divisions (debug)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+
+    from prrn_aln_amd import engine, operator as op, sweep
+    from prrn_aln_amd.synth import make_family
+
+    fam = make_family(args.nseq, args.length, args.seed)
+    alp = op.AlnParam()
+    sw = sweep.Sweep(fam, alp, weighted=True, limit=args.limit or None)
+    mine = sweep.shard(sw.order, world, rank)
+    ctx = engine.Context(local_rank)
+    holders = [sw.pwds[k] for k in mine]
+
+    # inputs resident in HBM before the timed region
+    class _H:                                   # adapter: engine.Context wants objects with a `.c` Problem
+        def __init__(self, q): self.c = q
+    batch = ctx.prepare([_H(p.problem) for p in holders])
+    cap = 4096                                  # corners per result slot (longer skeletons flag -99)
+    nslots = (len(sw) + world - 1) // world
+
+    def step():
+        batch.run()
+        res = batch.fetch()
+        out = [(scr, engine.stdskl(tr), st) for (scr, cells, tr, st) in res]
+        if world > 1:
+            slots = torch.from_numpy(sweep.pack_slots(mine, out, cap, nslots)).cuda()
+            gathered = [torch.empty_like(slots) for _ in range(world)]
+            dist.all_gather(gathered, slots)
+            return out, gathered
+        return out, None
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fwd_ms = tb_ms = 0.0
+    for _ in range(args.steps):
+        out, gathered = step()
+        f, t = batch.times_ms()
+        fwd_ms += f; tb_ms += t
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    bad = [mine[i] for i, (scr, skl, st) in enumerate(out) if st != 0 or len(skl) < 2]
+    my_cells = int(sum(sw.cells[k] for k in mine))
+    total_cells = int(sw.cells.sum())
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        value = total_cells * args.steps / dt
+        fwd_avg_ms = fwd_ms / args.steps
+        noll = holders[0].problem.noll if holders else 2
+        ach = my_cells * BYTES_PER_CELL[noll] / (fwd_avg_ms * 1e-3) / 1e9 if fwd_avg_ms else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "DP cells/s (profile-profile fwd2) + SP-score delta vs ref, 256x1024aa refinement",
+            "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "prrn refinement sweep: %d proteins x %d aa (seed %d), start MSA %d columns, "
+                                   "%d tree-branch divisions (HLF/RHF %d, GPF %d), %.4g in-band cells/sweep, band sh=-60"
+                                   % (args.nseq, args.length, args.seed, len(fam.msa[0]), len(sw),
+                                      sum(1 for p in sw.pwds if p.alnmode in (7, 8)),
+                                      sum(1 for p in sw.pwds if p.alnmode == 9), total_cells),
+                       "divisions": len(sw), "cells_per_step": total_cells, "parallelism": "divisions round-robin by size over %d GPU(s)" % world,
+                       "failed_items": bad},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "g2g_forward_kernel", "kernel_ms": fwd_avg_ms, "traceback_ms": tb_ms / args.steps,
+                         "bytes_per_cell": BYTES_PER_CELL[noll], "cells_per_launch": my_cells},
+        }
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(sw, args.cpu_seconds)
+            if line["cpu_baseline"]["value"]:
+                line["config"]["gpu_over_cpu_1core"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <time.h>
 // compiled with -fno-access-control: the dump reads PwdM's private scalars and fn-pointers
 #include "aln.h"
 #include "mseq.h"
@@ -336,7 +337,46 @@ int ref_align_dump(void* ga, void* gb, const char* path)
 	return pwd.alnmode;
 }
 
-// Timed leg for bench.py's cpu_baseline (kind "reference"): PwdM + align2 only, no dump.
+// Timed leg for bench.py's cpu_baseline (kind "reference"): ONLY the hot path -- alignC<recd_t> =
+// Fwd2c ctor + forwardB + Vmf traceback (fwd2c.h:671-677) -- is inside the clock; PwdM (profiles, gap
+// profiles) is built before it starts.  Returns seconds; *cells = in-band cells (fwd2c.h:373-374,393).
+double ref_forward_timed(void* ga, void* gb, int64_t* cells, int* alnmode, double* score)
+{
+	mSeq*	sqs[3] = {(mSeq*) ga, (mSeq*) gb, 0};
+	sqs[0]->exg_seq(sqs[0]->inex.exgl, sqs[0]->inex.exgr);
+	sqs[1]->exg_seq(sqs[1]->inex.exgl, sqs[1]->inex.exgr);
+	PwdM	pwd(sqs);
+	mSeq*	a = sqs[0];
+	mSeq*	b = sqs[1];
+	if (alnmode) *alnmode = pwd.alnmode;
+	WINDOW	wdw;
+	stripe((const Seq**) sqs, &wdw, pwd.alnprm.sh);
+	int64_t	c = 0;
+	for (int m = a->left; m < a->right; ++m) {
+	    int	n = std::max(m + wdw.lw, b->left);
+	    int	n9 = std::min(m + wdw.up + 1, b->right);
+	    if (n9 > n) c += n9 - n;
+	}
+	if (cells) *cells = c;
+	VTYPE	scr = 0;
+	SKL*	raw = 0;
+	struct timespec t0, t1;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	switch (pwd.alnmode) {
+	    case NGP_ALB: raw = alignC<DPunit>(sqs, &pwd, &scr); break;
+	    case HLF_ALB:
+	    case RHF_ALB: raw = alignC<DPunit_hf>(sqs, &pwd, &scr); break;
+	    case GPF_ALB: raw = alignC<DPunit_pf>(sqs, &pwd, &scr); break;
+	    case NTV_ALB: raw = alignC<DPunit_nv>(sqs, &pwd, &scr); break;
+	    default: return -1;
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	delete[] raw;
+	if (score) *score = scr;
+	return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+}
+
+// Whole-operator timing (PwdM + align2), kept for reference (kind "reference"): PwdM + align2 only, no dump.
 // Returns the DP score; *cells receives the in-band cell count of forwardB (fwd2c.h:373-374,393).
 double ref_align_timed(void* ga, void* gb, int64_t* cells, int* alnmode)
 {

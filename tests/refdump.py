@@ -85,6 +85,9 @@ class RefLib:
         L.ref_align_timed.restype = ctypes.c_double
         L.ref_align_timed.argtypes = [ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]
+        L.ref_forward_timed.restype = ctypes.c_double
+        L.ref_forward_timed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
+                                        ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
         L.ref_set_tgapf.argtypes = [ctypes.c_double]
         if tgapf is not None:
             L.ref_set_tgapf(tgapf)
@@ -130,6 +133,14 @@ class RefLib:
             return parse_dump(path)
         finally:
             os.unlink(path)
+
+    def forward_timed(self, ga, gb):
+        """(seconds, cells, alnmode, score) of the reference's alignC<recd_t> alone."""
+        cells = ctypes.c_int64(0)
+        mode = ctypes.c_int(0)
+        scr = ctypes.c_double(0)
+        sec = self.lib.ref_forward_timed(ga, gb, ctypes.byref(cells), ctypes.byref(mode), ctypes.byref(scr))
+        return sec, cells.value, mode.value, scr.value
 
     def align_timed(self, ga, gb):
         cells = ctypes.c_int64(0)

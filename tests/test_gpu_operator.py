@@ -1,0 +1,77 @@
+"""The operator surface end to end on the GPU: groups -> PwdM (host builders) -> align2 (HIP DP +
+traceback + stdskl + end check) against the reference's align2() results stored in the goldens, plus
+size-independent properties at bench-like sizes."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oraclelib
+from prrn_aln_amd import _abi, engine, operator as op, sweep
+from prrn_aln_amd.synth import make_family
+from test_host_builders import groups_from_golden, params_from_golden
+
+pytestmark = pytest.mark.gpu
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = engine.Context()
+    yield c
+    c.close()
+
+
+def test_align2_matches_reference_goldens(ctx):
+    bad = []
+    for f in GOLD:
+        d = dict(np.load(f))
+        alp = params_from_golden(d)
+        ga, gb = groups_from_golden(d, alp)
+        pw = op.PwdM([ga, gb], alp)
+        scr, skl, st = op.align2(ctx, pw)
+        if st != 0 or scr != d["align2_scr"][0] or not np.array_equal(skl, d["align2_skl"]):
+            bad.append((os.path.basename(f), st, scr, float(d["align2_scr"][0])))
+    assert not bad, bad
+
+
+def test_sweep_batch_vs_oracle_and_properties(ctx):
+    """A whole (small) sweep as one batch: every DP bit-equal to the oracle; skeleton properties hold."""
+    fam = make_family(40, 160, 21)
+    alp = op.AlnParam()
+    sw = sweep.Sweep(fam, alp)
+    res = op.align2_batch(ctx, sw.pwds)
+    L = oraclelib.load()
+    for pw, (scr, skl, st) in zip(sw.pwds, res):
+        assert st == 0
+
+        class H:
+            c = pw.problem
+        oscr, ocells, otr = oraclelib.forward(L, H)
+        assert scr == oscr
+        assert np.array_equal(skl, oraclelib.stdskl(L, otr))
+        q = pw.problem
+        # skeleton: starts at (left,left), ends at (right,right), monotone, each step diagonal or pure gap
+        assert tuple(skl[0]) == (q.a.left, q.b.left) and tuple(skl[-1]) == (q.a.right, q.b.right)
+        dm, dn = np.diff(skl[:, 0]), np.diff(skl[:, 1])
+        assert (dm >= 0).all() and (dn >= 0).all()
+        assert ((dm == dn) | (dm == 0) | (dn == 0)).all()
+
+
+def test_bench_size_dp_properties(ctx):
+    """BASELINE-size DPs (256 x 1024 family): too slow for the oracle in a test, so check properties:
+    identical replicas in one batch agree bit for bit, and the score does not depend on batch order."""
+    fam = make_family(256, 1024, 1)
+    alp = op.AlnParam()
+    sw = sweep.Sweep(fam, alp, limit=6)
+    r1 = op.align2_batch(ctx, sw.pwds)
+    r2 = op.align2_batch(ctx, list(reversed(sw.pwds)))[::-1]
+    r3 = op.align2_batch(ctx, [sw.pwds[0]] * 3)
+    for (s1, k1, st1), (s2, k2, st2) in zip(r1, r2):
+        assert st1 == 0 and st2 == 0
+        assert s1 == s2 and np.array_equal(k1, k2)
+    assert all(r[0] == r1[0][0] and np.array_equal(r[1], r1[0][1]) for r in r3)
+    q = sw.pwds[0].problem
+    assert tuple(r1[0][1][-1]) == (q.a.right, q.b.right)
