@@ -7,11 +7,13 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include "../../include/g2g.h"
 #include "g2g_device.h"
 #include "g2g_internal.h"
 
 #include "g2g_kernels.hip"          // one translation unit: kernels + launcher (no -fgpu-rdc needed)
+#include "g2g_kernels_v2.hip"
 
 static thread_local std::string g_err;
 void g2g_set_error(const char *fmt, const char *a)
@@ -94,8 +96,20 @@ struct g2g_batch {
     char *d_arena;
     size_t arena_bytes, in_bytes;
     DevProb *d_probs;
+    int *d_idx1, *d_idx2;           // problems run by the v1 / v2 forward kernel
+    int n1, n2;
+    size_t lds2;                    // dynamic LDS bytes of the v2 launch
     float fwd_ms, tb_ms;
 };
+
+// LDS footprint of g2g_forward_kernel_v2 for one problem (see V2Geom): (slots * R + extras) records
+static size_t v2_lds_bytes(int kind, int noll, int capa, int capb)
+{
+    const size_t recsz = (16 + 4 * (size_t) (capa + (kind == 2 ? capb : 0)) + 15) & ~(size_t) 15;
+    const size_t R = G2G_V2_THREADS / 8;
+    return ((noll == 3 ? 9 : 6) * R + 5) * recsz;
+}
+static const size_t V2_LDS_MAX = 160 * 1024;
 
 static int kind_of(int alnmode)
 {
@@ -209,6 +223,9 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         pack_side(bl, p->a, d.a, d.kind, d.kind == 1 || d.kind == 2);
         pack_side(bl, p->b, d.b, d.kind, d.kind == 2);
     }
+    // index lists for the two forward kernels (filled below, once eligibility is known)
+    const size_t idx_off = bl.put(0, 0);
+    bl.h.resize(idx_off + sizeof(int) * 2 * (size_t) (n > 0 ? n : 1));
     b->in_bytes = (bl.h.size() + 255) & ~(size_t) 255;
     // 2. state / trace / outputs (device only)
     size_t off = b->in_bytes;
@@ -245,6 +262,17 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         b->cells[i] = cells; d.cells = cells;
         d.tstride = tmax;
         d.trace = OFF<uint8_t>(take((size_t) (d.d1 - d.d0 + 1) * tmax));
+        // v2 kernel (gap-profile engines): packed 16-bit gap lengths and an LDS budget decide eligibility
+        d.v2_ok = 0;
+        if ((d.kind == 1 || d.kind == 2) && !getenv("G2G_FORCE_V1") && p->a.len + p->b.len < 65000 &&
+            v2_lds_bytes(d.kind, d.noll, d.capa, d.capb) <= V2_LDS_MAX) {
+            const size_t recsz = (16 + 4 * (size_t) (d.capa + (d.kind == 2 ? d.capb : 0)) + 15) & ~(size_t) 15;
+            d.v2_ok = 1;
+            d.v2_rowH = OFF<void>(take(recsz * ((size_t) p->b.len + 3)));
+            d.v2_rowG = OFF<void>(take(recsz * ((size_t) p->b.len + 3)));
+            if (d.noll == 3) d.v2_rowG2 = OFF<void>(take(recsz * ((size_t) p->b.len + 3)));
+            d.v2_colH = OFF<void>(take(recsz * ((size_t) (ar - al) + 3)));
+        }
         d.tcap = (ar - al) + (br - bl_) + 4;
         b->tcap[i] = d.tcap;
         b->out_off[i] = take(sizeof(double) + sizeof(int) * 2 + sizeof(int2) * (size_t) d.tcap);
@@ -264,7 +292,20 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             rebase(d.val[x], b->d_arena); rebase(d.dir[x], b->d_arena); rebase(d.dla[x], b->d_arena);
             rebase(d.dlb[x], b->d_arena); rebase(d.glb[x], b->d_arena);
         }
+        rebase(d.v2_rowH, b->d_arena); rebase(d.v2_rowG, b->d_arena); rebase(d.v2_rowG2, b->d_arena); rebase(d.v2_colH, b->d_arena);
         rebase(d.trace, b->d_arena); rebase(d.score, b->d_arena); rebase(d.ntrace, b->d_arena); rebase(d.otrace, b->d_arena);
+    }
+    {
+        int *i1 = (int *) (bl.h.data() + idx_off), *i2 = i1 + (n > 0 ? n : 1);
+        b->n1 = b->n2 = 0; b->lds2 = 0;
+        for (int i = 0; i < n; ++i) {
+            const DevProb &d = b->dp[i];
+            if (d.kind < 0) continue;
+            if (d.v2_ok) { i2[b->n2++] = i; b->lds2 = std::max(b->lds2, v2_lds_bytes(d.kind, d.noll, d.capa, d.capb)); }
+            else i1[b->n1++] = i;
+        }
+        b->d_idx1 = (int *) (b->d_arena + idx_off);
+        b->d_idx2 = b->d_idx1 + (n > 0 ? n : 1);
     }
     if (n) memcpy(bl.h.data() + probs_off, b->dp.data(), sizeof(DevProb) * (size_t) n);
     b->d_probs = (DevProb *) (b->d_arena + probs_off);
@@ -283,8 +324,18 @@ extern "C" int g2g_batch_run(g2g_batch *b)
     HIPCHK(hipSetDevice(ctx->device));
     if (b->n == 0) return G2G_OK;
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL(g2g_forward_kernel, dim3(b->n), dim3(G2G_FWD_THREADS), 0, ctx->stream, (const DevProb *) b->d_probs);
-    HIPCHK(hipGetLastError());
+    if (b->n2) {
+        if (b->lds2 > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *) g2g_forward_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2));
+        hipLaunchKernelGGL(g2g_forward_kernel_v2, dim3(b->n2), dim3(G2G_V2_THREADS), b->lds2, ctx->stream,
+                           (const DevProb *) b->d_probs, (const int *) b->d_idx2);
+        HIPCHK(hipGetLastError());
+    }
+    if (b->n1) {
+        hipLaunchKernelGGL(g2g_forward_kernel, dim3(b->n1), dim3(G2G_FWD_THREADS), 0, ctx->stream,
+                           (const DevProb *) b->d_probs, (const int *) b->d_idx1);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     hipLaunchKernelGGL(g2g_traceback_kernel, dim3((b->n + 63) / 64), dim3(64), 0, ctx->stream, (const DevProb *) b->d_probs, b->n);
     HIPCHK(hipGetLastError());

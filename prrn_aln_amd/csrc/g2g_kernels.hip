@@ -21,6 +21,9 @@
 #ifndef G2G_FWD_THREADS
 #define G2G_FWD_THREADS 256
 #endif
+#ifndef G2G_V2_THREADS
+#define G2G_V2_THREADS 512
+#endif
 
 // TraceBackDir values Fwd2c produces (src/aln.h:47-52) and their classes (:59-61)
 enum { D_DEAD = 0, D_DIAG = 2, D_NEWD = 3, D_VERT = 4, D_HORI = 8, D_NEWV = 12, D_NEWH = 13 };
@@ -555,9 +558,9 @@ __device__ void run_forward(const DevProb &P)
 }
 
 extern "C" __global__ void __launch_bounds__(G2G_FWD_THREADS)
-g2g_forward_kernel(const DevProb *probs)
+g2g_forward_kernel(const DevProb *probs, const int *idx)
 {
-    const DevProb &P = probs[blockIdx.x];
+    const DevProb &P = probs[idx[blockIdx.x]];
     if (P.kind < 0) return;                             // rejected by the host-side argument check
     if (P.noll == 3) {
         switch (P.kind) {
