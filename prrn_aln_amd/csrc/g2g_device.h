@@ -14,6 +14,7 @@
 
 struct DevSide {
     int many, len, left, right, nils, nelm, felm, hetero;
+    int maxlist;         // longest static gap-profile list incl. its terminator (any view, any position)
     const uint8_t *seq;
     const double  *weight;
     const double  *pseq;

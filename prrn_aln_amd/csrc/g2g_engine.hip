@@ -103,11 +103,12 @@ struct g2g_batch {
 };
 
 // LDS footprint of g2g_forward_kernel_v2 for one problem (see V2Geom): (slots * R + extras) records
-static size_t v2_lds_bytes(int kind, int noll, int capa, int capb)
+static size_t v2_lds_bytes(int kind, int noll, int capa, int capb, int mla, int mlb)
 {
     const size_t recsz = (16 + 4 * (size_t) (capa + (kind == 2 ? capb : 0)) + 15) & ~(size_t) 15;
     const size_t R = G2G_V2_THREADS / 8;
-    return ((noll == 3 ? 9 : 6) * R + 5) * recsz;
+    const size_t lists = (size_t) 12 * 3 * (R * mla + (kind == 2 ? 2 * R * mlb : 0));   // glen i32 + freq f64
+    return ((noll == 3 ? 9 : 6) * R + 5) * recsz + lists + 16;
 }
 static const size_t V2_LDS_MAX = 160 * 1024;
 
@@ -176,6 +177,7 @@ static void pack_side(Blob &bl, const g2g_side &s, DevSide &d, int kind, bool ne
         for (int v = 0; v < 3; ++v) {
             const int nlist = s.len + 2;                       // offsets for positions -1..len-1 + end
             const int pool = s.gfq.off[v][s.len + 1];
+            for (int i = 0; i + 1 < nlist; ++i) d.maxlist = std::max(d.maxlist, s.gfq.off[v][i + 1] - s.gfq.off[v][i]);
             d.off[v] = OFF<const int>(bl.put(s.gfq.off[v], sizeof(int) * nlist));
             d.glen[v] = OFF<const int>(bl.put(s.gfq.glen[v], sizeof(int) * pool));
             d.freq[v] = OFF<const double>(bl.put(s.gfq.freq[v], sizeof(double) * pool));
@@ -265,7 +267,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         // v2 kernel (gap-profile engines): packed 16-bit gap lengths and an LDS budget decide eligibility
         d.v2_ok = 0;
         if ((d.kind == 1 || d.kind == 2) && !getenv("G2G_FORCE_V1") && p->a.len + p->b.len < 65000 &&
-            v2_lds_bytes(d.kind, d.noll, d.capa, d.capb) <= V2_LDS_MAX) {
+            v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist) <= V2_LDS_MAX) {
             const size_t recsz = (16 + 4 * (size_t) (d.capa + (d.kind == 2 ? d.capb : 0)) + 15) & ~(size_t) 15;
             d.v2_ok = 1;
             d.v2_rowH = OFF<void>(take(recsz * ((size_t) p->b.len + 3)));
@@ -301,7 +303,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         for (int i = 0; i < n; ++i) {
             const DevProb &d = b->dp[i];
             if (d.kind < 0) continue;
-            if (d.v2_ok) { i2[b->n2++] = i; b->lds2 = std::max(b->lds2, v2_lds_bytes(d.kind, d.noll, d.capa, d.capb)); }
+            if (d.v2_ok) { i2[b->n2++] = i; b->lds2 = std::max(b->lds2, v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist)); }
             else i1[b->n1++] = i;
         }
         b->d_idx1 = (int *) (b->d_arena + idx_off);

@@ -23,13 +23,23 @@
 #define DL_END 0xFFFFu                       // packed terminator glen (INT_MAX in the reference)
 #define DL_GUARD 4096                        // no list is this long: a corrupted one must not hang the wave
 
+// Everything below lives in LDS and says so in its pointer types (address space 3): generic pointers
+// would compile to flat_load/flat_store instead of ds_read/ds_write.
+#define LDS __attribute__((address_space(3)))
+typedef LDS char lchar;
+typedef LDS unsigned lu32;
+typedef LDS int li32;
+typedef LDS double lf64;
+
 // ---- LDS record: {f64 val; i32 dir; i32 glb; u32 dla[capa]; u32 dlb[capb]} -----------------------
-struct LRec { char *p; };
-__device__ __forceinline__ double &lval(LRec r) { return *(double *) r.p; }
-__device__ __forceinline__ int &ldir(LRec r) { return *(int *) (r.p + 8); }
-__device__ __forceinline__ int &lglb(LRec r) { return *(int *) (r.p + 12); }
-__device__ __forceinline__ unsigned *ldla(LRec r) { return (unsigned *) (r.p + 16); }
-__device__ __forceinline__ unsigned *ldlb(LRec r, int capa) { return (unsigned *) (r.p + 16) + capa; }
+struct LRec { lchar *p; };
+__device__ __forceinline__ lf64 &lval(LRec r) { return *(lf64 *) r.p; }
+__device__ __forceinline__ li32 &ldir(LRec r) { return *(li32 *) (r.p + 8); }
+__device__ __forceinline__ li32 &lglb(LRec r) { return *(li32 *) (r.p + 12); }
+__device__ __forceinline__ lu32 *ldla(LRec r) { return (lu32 *) (r.p + 16); }
+__device__ __forceinline__ lu32 *ldlb(LRec r, int capa) { return (lu32 *) (r.p + 16) + capa; }
+// a static GFREQ list cached in LDS
+struct LList { const li32 *glen; const lf64 *freq; };
 
 __device__ __forceinline__ void team_sync()
 {   // lanes of a team live in one wave: ordering LDS traffic between phases is a compiler matter only
@@ -38,14 +48,15 @@ __device__ __forceinline__ void team_sync()
 }
 
 // GapLenSD, gfreq.h:67, on a packed list
-__device__ __forceinline__ int p_gaplen(int g, const unsigned *dl)
+__device__ __forceinline__ int p_gaplen(int g, const lu32 *dl)
 {
     int k = 0;
     while (g >= (int) (dl[k + 1] >> 16) && k < DL_GUARD) ++k;
     return g + (int) (dl[k] & 0xFFFFu);
 }
 // newgap(cf, dlc, df, dld), gfreq.cc:507-521
-__device__ double p_newgap4(const SList cf, const unsigned *dlc, const SList df, const unsigned *dld)
+template <class CL, class DL>
+__device__ double p_newgap4(const CL cf, const lu32 *dlc, const DL df, const lu32 *dld)
 {
     double g = 0;
     int ci = 0;
@@ -61,7 +72,8 @@ __device__ double p_newgap4(const SList cf, const unsigned *dlc, const SList df,
     return g;
 }
 // newgap1 / newgap2, maln.h:296-308 (+ newgapc/newgapd :280-291)
-__device__ double p_newgap1(const DevProb &P, const SList acf, const unsigned *dla, int glb)
+template <class CL>
+__device__ double p_newgap1(const DevProb &P, const CL acf, const lu32 *dla, int glb)
 {
     if (acf.glen[0] < 0) return 0;
     if (acf.glen[1] >= 0) {
@@ -71,7 +83,8 @@ __device__ double p_newgap1(const DevProb &P, const SList acf, const unsigned *d
     }
     return ((int) (dla[0] & 0xFFFFu) + acf.glen[0] >= glb) ? (P.weighted_gop * acf.freq[0]) : 0;
 }
-__device__ double p_newgap2(const DevProb &P, const SList adf, int glb, const unsigned *dla)
+template <class CL>
+__device__ double p_newgap2(const DevProb &P, const CL adf, int glb, const lu32 *dla)
 {
     if (adf.glen[0] < 0) return 0;
     if (adf.glen[1] >= 0) {                                 // newgap(df, i, dld), gfreq.cc:534-545
@@ -88,7 +101,8 @@ __device__ double p_newgap2(const DevProb &P, const SList adf, int glb, const un
 }
 // newdelta(dlt, df, dln, 1), gfreq.cc:570-587; up to two destinations (the record itself and, when that
 // record wins the cell, the new H).  dst may alias src (stores trail the loads they could affect).
-__device__ void p_newdelta(unsigned *dst, unsigned *dst2, const SList df, const unsigned *src)
+template <class CL>
+__device__ void p_newdelta(lu32 *dst, lu32 *dst2, const CL df, const lu32 *src)
 {
     int kd = 0, ks = 0;
     unsigned tg = 0, tn = 0;
@@ -111,7 +125,7 @@ __device__ void p_newdelta(unsigned *dst, unsigned *dst2, const SList df, const 
     if (dst2) { dst2[kd] = e; dst2[kd + 1] = DL_END << 16; }
 }
 // incdelta(dlt, dln, 1), gfreq.cc:598-605
-__device__ void p_incdelta(unsigned *dst, unsigned *dst2, const unsigned *src)
+__device__ void p_incdelta(lu32 *dst, lu32 *dst2, const lu32 *src)
 {
     int k = 0;
     for ( ; k < DL_GUARD; ++k) {
@@ -121,21 +135,21 @@ __device__ void p_incdelta(unsigned *dst, unsigned *dst2, const unsigned *src)
         dst[k] = e; if (dst2) dst2[k] = e;
     }
 }
-__device__ void p_copylist(unsigned *dst, const unsigned *src)
+__device__ void p_copylist(lu32 *dst, const lu32 *src)
 {
     for (int k = 0; ; ++k) { const unsigned e = src[k]; dst[k] = e; if ((e >> 16) == DL_END) break; }
 }
-__device__ __forceinline__ void p_clearlist(unsigned *d) { d[0] = 0; d[1] = DL_END << 16; }
+__device__ __forceinline__ void p_clearlist(lu32 *d) { d[0] = 0; d[1] = DL_END << 16; }
 
 // global <-> LDS record moves by one team (lane j moves dwords j, j+8, ...)
 __device__ __forceinline__ void rec_g2l(LRec dst, const unsigned *src, int ndw, int lane)
 {
-    unsigned *d = (unsigned *) dst.p;
+    lu32 *d = (lu32 *) dst.p;
     for (int k = lane; k < ndw; k += TEAM) d[k] = src[k];
 }
 __device__ __forceinline__ void rec_l2g(unsigned *dst, LRec src, int ndw, int lane)
 {
-    const unsigned *s = (const unsigned *) src.p;
+    const lu32 *s = (const lu32 *) src.p;
     for (int k = lane; k < ndw; k += TEAM) dst[k] = s[k];
 }
 
@@ -143,10 +157,10 @@ struct V2Geom {
     int capa, capb, recsz, ndw;       // list capacities, record bytes / dwords
     int nslot;                        // ring slots per row: 6 (Noll 2) or 9 (Noll 3)
     int R;                            // rows per strip
-    char *lds;
+    lchar *lds;
     // slot ids inside a row
-    __device__ __forceinline__ LRec row(int t, int slot) const { LRec r; r.p = lds + ((size_t) t * nslot + slot) * recsz; return r; }
-    __device__ __forceinline__ LRec extra(int k) const { LRec r; r.p = lds + ((size_t) R * nslot + k) * recsz; return r; }
+    __device__ __forceinline__ LRec row(int t, int slot) const { LRec r; r.p = lds + (t * nslot + slot) * recsz; return r; }
+    __device__ __forceinline__ LRec extra(int k) const { LRec r; r.p = lds + (R * nslot + k) * recsz; return r; }
 };
 // ring slots: H corner c -> c mod 3 (0..2); G corner c -> 3 + (c & 1); F -> 5; G2 -> 6 + (c & 1); F2 -> 8
 __device__ __forceinline__ int mod3(int c) { return ((c % 3) + 3) % 3; }
@@ -167,25 +181,38 @@ __device__ __forceinline__ void lrec_black(LRec r, int capa)
     if (KIND == 2) p_clearlist(ldlb(r, capa));
 }
 
-// gap-open cost of record rc for move d3 -- Fwd2c<_hf/_pf>::gapopen (fwd2c.cc:152-160, 203-212), one
-// list merge per call; `part` selects the first/second merge of the _pf diagonal case
-template <int KIND>
-__device__ double v2_gapopen(const DevProb &P, LRec rc, int capa, int m, int n, int d3, int part)
+// The six static lists a cell touches: a's s/t/r views at row m, b's at column n (LDS cache in the
+// sweep, HBM in the boundary chains)
+template <class SL> struct CellLists { SL as, at, ar, bs, bt, br; };
+
+// Fwd2c<_hf/_pf>::gapopen (fwd2c.cc:152-160, 203-212), one list merge per call
+template <int KIND, class SL>
+__device__ __forceinline__ double gap_diag(const DevProb &P, const CellLists<SL> &L, LRec rc, int capa, int part)
 {
-    if (KIND == 1) {
-        if (d3 > 0) return p_newgap1(P, gfq_at(P.a, 0, m), ldla(rc), lglb(rc));
-        return p_newgap2(P, gfq_at(P.a, d3 == 0 ? 1 : 2, m), lglb(rc), ldla(rc));
-    } else {
-        const unsigned *dla = ldla(rc), *dlb = ldlb(rc, capa);
-        if (d3 == 0) {
-            if (part == 0) return p_newgap4(gfq_at(P.a, 0, m), dla, gfq_at(P.b, 1, n), dlb) * P.basic_gop;
-            return p_newgap4(gfq_at(P.b, 0, n), dlb, gfq_at(P.a, 1, m), dla) * P.basic_gop;
-        } else if (d3 > 0) return p_newgap4(gfq_at(P.a, 0, m), dla, gfq_at(P.b, 2, n), dlb) * P.basic_gop;
-        return p_newgap4(gfq_at(P.b, 0, n), dlb, gfq_at(P.a, 2, m), dla) * P.basic_gop;
-    }
+    if (KIND == 1) return p_newgap2(P, L.at, lglb(rc), ldla(rc));
+    if (part == 0) return p_newgap4(L.as, ldla(rc), L.bt, ldlb(rc, capa)) * P.basic_gop;
+    return p_newgap4(L.bs, ldlb(rc, capa), L.at, ldla(rc)) * P.basic_gop;
+}
+template <int KIND, class SL>
+__device__ __forceinline__ double gap_vert(const DevProb &P, const CellLists<SL> &L, LRec rc, int capa)
+{
+    if (KIND == 1) return p_newgap1(P, L.as, ldla(rc), lglb(rc));
+    return p_newgap4(L.as, ldla(rc), L.br, ldlb(rc, capa)) * P.basic_gop;
+}
+template <int KIND, class SL>
+__device__ __forceinline__ double gap_hori(const DevProb &P, const CellLists<SL> &L, LRec rc, int capa)
+{
+    if (KIND == 1) return p_newgap2(P, L.ar, lglb(rc), ldla(rc));
+    return p_newgap4(L.bs, ldlb(rc, capa), L.ar, ldla(rc)) * P.basic_gop;
 }
 
-// ---- prologue: the boundary chains of initB (fwd2c.h:138-176), one lane each ----------------------
+__device__ __forceinline__ void rec_store_all(unsigned *dst, LRec src, int ndw)
+{
+    const lu32 *sp = (const lu32 *) src.p;
+    for (int k = 0; k < ndw; ++k) dst[k] = sp[k];
+}
+
+// ---- prologue: the boundary chains of initB (fwd2c.h:138-176), one lane each, lists straight from HBM
 template <int KIND>
 __device__ void v2_chain_top(const DevProb &P, const V2Geom &G, LRec s0, LRec s1, unsigned *rowH)
 {
@@ -193,20 +220,24 @@ __device__ void v2_chain_top(const DevProb &P, const V2Geom &G, LRec s0, LRec s1
     int rrt = b.right - a.left; if (P.up < rrt) rrt = P.up;
     const int nlast = a.left + rrt, ai = a.left - 1;
     lrec_black<KIND>(s0, G.capa); lval(s0) = 0; ldir(s0) = D_DIAG;          // origin
-    { const unsigned *s = (const unsigned *) s0.p; unsigned *d = rowH + (size_t) b.left * G.ndw; for (int k = 0; k < G.ndw; ++k) d[k] = s[k]; }
+    rec_store_all(rowH + (size_t) b.left * G.ndw, s0, G.ndw);
     LRec prv = s0, cur = s1;
+    CellLists<SList> L;
+    L.as = gfq_at(a, 0, ai); L.at = gfq_at(a, 1, ai); L.ar = gfq_at(a, 2, ai);
+    L.bs = L.bt = L.br = L.as;
     for (int n = b.left + 1; n <= nlast; ++n) {
         const int bi = n - 1;
+        if (KIND == 2) { L.bs = gfq_at(b, 0, bi); L.bt = gfq_at(b, 1, bi); L.br = gfq_at(b, 2, bi); }
         const double pub = unpb(P, bi, ai);
-        double gnp = (KIND == 1) ? v2_gapopen<KIND>(P, prv, G.capa, ai, bi, -1, 0)
-                                 : v2_gapopen<KIND>(P, prv, G.capa, ai, bi, -1, 0);
+        double gnp = gap_hori<KIND>(P, L, prv, G.capa);
         gnp = (n - b.left < P.codonk1) ? gnp + pub : (P.v2divv1 * gnp + P.u2divu1 * pub);
         // update(h, h-1, ..., -1): fwd2c.cc:175-178 / 226-229
         ldir(cur) = isvert(ldir(prv)) ? D_NEWH : D_HORI;
-        if (KIND == 1) { p_incdelta(ldla(cur), 0, ldla(prv)); lglb(cur) = 0; }
-        else { p_newdelta(ldlb(cur, G.capa), 0, gfq_at(P.b, 1, bi), ldlb(prv, G.capa)); p_incdelta(ldla(cur), 0, ldla(prv)); lglb(cur) = 0; }
+        if (KIND == 2) p_newdelta(ldlb(cur, G.capa), (lu32 *) 0, L.bt, ldlb(prv, G.capa));
+        p_incdelta(ldla(cur), (lu32 *) 0, ldla(prv));
+        lglb(cur) = 0;
         lval(cur) = lval(prv) + gnp;
-        { const unsigned *s = (const unsigned *) cur.p; unsigned *d = rowH + (size_t) n * G.ndw; for (int k = 0; k < G.ndw; ++k) d[k] = s[k]; }
+        rec_store_all(rowH + (size_t) n * G.ndw, cur, G.ndw);
         LRec t = prv; prv = cur; cur = t;
     }
 }
@@ -218,19 +249,23 @@ __device__ void v2_chain_left(const DevProb &P, const V2Geom &G, LRec s0, LRec s
     const int mlast = b.left - rrl, bi = b.left - 1;
     lrec_black<KIND>(s0, G.capa); lval(s0) = 0; ldir(s0) = D_DIAG;
     LRec prv = s0, cur = s1;
+    CellLists<SList> L;
+    L.as = gfq_at(a, 0, a.left); L.at = L.ar = L.bs = L.bt = L.br = L.as;
+    if (KIND == 2) { L.bs = gfq_at(b, 0, bi); L.bt = gfq_at(b, 1, bi); L.br = gfq_at(b, 2, bi); }
     for (int m = a.left + 1; m <= mlast; ++m) {
         const int ai = m - 1;
+        L.as = gfq_at(a, 0, ai); L.at = gfq_at(a, 1, ai); L.ar = gfq_at(a, 2, ai);
         const double pua = unpa(P, ai, bi);
-        double gnp = v2_gapopen<KIND>(P, prv, G.capa, ai, bi, 1, 0);
+        double gnp = gap_vert<KIND>(P, L, prv, G.capa);
         gnp = (m - a.left < P.codonk1) ? gnp + pua : (P.v2divv1 * gnp + P.u2divu1 * pua);
         // update(h, h+1, ..., 1): fwd2c.cc:170-173 / 222-225
         ldir(cur) = ishori(ldir(prv)) ? D_NEWV : D_VERT;
         const int g1 = lglb(prv) + 1;
-        p_newdelta(ldla(cur), 0, gfq_at(P.a, 1, ai), ldla(prv));
+        p_newdelta(ldla(cur), (lu32 *) 0, L.at, ldla(prv));
         if (KIND == 1) lglb(cur) = g1;
-        else { p_incdelta(ldlb(cur, G.capa), 0, ldlb(prv, G.capa)); lglb(cur) = 0; }
+        else { p_incdelta(ldlb(cur, G.capa), (lu32 *) 0, ldlb(prv, G.capa)); lglb(cur) = 0; }
         lval(cur) = lval(prv) + gnp;
-        { const unsigned *s = (const unsigned *) cur.p; unsigned *d = colH + (size_t) (m - a.left) * G.ndw; for (int k = 0; k < G.ndw; ++k) d[k] = s[k]; }
+        rec_store_all(colH + (size_t) (m - a.left) * G.ndw, cur, G.ndw);
         LRec t = prv; prv = cur; cur = t;
     }
 }
@@ -240,32 +275,40 @@ struct CellSrc { LRec hd, hu, gu, g2u, hl, fl, f2l; };   // records the cell rea
 struct CellDst { LRec h, g, g2, f, f2; };                 // records it writes
 
 template <int KIND, bool NOLL3>
-__device__ void v2_cell(const DevProb &P, const V2Geom &G, int m, int n, int lane,
+__device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList> &L, int m, int n, int lane,
                         const CellSrc &S, const CellDst &D, bool do_vert, bool do_hori, uint8_t *tr)
 {
     const DevSide &a = P.a, &b = P.b;
     const int capa = G.capa;
-    // ---- phase A: one independent cost per lane -----------------------------------------------
+    // ---- phase A: one independent cost per lane.  Lanes of a wave that take different branches are
+    // serialised, so the jobs are expressed as ONE call with per-lane operands (select, then call):
+    //   lane 0/1 diagonal (two merges for _pf), 2 vertical from G, 3 vertical from H, 4 horizontal from F,
+    //   5 horizontal from H, 6 horizontal2 from F2, 7 vertical2 from G2 (Noll 3); then lane 6: sim2.
+    const int jk = (lane == 0) ? 0 : (lane == 1) ? 1 : (lane == 2 || lane == 3 || lane == 7) ? 2 : 3;
+    const LRec rc = (lane < 2) ? S.hd : (lane == 2) ? S.gu : (lane == 3) ? S.hu : (lane == 4) ? S.fl
+                  : (lane == 5) ? S.hl : (lane == 6) ? S.f2l : S.g2u;
+    bool on = (jk == 0) || (jk == 1 && KIND == 2) || (jk == 2 && do_vert && (lane != 7 || NOLL3))
+              || (jk == 3 && do_hori && (lane != 6 || NOLL3));
     double r = 0;
-    switch (lane) {
-    case 0: r = v2_gapopen<KIND>(P, S.hd, capa, m, n, 0, 0); break;
-    case 1: if (KIND == 2) r = v2_gapopen<KIND>(P, S.hd, capa, m, n, 0, 1); break;
-    case 2: if (do_vert) r = v2_gapopen<KIND>(P, S.gu, capa, m, n, 1, 0); break;
-    case 3: if (do_vert) r = v2_gapopen<KIND>(P, S.hu, capa, m, n, 1, 0); break;
-    case 4: if (do_hori) r = v2_gapopen<KIND>(P, S.fl, capa, m, n, -1, 0); break;
-    case 5: if (do_hori) r = v2_gapopen<KIND>(P, S.hl, capa, m, n, -1, 0); break;
-    case 6: r = sim2(P, m, n); break;
-    default: if (NOLL3 && do_vert) r = v2_gapopen<KIND>(P, S.g2u, capa, m, n, 1, 0); break;
+    if (KIND == 2) {
+        const bool aside = (jk == 0 || jk == 2);        // merge a's s-list against b's t/r list, or the mirror
+        const LList cf = aside ? L.as : L.bs;
+        const LList df = (jk == 0) ? L.bt : (jk == 1) ? L.at : (jk == 2) ? L.br : L.ar;
+        const lu32 *dlc = aside ? ldla(rc) : ldlb(rc, capa);
+        const lu32 *dld = aside ? ldlb(rc, capa) : ldla(rc);
+        if (on) r = p_newgap4(cf, dlc, df, dld) * P.basic_gop;
+    } else {
+        if (on && jk == 2) r = p_newgap1(P, L.as, ldla(rc), lglb(rc));
+        if (on && jk != 2) r = p_newgap2(P, jk == 0 ? L.at : L.ar, lglb(rc), ldla(rc));
     }
-    double r8 = 0;
-    if (NOLL3 && do_hori && lane == 1 && KIND == 1) r8 = v2_gapopen<KIND>(P, S.f2l, capa, m, n, -1, 0);
-    if (NOLL3 && do_hori && lane == 6 && KIND == 2) r8 = v2_gapopen<KIND>(P, S.f2l, capa, m, n, -1, 0);
+    double r8 = r;                                       // lane 6's horizontal2 cost (Noll 3)
+    if (lane == 6) r = sim2(P, m, n);
     const double c_d0 = __shfl(r, 0, TEAM), c_d1 = __shfl(r, 1, TEAM);
     const double c_gnpv = __shfl(r, 2, TEAM), c_gopv = __shfl(r, 3, TEAM);
     const double c_gnph = __shfl(r, 4, TEAM), c_goph = __shfl(r, 5, TEAM);
     const double dab = __shfl(r, 6, TEAM);
     const double c_gnpv2 = NOLL3 ? __shfl(r, 7, TEAM) : 0;
-    const double c_gnph2 = NOLL3 ? __shfl(r8, KIND == 1 ? 1 : 6, TEAM) : 0;
+    const double c_gnph2 = NOLL3 ? __shfl(r8, 6, TEAM) : 0;
     // ---- scalar decisions, replayed by every lane (fwd2c.h:395-453) ------------------------------
     double gop = (KIND == 2) ? c_d0 + c_d1 : c_d0;
     const double hval = lval(S.hd) + (dab + gop);
@@ -300,8 +343,7 @@ __device__ void v2_cell(const DevProb &P, const V2Geom &G, int m, int n, int lan
             if (g2val > mxval) { mxval = g2val; win = 2; }
         }
     } else {
-        // first row: G is never touched; mx starts as the (black) G record
-        mxval = NEVSEL; win = 1;
+        mxval = NEVSEL; win = 1;                     // first row: mx starts as the untouched black G
     }
     if (do_hori) {
         const double pub = unpb(P, n, m);
@@ -327,37 +369,51 @@ __device__ void v2_cell(const DevProb &P, const V2Geom &G, int m, int n, int lan
             if (f2val >= mxval) { mxval = f2val; win = 4; }
         }
     }
-    const bool mx_wins = mxval > hval;                 // diagonal wins ties (fwd2c.h:453)
-    if (!mx_wins) win = 0;
-    if (!do_vert && win == 1) win = 0;                 // (black G can never win: NEVSEL > hval is false)
+    if (!(mxval > hval)) win = 0;                      // diagonal wins ties (fwd2c.h:453)
+    if (!do_vert && win == 1) win = 0;                 // (the black G can never win)
     // ---- phase B: list updates, one per lane; the winner's lists are also written to the new H ----
     team_sync();
     const LRec gs = g_from_h ? S.hu : S.gu, gs2 = g2_from_h ? S.hu : S.g2u;
     const LRec fs = f_from_h ? S.hl : S.fl, fs2 = f2_from_h ? S.hl : S.f2l;
-    const SList at = gfq_at(P.a, 1, m);
-    if (KIND == 2) {
-        const SList bt = gfq_at(P.b, 1, n);
-        switch (lane) {
-        case 0: if (win == 0) p_newdelta(ldla(D.h), 0, at, ldla(S.hd)); break;
-        case 1: if (win == 0) p_newdelta(ldlb(D.h, capa), 0, bt, ldlb(S.hd, capa)); break;
-        case 2: if (do_vert) p_newdelta(ldla(D.g), win == 1 ? ldla(D.h) : 0, at, ldla(gs)); break;
-        case 3: if (do_vert) p_incdelta(ldlb(D.g, capa), win == 1 ? ldlb(D.h, capa) : 0, ldlb(gs, capa)); break;
-        case 4: if (do_hori) p_newdelta(ldlb(D.f, capa), win == 3 ? ldlb(D.h, capa) : 0, bt, ldlb(fs, capa)); break;
-        case 5: if (do_hori) p_incdelta(ldla(D.f), win == 3 ? ldla(D.h) : 0, ldla(fs)); break;
-        case 6: if (NOLL3 && do_vert) { p_newdelta(ldla(D.g2), win == 2 ? ldla(D.h) : 0, at, ldla(gs2));
-                                        p_incdelta(ldlb(D.g2, capa), win == 2 ? ldlb(D.h, capa) : 0, ldlb(gs2, capa)); } break;
-        default: if (NOLL3 && do_hori) { p_newdelta(ldlb(D.f2, capa), win == 4 ? ldlb(D.h, capa) : 0, bt, ldlb(fs2, capa));
-                                         p_incdelta(ldla(D.f2), win == 4 ? ldla(D.h) : 0, ldla(fs2)); } break;
+    lu32 *const nul = (lu32 *) 0;
+    {   // newdelta jobs (one call, per-lane operands), then incdelta jobs (one call)
+        lu32 *d1 = nul, *d2 = nul; const lu32 *sp = nul; LList df = L.at; bool go = false;
+        if (KIND == 2) {
+            switch (lane) {
+            case 0: go = win == 0; d1 = ldla(D.h); sp = ldla(S.hd); break;
+            case 1: go = win == 0; d1 = ldlb(D.h, capa); sp = ldlb(S.hd, capa); df = L.bt; break;
+            case 2: go = do_vert; d1 = ldla(D.g); d2 = win == 1 ? ldla(D.h) : nul; sp = ldla(gs); break;
+            case 4: go = do_hori; d1 = ldlb(D.f, capa); d2 = win == 3 ? ldlb(D.h, capa) : nul; sp = ldlb(fs, capa); df = L.bt; break;
+            case 6: go = NOLL3 && do_vert; d1 = ldla(D.g2); d2 = win == 2 ? ldla(D.h) : nul; sp = ldla(gs2); break;
+            case 7: go = NOLL3 && do_hori; d1 = ldlb(D.f2, capa); d2 = win == 4 ? ldlb(D.h, capa) : nul; sp = ldlb(fs2, capa); df = L.bt; break;
+            default: break;
+            }
+        } else {
+            switch (lane) {
+            case 0: go = win == 0; d1 = ldla(D.h); sp = ldla(S.hd); break;
+            case 2: go = do_vert; d1 = ldla(D.g); d2 = win == 1 ? ldla(D.h) : nul; sp = ldla(gs); break;
+            case 6: go = NOLL3 && do_vert; d1 = ldla(D.g2); d2 = win == 2 ? ldla(D.h) : nul; sp = ldla(gs2); break;
+            default: break;
+            }
         }
-    } else {
-        switch (lane) {
-        case 0: if (win == 0) p_newdelta(ldla(D.h), 0, at, ldla(S.hd)); break;
-        case 2: if (do_vert) p_newdelta(ldla(D.g), win == 1 ? ldla(D.h) : 0, at, ldla(gs)); break;
-        case 4: if (do_hori) p_incdelta(ldla(D.f), win == 3 ? ldla(D.h) : 0, ldla(fs)); break;
-        case 6: if (NOLL3 && do_vert) p_newdelta(ldla(D.g2), win == 2 ? ldla(D.h) : 0, at, ldla(gs2)); break;
-        case 7: if (NOLL3 && do_hori) p_incdelta(ldla(D.f2), win == 4 ? ldla(D.h) : 0, ldla(fs2)); break;
-        default: break;
+        if (go) p_newdelta(d1, d2, df, sp);
+        go = false; d2 = nul;
+        if (KIND == 2) {
+            switch (lane) {
+            case 3: go = do_vert; d1 = ldlb(D.g, capa); d2 = win == 1 ? ldlb(D.h, capa) : nul; sp = ldlb(gs, capa); break;
+            case 5: go = do_hori; d1 = ldla(D.f); d2 = win == 3 ? ldla(D.h) : nul; sp = ldla(fs); break;
+            case 0: go = NOLL3 && do_vert; d1 = ldlb(D.g2, capa); d2 = win == 2 ? ldlb(D.h, capa) : nul; sp = ldlb(gs2, capa); break;
+            case 1: go = NOLL3 && do_hori; d1 = ldla(D.f2); d2 = win == 4 ? ldla(D.h) : nul; sp = ldla(fs2); break;
+            default: break;
+            }
+        } else {
+            switch (lane) {
+            case 4: go = do_hori; d1 = ldla(D.f); d2 = win == 3 ? ldla(D.h) : nul; sp = ldla(fs); break;
+            case 7: go = NOLL3 && do_hori; d1 = ldla(D.f2); d2 = win == 4 ? ldla(D.h) : nul; sp = ldla(fs2); break;
+            default: break;
+            }
         }
+        if (go) p_incdelta(d1, d2, sp);
     }
     // scalars of the produced records (lane 0 writes; glb per fwd2c.cc:169,173,177)
     const int glb_g = (KIND == 1 && do_vert) ? lglb(gs) + 1 : 0;
@@ -380,8 +436,17 @@ __device__ void v2_cell(const DevProb &P, const V2Geom &G, int m, int n, int lan
     team_sync();
 }
 
+// copy one static list (with its terminator) from the HBM pool into an LDS slot, `nl` lanes sharing it
+__device__ __forceinline__ void list_g2l(li32 *gl, lf64 *fr, const DevSide &s, int view, int pos, int lane, int nl)
+{
+    const int o = s.off[view][pos + 1], e = s.off[view][pos + 2];
+    const int *sg = s.glen[view] + o;
+    const double *sf = s.freq[view] + o;
+    for (int k = lane; k < e - o; k += nl) { gl[k] = sg[k]; fr[k] = sf[k]; }
+}
+
 template <int KIND, bool NOLL3>
-__device__ void v2_run(const DevProb &P, char *lds)
+__device__ void v2_run(const DevProb &P, lchar *lds)
 {
     const DevSide &a = P.a, &b = P.b;
     const int tid = threadIdx.x, lane = tid & (TEAM - 1), team = tid / TEAM;
@@ -391,9 +456,16 @@ __device__ void v2_run(const DevProb &P, char *lds)
     G.nslot = NOLL3 ? 9 : 6;
     G.R = blockDim.x / TEAM;
     G.lds = lds;
+    const int R = G.R, RC = 2 * R;                         // RC: column ring (power of two, >= R + 2)
+    // LDS carve-up after the records: a-side lists of the strip's rows, ring of b-side lists
+    const int mla = P.a.maxlist, mlb = (KIND == 2) ? P.b.maxlist : 0;
+    lchar *q = lds + ((size_t) R * G.nslot + EX_N) * G.recsz;
+    lf64 *afreq = (lf64 *) q;            q += sizeof(double) * (size_t) R * 3 * mla;
+    lf64 *bfreq = (lf64 *) q;            q += sizeof(double) * (size_t) RC * 3 * mlb;
+    li32 *aglen = (li32 *) q;            q += sizeof(int) * (size_t) R * 3 * mla;
+    li32 *bglen = (li32 *) q;
     unsigned *rowH = (unsigned *) P.v2_rowH, *rowG = (unsigned *) P.v2_rowG, *rowG2 = (unsigned *) P.v2_rowG2;
     unsigned *colH = (unsigned *) P.v2_colH;
-    const int R = G.R;
     // black record
     if (tid == 0) lrec_black<KIND>(G.extra(EX_BLACK), G.capa);
     // prologue chains: lane 0 of wave 0 (top row) and lane 0 of the last wave (left column)
@@ -412,17 +484,56 @@ __device__ void v2_run(const DevProb &P, char *lds)
         int mlast = m0 + R - 1; if (mlast > a.right - 1) mlast = a.right - 1;
         int cend = mlast + P.up + 1; if (cend > b.right) cend = b.right;     // last row's end
         const int nsteps = (cend - cbase) + (mlast - m0) + 1;
-        // new rows: F (and F2) start black (reset(f1), reset(f2), fwd2c.h:385-386)
-        // (G of the DP's first row is never written and is read as black by the row below, fwd2c.h:401)
+        // new rows: every ring slot black (reset(f1), reset(f2), fwd2c.h:385-386; G of the DP's first
+        // row is never written and is read as black by the row below, fwd2c.h:401)
         if (lane < G.nslot) lrec_black<KIND>(G.row(team, lane), G.capa);
         if (lane == 0 && G.nslot > TEAM) lrec_black<KIND>(G.row(team, 8), G.capa);
+        // this row's static lists -> LDS (they serve every cell of the row)
+        CellLists<LList> L;
+        {
+            li32 *ag = aglen + (size_t) team * 3 * mla;
+            lf64 *af = afreq + (size_t) team * 3 * mla;
+            if (row_ok) for (int v = 0; v < 3; ++v) list_g2l(ag + v * mla, af + v * mla, a, v, m, lane, TEAM);
+            L.as.glen = ag; L.as.freq = af;
+            L.at.glen = ag + mla; L.at.freq = af + mla;
+            L.ar.glen = ag + 2 * mla; L.ar.freq = af + 2 * mla;
+            L.bs = L.bt = L.br = L.as;
+        }
+        // column ring: column cbase for step 0
+        if (KIND == 2 && tid < 3 * TEAM) {
+            const int v = tid / TEAM;
+            list_g2l(bglen + (size_t) v * mlb, bfreq + (size_t) v * mlb, b, v, cbase, lane, TEAM);
+        }
         __syncthreads();
         for (int s = 0; s < nsteps; ++s) {
             const int n = cbase + s - team;
             const bool active = row_ok && n >= nlo && n < nhi;
+            // prefetch the column row m0 reaches next step into the ring (3 teams, one view each): the
+            // loads are issued here, the LDS stores wait until the cell work of this step is done
+            int pf_g[4]; double pf_f[4]; int pf_n = 0, pf_base = 0;
+            const bool pf_on = KIND == 2 && tid < 3 * TEAM && cbase + s + 1 < b.right;
+            if (pf_on) {
+                const int v = tid / TEAM, pos = cbase + s + 1;
+                const int o = b.off[v][pos + 1];
+                pf_n = b.off[v][pos + 2] - o;
+                pf_base = (((s + 1) & (RC - 1)) * 3 + v) * mlb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = lane + j * TEAM;
+                    if (k < pf_n) { pf_g[j] = b.glen[v][o + k]; pf_f[j] = b.freq[v][o + k]; }
+                }
+            }
             if (active) {
                 CellSrc S; CellDst D;
                 const bool do_vert = m > a.left, do_hori = n > b.left;
+                if (KIND == 2) {
+                    const int slot = (s - team) & (RC - 1);
+                    const li32 *bg = bglen + (size_t) slot * 3 * mlb;
+                    const lf64 *bf = bfreq + (size_t) slot * 3 * mlb;
+                    L.bs.glen = bg; L.bs.freq = bf;
+                    L.bt.glen = bg + mlb; L.bt.freq = bf + mlb;
+                    L.br.glen = bg + 2 * mlb; L.br.freq = bf + 2 * mlb;
+                }
                 // -- sources -------------------------------------------------------------------
                 if (team == 0) {
                     // the row above lives in HBM (previous strip's last row / the top boundary chain)
@@ -451,8 +562,6 @@ __device__ void v2_run(const DevProb &P, char *lds)
                 S.hl = left_in ? G.row(team, SLOT_H(n)) : black;
                 S.fl = left_in ? G.row(team, SLOT_F) : black;
                 S.f2l = (NOLL3 && left_in) ? G.row(team, SLOT_F2) : black;
-                // at the row's first cell F must read black even though the slot is reused in place
-                if (!left_in && do_hori) { S.fl = black; S.f2l = black; }
                 D.h = G.row(team, SLOT_H(n + 1));
                 D.g = G.row(team, SLOT_G(n + 1));
                 D.g2 = G.row(team, NOLL3 ? SLOT_G2(n + 1) : SLOT_G(n + 1));
@@ -462,7 +571,7 @@ __device__ void v2_run(const DevProb &P, char *lds)
                 const int d = m + n;
                 diag_rows(d, a.left, a.right, b.left, b.right, P.lw, P.up, &mlo, &mhi);
                 uint8_t *tr = P.trace + (size_t) (d - P.d0) * P.tstride + (m - mlo);
-                v2_cell<KIND, NOLL3>(P, G, m, n, lane, S, D, do_vert, do_hori, tr);
+                v2_cell<KIND, NOLL3>(P, G, L, m, n, lane, S, D, do_vert, do_hori, tr);
                 // the row below starts at b.left with the left-boundary corner (m+1, b.left) as its
                 // diagonal source: park it in this row's H ring where that row will look for it
                 if (n == b.left && team + 1 < R && m + 1 < a.right && m + 1 <= m_left_last && (m + 1 + P.lw) <= b.left) {
@@ -476,6 +585,17 @@ __device__ void v2_run(const DevProb &P, char *lds)
                 }
                 if (m == a.right - 1 && n == b.right - 1 && lane == 0) *P.score = lval(D.h);
             }
+            if (pf_on) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = lane + j * TEAM;
+                    if (k < pf_n) { bglen[pf_base + k] = pf_g[j]; bfreq[pf_base + k] = pf_f[j]; }
+                }
+                if (pf_n > 4 * TEAM) {                      // (lists longer than 32 entries: straight copy)
+                    const int v = tid / TEAM, pos = cbase + s + 1, o = b.off[v][pos + 1];
+                    for (int k = lane + 4 * TEAM; k < pf_n; k += TEAM) { bglen[pf_base + k] = b.glen[v][o + k]; bfreq[pf_base + k] = b.freq[v][o + k]; }
+                }
+            }
             __syncthreads();
         }
     }
@@ -485,7 +605,8 @@ extern "C" __global__ void __launch_bounds__(G2G_V2_THREADS)
 g2g_forward_kernel_v2(const DevProb *probs, const int *idx)
 {
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];
+    lchar *lds = (lchar *) g2g_lds;
     const DevProb &P = probs[idx[blockIdx.x]];
-    if (P.kind == 1) { if (P.noll == 3) v2_run<1, true>(P, g2g_lds); else v2_run<1, false>(P, g2g_lds); }
-    else if (P.kind == 2) { if (P.noll == 3) v2_run<2, true>(P, g2g_lds); else v2_run<2, false>(P, g2g_lds); }
+    if (P.kind == 1) { if (P.noll == 3) v2_run<1, true>(P, lds); else v2_run<1, false>(P, lds); }
+    else if (P.kind == 2) { if (P.noll == 3) v2_run<2, true>(P, lds); else v2_run<2, false>(P, lds); }
 }
