@@ -1,0 +1,73 @@
+"""The N>1 path of a sweep on CPU: divisions dealt to ranks, result slots packed, all-gathered over gloo
+(world_size 2) and unpacked -- every rank must end up with every division's result.  The DP itself needs a
+GPU, so results here are synthetic skeletons; the sharding / slot / gather logic is the code bench.py runs."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from prrn_aln_amd import sweep
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from prrn_aln_amd import sweep
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n, cap = 23, 64
+rng = np.random.RandomState(5)
+cells = rng.randint(10, 1000, size=n)
+order = np.argsort(-cells, kind="stable")
+mine = sweep.shard(order, world, rank)
+def fake(k):      # what the GPU would return for division k
+    r = np.random.RandomState(100 + k); m = r.randint(2, cap)
+    return (float(r.rand() * 1000 - 500), r.randint(0, 5000, size=(m, 2)).astype(np.int32), 0)
+res = [fake(k) for k in mine]
+nslots = (n + world - 1) // world
+slots = torch.from_numpy(sweep.pack_slots(mine, res, cap, nslots))
+gathered = [torch.empty_like(slots) for _ in range(world)]
+dist.all_gather(gathered, slots)
+allres = sweep.unpack_slots(torch.stack(gathered).numpy())
+ok = sorted(allres) == list(range(n))
+for k, (scr, skl, st) in allres.items():
+    s2, k2, st2 = fake(k)
+    ok = ok and scr == s2 and np.array_equal(skl, k2) and st == st2
+dist.barrier(); dist.destroy_process_group()
+print(json.dumps({{"rank": rank, "ok": bool(ok), "mine": len(mine)}}))
+'''
+
+
+def test_shard_partitions_everything():
+    order = list(np.argsort(-np.arange(37)))
+    for world in (1, 2, 3, 8):
+        parts = [sweep.shard(order, world, r) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(37))
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def test_pack_unpack_roundtrip():
+    skl = np.array([[0, 0], [3, 3], [3, 5], [9, 11]], np.int32)
+    slots = sweep.pack_slots([7, 2], [(1.25, skl, 0), (-3.5e300, skl[:2], -6)], cap=8, nslots=3)
+    out = sweep.unpack_slots(slots)
+    assert set(out) == {7, 2}
+    assert out[7][0] == 1.25 and np.array_equal(out[7][1], skl) and out[7][2] == 0
+    assert out[2][0] == -3.5e300 and out[2][2] == -6
+
+
+def test_two_rank_gloo_allgather():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER.format(root=root)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    import json
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err.decode()[-2000:]
+        r = json.loads(out.decode().strip().splitlines()[-1])
+        assert r["ok"], r
