@@ -44,7 +44,9 @@ struct DevProb {
     int2    *dlb[NX];
     int     *glb[NX];    // _hf: running gap length of b ; _nv: gla/glb member arrays [(an+bn)][width]
     // v2 kernel: strip boundary (one record per column) and left boundary chain (one per row) in HBM
-    void    *v2_rowH, *v2_rowG, *v2_rowG2, *v2_colH;
+    void    *v2_rowH, *v2_rowG, *v2_rowG2, *v2_colH;   // rowX: 3 buffers of v2_rowstride records
+    void    *v2_cbH, *v2_cbF, *v2_cbF2;                // per row: records at the current column-block edge
+    int      v2_rowstride;
     int      v2_ok;      // 1: handled by g2g_forward_kernel_v2
     // trace
     uint8_t *trace;

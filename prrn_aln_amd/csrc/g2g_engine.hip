@@ -99,6 +99,10 @@ struct g2g_batch {
     int *d_idx1, *d_idx2;           // problems run by the v1 / v2 forward kernel
     int n1, n2;
     size_t lds2;                    // dynamic LDS bytes of the v2 launch
+    size_t lds2p;                   // ... of the v2 prologue launch
+    V2Tile *d_tiles;                // v2 tiles ordered by wavefront index i + j
+    std::vector<int> wave_off;      // tiles of wavefront k: [wave_off[k], wave_off[k+1])
+    long long ntiles;
     float fwd_ms, tb_ms;
 };
 
@@ -270,10 +274,14 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist) <= V2_LDS_MAX) {
             const size_t recsz = (16 + 4 * (size_t) (d.capa + (d.kind == 2 ? d.capb : 0)) + 15) & ~(size_t) 15;
             d.v2_ok = 1;
-            d.v2_rowH = OFF<void>(take(recsz * ((size_t) p->b.len + 3)));
-            d.v2_rowG = OFF<void>(take(recsz * ((size_t) p->b.len + 3)));
-            if (d.noll == 3) d.v2_rowG2 = OFF<void>(take(recsz * ((size_t) p->b.len + 3)));
+            d.v2_rowstride = p->b.len + 3;
+            d.v2_rowH = OFF<void>(take(3 * recsz * (size_t) d.v2_rowstride));
+            d.v2_rowG = OFF<void>(take(3 * recsz * (size_t) d.v2_rowstride));
+            if (d.noll == 3) d.v2_rowG2 = OFF<void>(take(3 * recsz * (size_t) d.v2_rowstride));
             d.v2_colH = OFF<void>(take(recsz * ((size_t) (ar - al) + 3)));
+            d.v2_cbH = OFF<void>(take(recsz * ((size_t) (ar - al) + 3)));
+            d.v2_cbF = OFF<void>(take(recsz * ((size_t) (ar - al) + 3)));
+            if (d.noll == 3) d.v2_cbF2 = OFF<void>(take(recsz * ((size_t) (ar - al) + 3)));
         }
         d.tcap = (ar - al) + (br - bl_) + 4;
         b->tcap[i] = d.tcap;
@@ -295,6 +303,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             rebase(d.dlb[x], b->d_arena); rebase(d.glb[x], b->d_arena);
         }
         rebase(d.v2_rowH, b->d_arena); rebase(d.v2_rowG, b->d_arena); rebase(d.v2_rowG2, b->d_arena); rebase(d.v2_colH, b->d_arena);
+        rebase(d.v2_cbH, b->d_arena); rebase(d.v2_cbF, b->d_arena); rebase(d.v2_cbF2, b->d_arena);
         rebase(d.trace, b->d_arena); rebase(d.score, b->d_arena); rebase(d.ntrace, b->d_arena); rebase(d.otrace, b->d_arena);
     }
     {
@@ -308,6 +317,50 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         }
         b->d_idx1 = (int *) (b->d_arena + idx_off);
         b->d_idx2 = b->d_idx1 + (n > 0 ? n : 1);
+    }
+    // v2 tiles: (strip i of R rows) x (block j of G2G_V2_TILE_COLS columns), grouped by wavefront i + j
+    b->d_tiles = 0; b->ntiles = 0; b->lds2p = 0;
+    {
+        const int R = G2G_V2_THREADS / 8, C = G2G_V2_TILE_COLS;
+        std::vector<std::vector<V2Tile> > byk;
+        for (int i = 0; i < n; ++i) {
+            const DevProb &d = b->dp[i];
+            if (d.kind < 0 || !d.v2_ok) continue;
+            const size_t recsz = (16 + 4 * (size_t) (d.capa + (d.kind == 2 ? d.capb : 0)) + 15) & ~(size_t) 15;
+            b->lds2p = std::max(b->lds2p, 5 * recsz);
+            const int al = d.a.left, ar = d.a.right, bl_ = d.b.left, br = d.b.right;
+            const int nstrip = (ar - al + R - 1) / R, nblk = (br - bl_ + C - 1) / C;
+            for (int ti = 0; ti < nstrip; ++ti) {
+                const int m0 = al + ti * R;
+                for (int tj = 0; tj < nblk; ++tj) {
+                    const int c0 = bl_ + tj * C, c1 = std::min(c0 + C, br);
+                    int cbase = std::max(std::max(m0 + d.lw, bl_), c0);
+                    int nsteps = 0;
+                    for (int t = 0; t < R && m0 + t < ar; ++t) {
+                        const int m = m0 + t;
+                        const int lo = std::max(std::max(m + d.lw, bl_), c0), hi = std::min(std::min(m + d.up + 1, br), c1);
+                        if (hi > lo) nsteps = std::max(nsteps, hi - cbase + t);
+                    }
+                    if (!nsteps) continue;
+                    const int k = ti + tj;
+                    if ((int) byk.size() <= k) byk.resize(k + 1);
+                    V2Tile T = {i, ti, tj, nsteps};
+                    byk[k].push_back(T);
+                }
+            }
+        }
+        std::vector<V2Tile> all;
+        b->wave_off.assign(1, 0);
+        for (size_t k = 0; k < byk.size(); ++k) {
+            all.insert(all.end(), byk[k].begin(), byk[k].end());
+            b->wave_off.push_back((int) all.size());
+        }
+        b->ntiles = (long long) all.size();
+        if (!all.empty()) {
+            hipError_t e2 = hipMalloc((void **) &b->d_tiles, sizeof(V2Tile) * all.size());
+            if (e2 == hipSuccess) e2 = hipMemcpy(b->d_tiles, all.data(), sizeof(V2Tile) * all.size(), hipMemcpyHostToDevice);
+            if (e2 != hipSuccess) { g2g_set_error("tiles: %s", hipGetErrorString(e2)); hipFree(b->d_arena); delete b; return G2G_ERR_NOMEM; }
+        }
     }
     if (n) memcpy(bl.h.data() + probs_off, b->dp.data(), sizeof(DevProb) * (size_t) n);
     b->d_probs = (DevProb *) (b->d_arena + probs_off);
@@ -329,8 +382,16 @@ extern "C" int g2g_batch_run(g2g_batch *b)
     if (b->n2) {
         if (b->lds2 > 64 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *) g2g_forward_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2));
-        hipLaunchKernelGGL(g2g_forward_kernel_v2, dim3(b->n2), dim3(G2G_V2_THREADS), b->lds2, ctx->stream,
+        hipLaunchKernelGGL(g2g_v2_prologue_kernel, dim3(b->n2), dim3(128), b->lds2p, ctx->stream,
                            (const DevProb *) b->d_probs, (const int *) b->d_idx2);
+        HIPCHK(hipGetLastError());
+        // one launch per tile wavefront: stream order is the dependency between wavefronts
+        for (size_t k = 0; k + 1 < b->wave_off.size(); ++k) {
+            const int cnt = b->wave_off[k + 1] - b->wave_off[k];
+            if (!cnt) continue;
+            hipLaunchKernelGGL(g2g_forward_kernel_v2, dim3(cnt), dim3(G2G_V2_THREADS), b->lds2, ctx->stream,
+                               (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->wave_off[k]));
+        }
         HIPCHK(hipGetLastError());
     }
     if (b->n1) {
@@ -393,6 +454,7 @@ extern "C" void g2g_batch_free(g2g_batch *b)
     if (!b) return;
     hipSetDevice(b->ctx->device);
     if (b->d_arena) hipFree(b->d_arena);
+    if (b->d_tiles) hipFree(b->d_tiles);
     delete b;
 }
 

@@ -22,7 +22,10 @@
 #define G2G_FWD_THREADS 256
 #endif
 #ifndef G2G_V2_THREADS
-#define G2G_V2_THREADS 512
+#define G2G_V2_THREADS 256
+#endif
+#ifndef G2G_V2_TILE_COLS
+#define G2G_V2_TILE_COLS 256
 #endif
 
 // TraceBackDir values Fwd2c produces (src/aln.h:47-52) and their classes (:59-61)

@@ -445,8 +445,16 @@ __device__ __forceinline__ void list_g2l(li32 *gl, lf64 *fr, const DevSide &s, i
     for (int k = lane; k < e - o; k += nl) { gl[k] = sg[k]; fr[k] = sf[k]; }
 }
 
+// ---- one TILE = (strip of R rows) x (block of G2G_V2_TILE_COLS columns) by one workgroup ------------
+// Tiles of a DP depend on their upper, left and upper-left neighbours only, so all tiles with the same
+// i + j (over every DP of the batch) run in one launch; a big DP is spread over many workgroups instead
+// of bounding the sweep time.  What crosses tile borders lives in HBM:
+//   rowH/rowG/rowG2[3][col]  the last row's corners of a strip (3 buffers: strip i writes i % 3, reads
+//                            (i + 2) % 3; the top boundary chain is "strip -1" and writes buffer 2)
+//   cbH/cbF/cbF2[row]        each row's H corner and F records at the block's right edge
+//   colH[row]                the left boundary chain
 template <int KIND, bool NOLL3>
-__device__ void v2_run(const DevProb &P, lchar *lds)
+__device__ void v2_tile(const DevProb &P, lchar *lds, int ti, int tj, int nsteps)
 {
     const DevSide &a = P.a, &b = P.b;
     const int tid = threadIdx.x, lane = tid & (TEAM - 1), team = tid / TEAM;
@@ -457,156 +465,193 @@ __device__ void v2_run(const DevProb &P, lchar *lds)
     G.R = blockDim.x / TEAM;
     G.lds = lds;
     const int R = G.R, RC = 2 * R;                         // RC: column ring (power of two, >= R + 2)
-    // LDS carve-up after the records: a-side lists of the strip's rows, ring of b-side lists
     const int mla = P.a.maxlist, mlb = (KIND == 2) ? P.b.maxlist : 0;
-    lchar *q = lds + ((size_t) R * G.nslot + EX_N) * G.recsz;
+    lchar *q = lds + (R * G.nslot + EX_N) * G.recsz;
     lf64 *afreq = (lf64 *) q;            q += sizeof(double) * (size_t) R * 3 * mla;
     lf64 *bfreq = (lf64 *) q;            q += sizeof(double) * (size_t) RC * 3 * mlb;
     li32 *aglen = (li32 *) q;            q += sizeof(int) * (size_t) R * 3 * mla;
     li32 *bglen = (li32 *) q;
-    unsigned *rowH = (unsigned *) P.v2_rowH, *rowG = (unsigned *) P.v2_rowG, *rowG2 = (unsigned *) P.v2_rowG2;
-    unsigned *colH = (unsigned *) P.v2_colH;
-    // black record
+    const size_t rbuf = (size_t) P.v2_rowstride * G.ndw;
+    const int bprev = (ti + 2) % 3, bcur = ti % 3;
+    const unsigned *rowHp = (const unsigned *) P.v2_rowH + bprev * rbuf, *rowGp = (const unsigned *) P.v2_rowG + bprev * rbuf;
+    const unsigned *rowG2p = NOLL3 ? (const unsigned *) P.v2_rowG2 + bprev * rbuf : 0;
+    unsigned *rowHc = (unsigned *) P.v2_rowH + bcur * rbuf, *rowGc = (unsigned *) P.v2_rowG + bcur * rbuf;
+    unsigned *rowG2c = NOLL3 ? (unsigned *) P.v2_rowG2 + bcur * rbuf : 0;
+    const unsigned *colH = (const unsigned *) P.v2_colH;
+    unsigned *cbH = (unsigned *) P.v2_cbH, *cbF = (unsigned *) P.v2_cbF, *cbF2 = (unsigned *) P.v2_cbF2;
     if (tid == 0) lrec_black<KIND>(G.extra(EX_BLACK), G.capa);
-    // prologue chains: lane 0 of wave 0 (top row) and lane 0 of the last wave (left column)
-    if (tid == 0) v2_chain_top<KIND>(P, G, G.extra(EX_H0), G.extra(EX_H1), rowH);
-    if (tid == (int) blockDim.x - 64) v2_chain_left<KIND>(P, G, G.row(R - 1, 0), G.row(R - 1, 1), colH);
-    __syncthreads();
     int rrl = b.left - a.right; if (P.lw > rrl) rrl = P.lw;
     const int m_left_last = b.left - rrl;                  // last row whose corner (m, b.left) exists
     const LRec black = G.extra(EX_BLACK);
-    for (int m0 = a.left; m0 < a.right; m0 += R) {
-        const int m = m0 + team;
-        const bool row_ok = m < a.right;
-        int nlo = m + P.lw; if (nlo < b.left) nlo = b.left;
-        int nhi = m + P.up + 1; if (nhi > b.right) nhi = b.right;
-        int cbase = m0 + P.lw; if (cbase < b.left) cbase = b.left;          // first row's first column
-        int mlast = m0 + R - 1; if (mlast > a.right - 1) mlast = a.right - 1;
-        int cend = mlast + P.up + 1; if (cend > b.right) cend = b.right;     // last row's end
-        const int nsteps = (cend - cbase) + (mlast - m0) + 1;
-        // new rows: every ring slot black (reset(f1), reset(f2), fwd2c.h:385-386; G of the DP's first
-        // row is never written and is read as black by the row below, fwd2c.h:401)
-        if (lane < G.nslot) lrec_black<KIND>(G.row(team, lane), G.capa);
-        if (lane == 0 && G.nslot > TEAM) lrec_black<KIND>(G.row(team, 8), G.capa);
-        // this row's static lists -> LDS (they serve every cell of the row)
-        CellLists<LList> L;
-        {
-            li32 *ag = aglen + (size_t) team * 3 * mla;
-            lf64 *af = afreq + (size_t) team * 3 * mla;
-            if (row_ok) for (int v = 0; v < 3; ++v) list_g2l(ag + v * mla, af + v * mla, a, v, m, lane, TEAM);
-            L.as.glen = ag; L.as.freq = af;
-            L.at.glen = ag + mla; L.at.freq = af + mla;
-            L.ar.glen = ag + 2 * mla; L.ar.freq = af + 2 * mla;
-            L.bs = L.bt = L.br = L.as;
+    const int m0 = a.left + ti * R, m = m0 + team;
+    const int c0 = b.left + tj * G2G_V2_TILE_COLS;
+    int c1 = c0 + G2G_V2_TILE_COLS; if (c1 > b.right) c1 = b.right;
+    const bool row_ok = m < a.right;
+    int nlo = m + P.lw; if (nlo < b.left) nlo = b.left;    // the row's range, fwd2c.h:373-374
+    int nhi = m + P.up + 1; if (nhi > b.right) nhi = b.right;
+    const int lo = nlo > c0 ? nlo : c0, hi = nhi < c1 ? nhi : c1;      // ... clipped to this block
+    int cbase = m0 + P.lw; if (cbase < b.left) cbase = b.left; if (cbase < c0) cbase = c0;
+    // every ring slot black (reset(f1), reset(f2), fwd2c.h:385-386; G of the DP's first row is never
+    // written and is read as black by the row below, fwd2c.h:401)
+    if (lane < G.nslot) lrec_black<KIND>(G.row(team, lane), G.capa);
+    if (lane == 0 && G.nslot > TEAM) lrec_black<KIND>(G.row(team, 8), G.capa);
+    team_sync();
+    // rows that continue from the block on the left: their corner at the block edge and their F
+    if (row_ok && c0 - 1 >= nlo && c0 - 1 < nhi) {
+        rec_g2l(G.row(team, SLOT_H(c0)), cbH + (size_t) (m - a.left) * G.ndw, G.ndw, lane);
+        if (lo < hi) {
+            rec_g2l(G.row(team, SLOT_F), cbF + (size_t) (m - a.left) * G.ndw, G.ndw, lane);
+            if (NOLL3) rec_g2l(G.row(team, SLOT_F2), cbF2 + (size_t) (m - a.left) * G.ndw, G.ndw, lane);
         }
-        // column ring: column cbase for step 0
-        if (KIND == 2 && tid < 3 * TEAM) {
-            const int v = tid / TEAM;
-            list_g2l(bglen + (size_t) v * mlb, bfreq + (size_t) v * mlb, b, v, cbase, lane, TEAM);
+    }
+    // this row's static lists -> LDS (they serve every cell of the row)
+    CellLists<LList> L;
+    {
+        li32 *ag = aglen + (size_t) team * 3 * mla;
+        lf64 *af = afreq + (size_t) team * 3 * mla;
+        if (row_ok) for (int v = 0; v < 3; ++v) list_g2l(ag + v * mla, af + v * mla, a, v, m, lane, TEAM);
+        L.as.glen = ag; L.as.freq = af;
+        L.at.glen = ag + mla; L.at.freq = af + mla;
+        L.ar.glen = ag + 2 * mla; L.ar.freq = af + 2 * mla;
+        L.bs = L.bt = L.br = L.as;
+    }
+    if (KIND == 2 && tid < 3 * TEAM) {                     // column ring: column cbase for step 0
+        const int v = tid / TEAM;
+        list_g2l(bglen + (size_t) v * mlb, bfreq + (size_t) v * mlb, b, v, cbase, lane, TEAM);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int n = cbase + s - team;
+        const bool active = row_ok && n >= lo && n < hi;
+        // prefetch the column the first row reaches next step into the ring (3 teams, one view each): the
+        // loads are issued here, the LDS stores wait until the cell work of this step is done
+        int pf_g[4]; double pf_f[4]; int pf_n = 0, pf_base = 0;
+        const bool pf_on = KIND == 2 && tid < 3 * TEAM && cbase + s + 1 < c1;
+        if (pf_on) {
+            const int v = tid / TEAM, pos = cbase + s + 1;
+            const int o = b.off[v][pos + 1];
+            pf_n = b.off[v][pos + 2] - o;
+            pf_base = (((s + 1) & (RC - 1)) * 3 + v) * mlb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = lane + j * TEAM;
+                if (k < pf_n) { pf_g[j] = b.glen[v][o + k]; pf_f[j] = b.freq[v][o + k]; }
+            }
+        }
+        if (active) {
+            CellSrc S; CellDst D;
+            const bool do_vert = m > a.left, do_hori = n > b.left;
+            if (KIND == 2) {
+                const int slot = (s - team) & (RC - 1);
+                const li32 *bg = bglen + (size_t) slot * 3 * mlb;
+                const lf64 *bf = bfreq + (size_t) slot * 3 * mlb;
+                L.bs.glen = bg; L.bs.freq = bf;
+                L.bt.glen = bg + mlb; L.bt.freq = bf + mlb;
+                L.br.glen = bg + 2 * mlb; L.br.freq = bf + 2 * mlb;
+            }
+            // -- sources -----------------------------------------------------------------------
+            if (team == 0) {
+                // the row above lives in HBM (previous strip's last row / the top boundary chain)
+                const LRec hs0 = G.extra(EX_H0), hs1 = G.extra(EX_H1), gu = G.extra(EX_GU), g2u = G.extra(EX_G2U);
+                const LRec hcur = (n & 1) ? hs1 : hs0, hnxt = (n & 1) ? hs0 : hs1;
+                if (n == lo) {                                              // first cell of the row in this block
+                    if (n == b.left && m > a.left) rec_g2l(hcur, colH + (size_t) (m - a.left) * G.ndw, G.ndw, lane);
+                    else rec_g2l(hcur, rowHp + (size_t) n * G.ndw, G.ndw, lane);
+                }
+                const bool up_in = do_vert && (n - (m - 1) <= P.up);       // cell (m-1, n) exists
+                if (up_in || (!do_vert && n + 1 < nhi)) rec_g2l(hnxt, rowHp + (size_t) (n + 1) * G.ndw, G.ndw, lane);
+                if (up_in) {
+                    rec_g2l(gu, rowGp + (size_t) (n + 1) * G.ndw, G.ndw, lane);
+                    if (NOLL3) rec_g2l(g2u, rowG2p + (size_t) (n + 1) * G.ndw, G.ndw, lane);
+                }
+                team_sync();
+                S.hd = hcur; S.hu = up_in ? hnxt : black; S.gu = up_in ? gu : black; S.g2u = up_in ? g2u : black;
+            } else {
+                S.hd = G.row(team - 1, SLOT_H(n));
+                const bool up_in = (n - (m - 1) <= P.up);
+                S.hu = up_in ? G.row(team - 1, SLOT_H(n + 1)) : black;
+                S.gu = up_in ? G.row(team - 1, SLOT_G(n + 1)) : black;
+                S.g2u = (NOLL3 && up_in) ? G.row(team - 1, SLOT_G2(n + 1)) : black;
+            }
+            const bool left_in = (n - 1 - m >= P.lw);                      // cell (m, n-1) exists
+            S.hl = left_in ? G.row(team, SLOT_H(n)) : black;
+            S.fl = left_in ? G.row(team, SLOT_F) : black;
+            S.f2l = (NOLL3 && left_in) ? G.row(team, SLOT_F2) : black;
+            D.h = G.row(team, SLOT_H(n + 1));
+            D.g = G.row(team, SLOT_G(n + 1));
+            D.g2 = G.row(team, NOLL3 ? SLOT_G2(n + 1) : SLOT_G(n + 1));
+            D.f = G.row(team, SLOT_F);
+            D.f2 = G.row(team, NOLL3 ? SLOT_F2 : SLOT_F);
+            int mlo, mhi;
+            const int d = m + n;
+            diag_rows(d, a.left, a.right, b.left, b.right, P.lw, P.up, &mlo, &mhi);
+            uint8_t *tr = P.trace + (size_t) (d - P.d0) * P.tstride + (m - mlo);
+            v2_cell<KIND, NOLL3>(P, G, L, m, n, lane, S, D, do_vert, do_hori, tr);
+            // the row below starts at b.left with the left-boundary corner (m+1, b.left) as its
+            // diagonal source: park it in this row's H ring where that row will look for it
+            if (n == b.left && team + 1 < R && m + 1 < a.right && m + 1 <= m_left_last && (m + 1 + P.lw) <= b.left) {
+                rec_g2l(G.row(team, SLOT_H(b.left)), colH + (size_t) (m + 1 - a.left) * G.ndw, G.ndw, lane);
+            }
+            // strip boundary: the last row's corners go to HBM for the strip below
+            if (team == R - 1 || m == a.right - 1) {
+                rec_l2g(rowHc + (size_t) (n + 1) * G.ndw, D.h, G.ndw, lane);
+                rec_l2g(rowGc + (size_t) (n + 1) * G.ndw, D.g, G.ndw, lane);
+                if (NOLL3) rec_l2g(rowG2c + (size_t) (n + 1) * G.ndw, D.g2, G.ndw, lane);
+            }
+            // block boundary: this row's corner and F records for the block on the right
+            if (n == c1 - 1 && c1 < b.right) {
+                rec_l2g(cbH + (size_t) (m - a.left) * G.ndw, D.h, G.ndw, lane);
+                rec_l2g(cbF + (size_t) (m - a.left) * G.ndw, D.f, G.ndw, lane);
+                if (NOLL3) rec_l2g(cbF2 + (size_t) (m - a.left) * G.ndw, D.f2, G.ndw, lane);
+            }
+            if (m == a.right - 1 && n == b.right - 1 && lane == 0) *P.score = lval(D.h);
+        }
+        if (pf_on) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = lane + j * TEAM;
+                if (k < pf_n) { bglen[pf_base + k] = pf_g[j]; bfreq[pf_base + k] = pf_f[j]; }
+            }
+            if (pf_n > 4 * TEAM) {                          // (lists longer than 32 entries: straight copy)
+                const int v = tid / TEAM, pos = cbase + s + 1, o = b.off[v][pos + 1];
+                for (int k = lane + 4 * TEAM; k < pf_n; k += TEAM) { bglen[pf_base + k] = b.glen[v][o + k]; bfreq[pf_base + k] = b.freq[v][o + k]; }
+            }
         }
         __syncthreads();
-        for (int s = 0; s < nsteps; ++s) {
-            const int n = cbase + s - team;
-            const bool active = row_ok && n >= nlo && n < nhi;
-            // prefetch the column row m0 reaches next step into the ring (3 teams, one view each): the
-            // loads are issued here, the LDS stores wait until the cell work of this step is done
-            int pf_g[4]; double pf_f[4]; int pf_n = 0, pf_base = 0;
-            const bool pf_on = KIND == 2 && tid < 3 * TEAM && cbase + s + 1 < b.right;
-            if (pf_on) {
-                const int v = tid / TEAM, pos = cbase + s + 1;
-                const int o = b.off[v][pos + 1];
-                pf_n = b.off[v][pos + 2] - o;
-                pf_base = (((s + 1) & (RC - 1)) * 3 + v) * mlb;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = lane + j * TEAM;
-                    if (k < pf_n) { pf_g[j] = b.glen[v][o + k]; pf_f[j] = b.freq[v][o + k]; }
-                }
-            }
-            if (active) {
-                CellSrc S; CellDst D;
-                const bool do_vert = m > a.left, do_hori = n > b.left;
-                if (KIND == 2) {
-                    const int slot = (s - team) & (RC - 1);
-                    const li32 *bg = bglen + (size_t) slot * 3 * mlb;
-                    const lf64 *bf = bfreq + (size_t) slot * 3 * mlb;
-                    L.bs.glen = bg; L.bs.freq = bf;
-                    L.bt.glen = bg + mlb; L.bt.freq = bf + mlb;
-                    L.br.glen = bg + 2 * mlb; L.br.freq = bf + 2 * mlb;
-                }
-                // -- sources -------------------------------------------------------------------
-                if (team == 0) {
-                    // the row above lives in HBM (previous strip's last row / the top boundary chain)
-                    const LRec hs0 = G.extra(EX_H0), hs1 = G.extra(EX_H1), gu = G.extra(EX_GU), g2u = G.extra(EX_G2U);
-                    const LRec hcur = (n & 1) ? hs1 : hs0, hnxt = (n & 1) ? hs0 : hs1;
-                    if (n == nlo) {                                             // first cell of the row
-                        if (n == b.left && m > a.left) rec_g2l(hcur, colH + (size_t) (m - a.left) * G.ndw, G.ndw, lane);
-                        else rec_g2l(hcur, rowH + (size_t) n * G.ndw, G.ndw, lane);
-                    }
-                    const bool up_in = do_vert && (n - (m - 1) <= P.up);       // cell (m-1, n) exists
-                    if (up_in || (!do_vert && n + 1 < nhi)) rec_g2l(hnxt, rowH + (size_t) (n + 1) * G.ndw, G.ndw, lane);
-                    if (up_in) {
-                        rec_g2l(gu, rowG + (size_t) (n + 1) * G.ndw, G.ndw, lane);
-                        if (NOLL3) rec_g2l(g2u, rowG2 + (size_t) (n + 1) * G.ndw, G.ndw, lane);
-                    }
-                    team_sync();
-                    S.hd = hcur; S.hu = up_in ? hnxt : black; S.gu = up_in ? gu : black; S.g2u = up_in ? g2u : black;
-                } else {
-                    S.hd = G.row(team - 1, SLOT_H(n));
-                    const bool up_in = (n - (m - 1) <= P.up);
-                    S.hu = up_in ? G.row(team - 1, SLOT_H(n + 1)) : black;
-                    S.gu = up_in ? G.row(team - 1, SLOT_G(n + 1)) : black;
-                    S.g2u = (NOLL3 && up_in) ? G.row(team - 1, SLOT_G2(n + 1)) : black;
-                }
-                const bool left_in = (n - 1 - m >= P.lw);                      // cell (m, n-1) exists
-                S.hl = left_in ? G.row(team, SLOT_H(n)) : black;
-                S.fl = left_in ? G.row(team, SLOT_F) : black;
-                S.f2l = (NOLL3 && left_in) ? G.row(team, SLOT_F2) : black;
-                D.h = G.row(team, SLOT_H(n + 1));
-                D.g = G.row(team, SLOT_G(n + 1));
-                D.g2 = G.row(team, NOLL3 ? SLOT_G2(n + 1) : SLOT_G(n + 1));
-                D.f = G.row(team, SLOT_F);
-                D.f2 = G.row(team, NOLL3 ? SLOT_F2 : SLOT_F);
-                int mlo, mhi;
-                const int d = m + n;
-                diag_rows(d, a.left, a.right, b.left, b.right, P.lw, P.up, &mlo, &mhi);
-                uint8_t *tr = P.trace + (size_t) (d - P.d0) * P.tstride + (m - mlo);
-                v2_cell<KIND, NOLL3>(P, G, L, m, n, lane, S, D, do_vert, do_hori, tr);
-                // the row below starts at b.left with the left-boundary corner (m+1, b.left) as its
-                // diagonal source: park it in this row's H ring where that row will look for it
-                if (n == b.left && team + 1 < R && m + 1 < a.right && m + 1 <= m_left_last && (m + 1 + P.lw) <= b.left) {
-                    rec_g2l(G.row(team, SLOT_H(b.left)), colH + (size_t) (m + 1 - a.left) * G.ndw, G.ndw, lane);
-                }
-                // strip boundary: the last row's corners go to HBM for the next strip
-                if (team == R - 1 || m == a.right - 1) {
-                    rec_l2g(rowH + (size_t) (n + 1) * G.ndw, D.h, G.ndw, lane);
-                    rec_l2g(rowG + (size_t) (n + 1) * G.ndw, D.g, G.ndw, lane);
-                    if (NOLL3) rec_l2g(rowG2 + (size_t) (n + 1) * G.ndw, D.g2, G.ndw, lane);
-                }
-                if (m == a.right - 1 && n == b.right - 1 && lane == 0) *P.score = lval(D.h);
-            }
-            if (pf_on) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = lane + j * TEAM;
-                    if (k < pf_n) { bglen[pf_base + k] = pf_g[j]; bfreq[pf_base + k] = pf_f[j]; }
-                }
-                if (pf_n > 4 * TEAM) {                      // (lists longer than 32 entries: straight copy)
-                    const int v = tid / TEAM, pos = cbase + s + 1, o = b.off[v][pos + 1];
-                    for (int k = lane + 4 * TEAM; k < pf_n; k += TEAM) { bglen[pf_base + k] = b.glen[v][o + k]; bfreq[pf_base + k] = b.freq[v][o + k]; }
-                }
-            }
-            __syncthreads();
-        }
     }
 }
 
-extern "C" __global__ void __launch_bounds__(G2G_V2_THREADS)
-g2g_forward_kernel_v2(const DevProb *probs, const int *idx)
+// boundary chains of every DP: one small workgroup each (wave 0: top row, wave 1: left column)
+template <int KIND>
+__device__ void v2_prologue(const DevProb &P, lchar *lds)
+{
+    V2Geom G;
+    G.capa = P.capa; G.capb = (KIND == 2) ? P.capb : 0;
+    G.recsz = (16 + 4 * (G.capa + G.capb) + 15) & ~15; G.ndw = G.recsz / 4;
+    G.nslot = 1; G.R = 4; G.lds = lds;
+    unsigned *rowH2 = (unsigned *) P.v2_rowH + 2 * (size_t) P.v2_rowstride * G.ndw;
+    if (threadIdx.x == 0) v2_chain_top<KIND>(P, G, G.row(0, 0), G.row(1, 0), rowH2);
+    if (threadIdx.x == 64) v2_chain_left<KIND>(P, G, G.row(2, 0), G.row(3, 0), (unsigned *) P.v2_colH);
+}
+
+extern "C" __global__ void __launch_bounds__(128)
+g2g_v2_prologue_kernel(const DevProb *probs, const int *idx)
 {
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];
     lchar *lds = (lchar *) g2g_lds;
     const DevProb &P = probs[idx[blockIdx.x]];
-    if (P.kind == 1) { if (P.noll == 3) v2_run<1, true>(P, lds); else v2_run<1, false>(P, lds); }
-    else if (P.kind == 2) { if (P.noll == 3) v2_run<2, true>(P, lds); else v2_run<2, false>(P, lds); }
+    if (P.kind == 1) v2_prologue<1>(P, lds); else if (P.kind == 2) v2_prologue<2>(P, lds);
+}
+
+struct V2Tile { int prob, ti, tj, nsteps; };
+
+extern "C" __global__ void __launch_bounds__(G2G_V2_THREADS)
+g2g_forward_kernel_v2(const DevProb *probs, const V2Tile *tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) char g2g_lds[];
+    lchar *lds = (lchar *) g2g_lds;
+    const V2Tile T = tiles[blockIdx.x];
+    const DevProb &P = probs[T.prob];
+    if (P.kind == 1) { if (P.noll == 3) v2_tile<1, true>(P, lds, T.ti, T.tj, T.nsteps); else v2_tile<1, false>(P, lds, T.ti, T.tj, T.nsteps); }
+    else if (P.kind == 2) { if (P.noll == 3) v2_tile<2, true>(P, lds, T.ti, T.tj, T.nsteps); else v2_tile<2, false>(P, lds, T.ti, T.tj, T.nsteps); }
 }
