@@ -47,6 +47,8 @@ struct DevProb {
     void    *v2_rowH, *v2_rowG, *v2_rowG2, *v2_colH;   // rowX: 3 buffers of v2_rowstride records
     void    *v2_cbH, *v2_cbF, *v2_cbF2;                // per row: records at the current column-block edge
     int      v2_rowstride;
+    double  *v2_sim;       // sim2 of every in-band cell, row-major, row m at v2_rowoff[m - a.left] (- nlo(m))
+    long long *v2_rowoff;
     int      v2_ok;      // 1: handled by g2g_forward_kernel_v2
     // trace
     uint8_t *trace;

@@ -32,7 +32,9 @@ struct g2g_ctx {
     int device;
     int ok;
     hipStream_t stream;
+    hipStream_t vstream[4];         // one per v2 kernel variant: their tile wavefronts are independent
     hipEvent_t ev[4];
+    hipEvent_t vev[5];
 };
 
 extern "C" g2g_ctx *g2g_create(int device)
@@ -50,6 +52,8 @@ extern "C" g2g_ctx *g2g_create(int device)
     c->ok = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; g2g_set_error("%s", "stream"); return NULL; }
     for (int i = 0; i < 4; ++i) hipEventCreate(&c->ev[i]);
+    for (int i = 0; i < 4; ++i) hipStreamCreateWithFlags(&c->vstream[i], hipStreamNonBlocking);
+    for (int i = 0; i < 5; ++i) hipEventCreateWithFlags(&c->vev[i], hipEventDisableTiming);
     // the code object must contain an image for this GPU (the library is built for gfx950 only)
     hipFuncAttributes fa;
     hipError_t e = hipFuncGetAttributes(&fa, (const void *) g2g_forward_kernel);
@@ -65,6 +69,8 @@ extern "C" void g2g_destroy(g2g_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 5; ++i) hipEventDestroy(c->vev[i]);
+    for (int i = 0; i < 4; ++i) hipStreamDestroy(c->vstream[i]);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -100,8 +106,9 @@ struct g2g_batch {
     int n1, n2;
     size_t lds2;                    // dynamic LDS bytes of the v2 launch
     size_t lds2p;                   // ... of the v2 prologue launch
+    int v2_maxrows;                 // longest a-range among the v2 problems
     V2Tile *d_tiles;                // v2 tiles ordered by wavefront index i + j
-    std::vector<int> wave_off;      // tiles of wavefront k: [wave_off[k], wave_off[k+1])
+    std::vector<int> wave_off;      // tiles of (wavefront k, variant v): [wave_off[4k+v], wave_off[4k+v+1])
     long long ntiles;
     float fwd_ms, tb_ms;
 };
@@ -111,8 +118,8 @@ static size_t v2_lds_bytes(int kind, int noll, int capa, int capb, int mla, int 
 {
     const size_t recsz = (16 + 4 * (size_t) (capa + (kind == 2 ? capb : 0)) + 15) & ~(size_t) 15;
     const size_t R = G2G_V2_THREADS / 8;
-    const size_t lists = (size_t) 12 * 3 * (R * mla + (kind == 2 ? 2 * R * mlb : 0));   // glen i32 + freq f64
-    return ((noll == 3 ? 9 : 6) * R + 5) * recsz + lists + 16;
+    const size_t lists = (size_t) 12 * 3 * (R * mla + (kind == 2 ? (R + 2) * mlb : 0));   // glen i32 + freq f64
+    return ((noll == 3 ? 9 : 6) * R + 5) * recsz + 16 * R + lists + 16;
 }
 static const size_t V2_LDS_MAX = 160 * 1024;
 
@@ -282,6 +289,8 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             d.v2_cbH = OFF<void>(take(recsz * ((size_t) (ar - al) + 3)));
             d.v2_cbF = OFF<void>(take(recsz * ((size_t) (ar - al) + 3)));
             if (d.noll == 3) d.v2_cbF2 = OFF<void>(take(recsz * ((size_t) (ar - al) + 3)));
+            d.v2_rowoff = OFF<long long>(take(sizeof(long long) * ((size_t) (ar - al) + 2)));
+            d.v2_sim = OFF<double>(take(sizeof(double) * (size_t) cells + 64));
         }
         d.tcap = (ar - al) + (br - bl_) + 4;
         b->tcap[i] = d.tcap;
@@ -304,6 +313,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         }
         rebase(d.v2_rowH, b->d_arena); rebase(d.v2_rowG, b->d_arena); rebase(d.v2_rowG2, b->d_arena); rebase(d.v2_colH, b->d_arena);
         rebase(d.v2_cbH, b->d_arena); rebase(d.v2_cbF, b->d_arena); rebase(d.v2_cbF2, b->d_arena);
+        rebase(d.v2_rowoff, b->d_arena); rebase(d.v2_sim, b->d_arena);
         rebase(d.trace, b->d_arena); rebase(d.score, b->d_arena); rebase(d.ntrace, b->d_arena); rebase(d.otrace, b->d_arena);
     }
     {
@@ -319,15 +329,16 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         b->d_idx2 = b->d_idx1 + (n > 0 ? n : 1);
     }
     // v2 tiles: (strip i of R rows) x (block j of G2G_V2_TILE_COLS columns), grouped by wavefront i + j
-    b->d_tiles = 0; b->ntiles = 0; b->lds2p = 0;
+    b->d_tiles = 0; b->ntiles = 0; b->lds2p = 0; b->v2_maxrows = 1;
     {
         const int R = G2G_V2_THREADS / 8, C = G2G_V2_TILE_COLS;
-        std::vector<std::vector<V2Tile> > byk;
+        std::vector<std::vector<V2Tile> > byk;           // index 4 * wavefront + variant (hf2, hf3, pf2, pf3)
         for (int i = 0; i < n; ++i) {
             const DevProb &d = b->dp[i];
             if (d.kind < 0 || !d.v2_ok) continue;
             const size_t recsz = (16 + 4 * (size_t) (d.capa + (d.kind == 2 ? d.capb : 0)) + 15) & ~(size_t) 15;
-            b->lds2p = std::max(b->lds2p, 5 * recsz);
+            b->lds2p = std::max(b->lds2p, 5 * recsz + 64);
+            b->v2_maxrows = std::max(b->v2_maxrows, d.a.right - d.a.left);
             const int al = d.a.left, ar = d.a.right, bl_ = d.b.left, br = d.b.right;
             const int nstrip = (ar - al + R - 1) / R, nblk = (br - bl_ + C - 1) / C;
             for (int ti = 0; ti < nstrip; ++ti) {
@@ -342,8 +353,8 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
                         if (hi > lo) nsteps = std::max(nsteps, hi - cbase + t);
                     }
                     if (!nsteps) continue;
-                    const int k = ti + tj;
-                    if ((int) byk.size() <= k) byk.resize(k + 1);
+                    const int k = 4 * (ti + tj) + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
+                    if ((int) byk.size() <= k) byk.resize((k / 4 + 1) * 4);
                     V2Tile T = {i, ti, tj, nsteps};
                     byk[k].push_back(T);
                 }
@@ -380,19 +391,38 @@ extern "C" int g2g_batch_run(g2g_batch *b)
     if (b->n == 0) return G2G_OK;
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     if (b->n2) {
-        if (b->lds2 > 64 * 1024)
-            HIPCHK(hipFuncSetAttribute((const void *) g2g_forward_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2));
-        hipLaunchKernelGGL(g2g_v2_prologue_kernel, dim3(b->n2), dim3(128), b->lds2p, ctx->stream,
+        if (b->lds2 > 64 * 1024) {
+            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_hf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2));
+            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_hf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2));
+            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_pf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2));
+            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_pf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2));
+        }
+        hipLaunchKernelGGL(g2g_v2_prologue_kernel, dim3(b->n2), dim3(192), b->lds2p, ctx->stream,
+                           (const DevProb *) b->d_probs, (const int *) b->d_idx2);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(g2g_v2_sim_kernel, dim3(b->v2_maxrows, b->n2), dim3(256), 0, ctx->stream,
                            (const DevProb *) b->d_probs, (const int *) b->d_idx2);
         HIPCHK(hipGetLastError());
         // one launch per tile wavefront: stream order is the dependency between wavefronts
+        typedef void (*v2k_t)(const DevProb *, const V2Tile *);
+        static const v2k_t v2k[4] = {g2g_v2_hf2, g2g_v2_hf3, g2g_v2_pf2, g2g_v2_pf3};
+        // the wavefronts of one variant are ordered by its stream; variants overlap each other
+        HIPCHK(hipEventRecord(ctx->vev[4], ctx->stream));
+        bool used[4] = {false, false, false, false};
+        for (int v = 0; v < 4; ++v) HIPCHK(hipStreamWaitEvent(ctx->vstream[v], ctx->vev[4], 0));
         for (size_t k = 0; k + 1 < b->wave_off.size(); ++k) {
             const int cnt = b->wave_off[k + 1] - b->wave_off[k];
             if (!cnt) continue;
-            hipLaunchKernelGGL(g2g_forward_kernel_v2, dim3(cnt), dim3(G2G_V2_THREADS), b->lds2, ctx->stream,
+            used[k & 3] = true;
+            hipLaunchKernelGGL(v2k[k & 3], dim3(cnt), dim3(G2G_V2_THREADS), b->lds2, ctx->vstream[k & 3],
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->wave_off[k]));
         }
         HIPCHK(hipGetLastError());
+        for (int v = 0; v < 4; ++v) {
+            if (!used[v]) continue;
+            HIPCHK(hipEventRecord(ctx->vev[v], ctx->vstream[v]));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[v], 0));
+        }
     }
     if (b->n1) {
         hipLaunchKernelGGL(g2g_forward_kernel, dim3(b->n1), dim3(G2G_FWD_THREADS), 0, ctx->stream,

@@ -24,6 +24,9 @@
 #ifndef G2G_V2_THREADS
 #define G2G_V2_THREADS 256
 #endif
+#ifndef G2G_V2_MINWAVES
+#define G2G_V2_MINWAVES 4
+#endif
 #ifndef G2G_V2_TILE_COLS
 #define G2G_V2_TILE_COLS 256
 #endif

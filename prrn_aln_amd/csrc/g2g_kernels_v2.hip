@@ -159,8 +159,9 @@ struct V2Geom {
     int R;                            // rows per strip
     lchar *lds;
     // slot ids inside a row
-    __device__ __forceinline__ LRec row(int t, int slot) const { LRec r; r.p = lds + (t * nslot + slot) * recsz; return r; }
-    __device__ __forceinline__ LRec extra(int k) const { LRec r; r.p = lds + (R * nslot + k) * recsz; return r; }
+    // +16 B per row: the same field of the 8 rows of a wave must not share an LDS bank
+    __device__ __forceinline__ LRec row(int t, int slot) const { LRec r; r.p = lds + t * (nslot * recsz + 16) + slot * recsz; return r; }
+    __device__ __forceinline__ LRec extra(int k) const { LRec r; r.p = lds + R * (nslot * recsz + 16) + k * recsz; return r; }
 };
 // ring slots: H corner c -> c mod 3 (0..2); G corner c -> 3 + (c & 1); F -> 5; G2 -> 6 + (c & 1); F2 -> 8
 __device__ __forceinline__ int mod3(int c) { return ((c % 3) + 3) % 3; }
@@ -276,7 +277,8 @@ struct CellDst { LRec h, g, g2, f, f2; };                 // records it writes
 
 template <int KIND, bool NOLL3>
 __device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList> &L, int m, int n, int lane,
-                        const CellSrc &S, const CellDst &D, bool do_vert, bool do_hori, uint8_t *tr)
+                        const CellSrc &S, const CellDst &D, bool do_vert, bool do_hori, uint8_t *tr,
+                        double dab, double pua, double pub)
 {
     const DevSide &a = P.a, &b = P.b;
     const int capa = G.capa;
@@ -301,12 +303,10 @@ __device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList
         if (on && jk == 2) r = p_newgap1(P, L.as, ldla(rc), lglb(rc));
         if (on && jk != 2) r = p_newgap2(P, jk == 0 ? L.at : L.ar, lglb(rc), ldla(rc));
     }
-    double r8 = r;                                       // lane 6's horizontal2 cost (Noll 3)
-    if (lane == 6) r = sim2(P, m, n);
+    const double r8 = r;                                 // lane 6's horizontal2 cost (Noll 3)
     const double c_d0 = __shfl(r, 0, TEAM), c_d1 = __shfl(r, 1, TEAM);
     const double c_gnpv = __shfl(r, 2, TEAM), c_gopv = __shfl(r, 3, TEAM);
     const double c_gnph = __shfl(r, 4, TEAM), c_goph = __shfl(r, 5, TEAM);
-    const double dab = __shfl(r, 6, TEAM);
     const double c_gnpv2 = NOLL3 ? __shfl(r, 7, TEAM) : 0;
     const double c_gnph2 = NOLL3 ? __shfl(r8, 6, TEAM) : 0;
     // ---- scalar decisions, replayed by every lane (fwd2c.h:395-453) ------------------------------
@@ -319,8 +319,6 @@ __device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList
     int gdir = 0, g2dir = 0, fdir = 0, f2dir = 0;
     bool g_from_h = false, g2_from_h = false, f_from_h = false, f2_from_h = false;
     if (do_vert) {
-        int nf = m + P.lw; if (nf < b.left) nf = b.left;
-        const double pua = unpa(P, m, a.nils ? n : nf);
         const double gnp = c_gnpv;
         gop = c_gopv;
         const bool hu_nv = !isvert(ldir(S.hu));
@@ -346,7 +344,6 @@ __device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList
         mxval = NEVSEL; win = 1;                     // first row: mx starts as the untouched black G
     }
     if (do_hori) {
-        const double pub = unpb(P, n, m);
         const double gnp = c_gnph;
         gop = c_goph;
         const bool hl_nh = !ishori(ldir(S.hl));
@@ -464,9 +461,9 @@ __device__ void v2_tile(const DevProb &P, lchar *lds, int ti, int tj, int nsteps
     G.nslot = NOLL3 ? 9 : 6;
     G.R = blockDim.x / TEAM;
     G.lds = lds;
-    const int R = G.R, RC = 2 * R;                         // RC: column ring (power of two, >= R + 2)
+    const int R = G.R, RC = R + 2;                         // RC: slots of the column ring
     const int mla = P.a.maxlist, mlb = (KIND == 2) ? P.b.maxlist : 0;
-    lchar *q = lds + (R * G.nslot + EX_N) * G.recsz;
+    lchar *q = lds + R * (G.nslot * G.recsz + 16) + EX_N * G.recsz;
     lf64 *afreq = (lf64 *) q;            q += sizeof(double) * (size_t) R * 3 * mla;
     lf64 *bfreq = (lf64 *) q;            q += sizeof(double) * (size_t) RC * 3 * mlb;
     li32 *aglen = (li32 *) q;            q += sizeof(int) * (size_t) R * 3 * mla;
@@ -519,10 +516,27 @@ __device__ void v2_tile(const DevProb &P, lchar *lds, int ti, int tj, int nsteps
         const int v = tid / TEAM;
         list_g2l(bglen + (size_t) v * mlb, bfreq + (size_t) v * mlb, b, v, cbase, lane, TEAM);
     }
+    // per-row constants and one-step-ahead register pipelines (column score, b's column thickness,
+    // and -- for the strip's first row -- the upper neighbours' records): nothing that comes from HBM is
+    // waited for inside the step that uses it
+    const double a_efq = row_ok ? thk_at(a, m)[2] : 0;
+    int nf0 = m + P.lw; if (nf0 < b.left) nf0 = b.left;
+    const double pua_row = row_ok ? unpa(P, m, nf0) : 0;                 // fwd2c.h:380 (402 when a.inex.nils)
+    const double *simrow = row_ok ? P.v2_sim + P.v2_rowoff[m - a.left] - nlo : 0;
+    double sim_cur = 0, bc_cur = 0;
+    bool have = false;
+    int rslot = (RC - team % RC) % RC;                     // ring slot of column cbase + s - team
+    int wslot = 1 % RC;                                    // ring slot of column cbase + s + 1
+    const bool stage_regs = G.ndw <= 4 * TEAM;            // record fits 4 dwords per lane (128 B)
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int n = cbase + s - team;
         const bool active = row_ok && n >= lo && n < hi;
+        double sim_nx = 0, bc_nx = 0;
+        if (active) {
+            if (!have) { sim_cur = simrow[n]; bc_cur = thk_at(b, n)[0]; }
+            if (n + 1 < hi) { sim_nx = simrow[n + 1]; bc_nx = thk_at(b, n + 1)[0]; }
+        }
         // prefetch the column the first row reaches next step into the ring (3 teams, one view each): the
         // loads are issued here, the LDS stores wait until the cell work of this step is done
         int pf_g[4]; double pf_f[4]; int pf_n = 0, pf_base = 0;
@@ -531,7 +545,7 @@ __device__ void v2_tile(const DevProb &P, lchar *lds, int ti, int tj, int nsteps
             const int v = tid / TEAM, pos = cbase + s + 1;
             const int o = b.off[v][pos + 1];
             pf_n = b.off[v][pos + 2] - o;
-            pf_base = (((s + 1) & (RC - 1)) * 3 + v) * mlb;
+            pf_base = (wslot * 3 + v) * mlb;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = lane + j * TEAM;
@@ -542,7 +556,7 @@ __device__ void v2_tile(const DevProb &P, lchar *lds, int ti, int tj, int nsteps
             CellSrc S; CellDst D;
             const bool do_vert = m > a.left, do_hori = n > b.left;
             if (KIND == 2) {
-                const int slot = (s - team) & (RC - 1);
+                const int slot = rslot;
                 const li32 *bg = bglen + (size_t) slot * 3 * mlb;
                 const lf64 *bf = bfreq + (size_t) slot * 3 * mlb;
                 L.bs.glen = bg; L.bs.freq = bf;
@@ -550,19 +564,38 @@ __device__ void v2_tile(const DevProb &P, lchar *lds, int ti, int tj, int nsteps
                 L.br.glen = bg + 2 * mlb; L.br.freq = bf + 2 * mlb;
             }
             // -- sources -----------------------------------------------------------------------
+            unsigned pfh[4], pfgu[4], pfg2u[4];
+            bool pf_h = false, pf_gu = false;
             if (team == 0) {
-                // the row above lives in HBM (previous strip's last row / the top boundary chain)
+                // the row above lives in HBM (previous strip's last row / the top boundary chain); its
+                // records for the NEXT column are fetched into registers now and parked in LDS after the cell
                 const LRec hs0 = G.extra(EX_H0), hs1 = G.extra(EX_H1), gu = G.extra(EX_GU), g2u = G.extra(EX_G2U);
                 const LRec hcur = (n & 1) ? hs1 : hs0, hnxt = (n & 1) ? hs0 : hs1;
-                if (n == lo) {                                              // first cell of the row in this block
-                    if (n == b.left && m > a.left) rec_g2l(hcur, colH + (size_t) (m - a.left) * G.ndw, G.ndw, lane);
-                    else rec_g2l(hcur, rowHp + (size_t) n * G.ndw, G.ndw, lane);
-                }
                 const bool up_in = do_vert && (n - (m - 1) <= P.up);       // cell (m-1, n) exists
-                if (up_in || (!do_vert && n + 1 < nhi)) rec_g2l(hnxt, rowHp + (size_t) (n + 1) * G.ndw, G.ndw, lane);
-                if (up_in) {
-                    rec_g2l(gu, rowGp + (size_t) (n + 1) * G.ndw, G.ndw, lane);
-                    if (NOLL3) rec_g2l(g2u, rowG2p + (size_t) (n + 1) * G.ndw, G.ndw, lane);
+                if (n == lo || !stage_regs) {                               // first cell of the row in this block
+                    if (n == lo) {
+                        if (n == b.left && m > a.left) rec_g2l(hcur, colH + (size_t) (m - a.left) * G.ndw, G.ndw, lane);
+                        else rec_g2l(hcur, rowHp + (size_t) n * G.ndw, G.ndw, lane);
+                    }
+                    if (up_in || (!do_vert && n + 1 < nhi)) rec_g2l(hnxt, rowHp + (size_t) (n + 1) * G.ndw, G.ndw, lane);
+                    if (up_in) {
+                        rec_g2l(gu, rowGp + (size_t) (n + 1) * G.ndw, G.ndw, lane);
+                        if (NOLL3) rec_g2l(g2u, rowG2p + (size_t) (n + 1) * G.ndw, G.ndw, lane);
+                    }
+                }
+                if (stage_regs && n + 1 < hi) {
+                    const bool up_nx = do_vert && (n + 1 - (m - 1) <= P.up);
+                    pf_h = up_nx || (!do_vert && n + 2 < nhi);
+                    pf_gu = up_nx;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = lane + j * TEAM;
+                        if (k < G.ndw) {
+                            if (pf_h) pfh[j] = rowHp[(size_t) (n + 2) * G.ndw + k];
+                            if (pf_gu) pfgu[j] = rowGp[(size_t) (n + 2) * G.ndw + k];
+                            if (NOLL3 && pf_gu) pfg2u[j] = rowG2p[(size_t) (n + 2) * G.ndw + k];
+                        }
+                    }
                 }
                 team_sync();
                 S.hd = hcur; S.hu = up_in ? hnxt : black; S.gu = up_in ? gu : black; S.g2u = up_in ? g2u : black;
@@ -586,7 +619,22 @@ __device__ void v2_tile(const DevProb &P, lchar *lds, int ti, int tj, int nsteps
             const int d = m + n;
             diag_rows(d, a.left, a.right, b.left, b.right, P.lw, P.up, &mlo, &mhi);
             uint8_t *tr = P.trace + (size_t) (d - P.d0) * P.tstride + (m - mlo);
-            v2_cell<KIND, NOLL3>(P, G, L, m, n, lane, S, D, do_vert, do_hori, tr);
+            const double pua = a.nils ? unpa(P, m, n) : pua_row;
+            const double pub = bc_cur * a_efq * -P.u;                       // unp1(bsi, asi), maln.h:185-187
+            v2_cell<KIND, NOLL3>(P, G, L, m, n, lane, S, D, do_vert, do_hori, tr, sim_cur, pua, pub);
+            if (team == 0 && (pf_h || pf_gu)) {                             // park the prefetched neighbours
+                const LRec hslot = (n & 1) ? G.extra(EX_H1) : G.extra(EX_H0);   // corner n+2 shares corner n's slot
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = lane + j * TEAM;
+                    if (k < G.ndw) {
+                        if (pf_h) ((lu32 *) hslot.p)[k] = pfh[j];
+                        if (pf_gu) ((lu32 *) G.extra(EX_GU).p)[k] = pfgu[j];
+                        if (NOLL3 && pf_gu) ((lu32 *) G.extra(EX_G2U).p)[k] = pfg2u[j];
+                    }
+                }
+            }
+            sim_cur = sim_nx; bc_cur = bc_nx; have = (n + 1 < hi);
             // the row below starts at b.left with the left-boundary corner (m+1, b.left) as its
             // diagonal source: park it in this row's H ring where that row will look for it
             if (n == b.left && team + 1 < R && m + 1 < a.right && m + 1 <= m_left_last && (m + 1 + P.lw) <= b.left) {
@@ -617,6 +665,8 @@ __device__ void v2_tile(const DevProb &P, lchar *lds, int ti, int tj, int nsteps
                 for (int k = lane + 4 * TEAM; k < pf_n; k += TEAM) { bglen[pf_base + k] = b.glen[v][o + k]; bfreq[pf_base + k] = b.freq[v][o + k]; }
             }
         }
+        if (++rslot == RC) rslot = 0;
+        if (++wslot == RC) wslot = 0;
         __syncthreads();
     }
 }
@@ -632,9 +682,19 @@ __device__ void v2_prologue(const DevProb &P, lchar *lds)
     unsigned *rowH2 = (unsigned *) P.v2_rowH + 2 * (size_t) P.v2_rowstride * G.ndw;
     if (threadIdx.x == 0) v2_chain_top<KIND>(P, G, G.row(0, 0), G.row(1, 0), rowH2);
     if (threadIdx.x == 64) v2_chain_left<KIND>(P, G, G.row(2, 0), G.row(3, 0), (unsigned *) P.v2_colH);
+    if (threadIdx.x == 128) {                               // row offsets of the column-score matrix
+        long long o = 0;
+        for (int m = P.a.left; m < P.a.right; ++m) {
+            int nlo = m + P.lw; if (nlo < P.b.left) nlo = P.b.left;
+            int nhi = m + P.up + 1; if (nhi > P.b.right) nhi = P.b.right;
+            P.v2_rowoff[m - P.a.left] = o;
+            if (nhi > nlo) o += nhi - nlo;
+        }
+        P.v2_rowoff[P.a.right - P.a.left] = o;
+    }
 }
 
-extern "C" __global__ void __launch_bounds__(128)
+extern "C" __global__ void __launch_bounds__(192)
 g2g_v2_prologue_kernel(const DevProb *probs, const int *idx)
 {
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];
@@ -643,15 +703,32 @@ g2g_v2_prologue_kernel(const DevProb *probs, const int *idx)
     if (P.kind == 1) v2_prologue<1>(P, lds); else if (P.kind == 2) v2_prologue<2>(P, lds);
 }
 
+// PwdM::sim2 for every in-band cell of the gap-profile DPs (maln.h:160-172, maln2.cc:534-623,1230-1296):
+// independent of the recurrence, so it is computed ahead of it, fully parallel, row-major per DP
+extern "C" __global__ void __launch_bounds__(256)
+g2g_v2_sim_kernel(const DevProb *probs, const int *idx)
+{
+    const DevProb &P = probs[idx[blockIdx.y]];
+    const int m = P.a.left + blockIdx.x;
+    if (m >= P.a.right) return;
+    int nlo = m + P.lw; if (nlo < P.b.left) nlo = P.b.left;
+    int nhi = m + P.up + 1; if (nhi > P.b.right) nhi = P.b.right;
+    double *out = P.v2_sim + P.v2_rowoff[m - P.a.left] - nlo;
+    for (int n = nlo + threadIdx.x; n < nhi; n += blockDim.x) out[n] = sim2(P, m, n);
+}
+
 struct V2Tile { int prob, ti, tj, nsteps; };
 
-extern "C" __global__ void __launch_bounds__(G2G_V2_THREADS)
-g2g_forward_kernel_v2(const DevProb *probs, const V2Tile *tiles)
-{
-    extern __shared__ __attribute__((aligned(16))) char g2g_lds[];
-    lchar *lds = (lchar *) g2g_lds;
-    const V2Tile T = tiles[blockIdx.x];
-    const DevProb &P = probs[T.prob];
-    if (P.kind == 1) { if (P.noll == 3) v2_tile<1, true>(P, lds, T.ti, T.tj, T.nsteps); else v2_tile<1, false>(P, lds, T.ti, T.tj, T.nsteps); }
-    else if (P.kind == 2) { if (P.noll == 3) v2_tile<2, true>(P, lds, T.ti, T.tj, T.nsteps); else v2_tile<2, false>(P, lds, T.ti, T.tj, T.nsteps); }
+// one kernel per (record type, Noll): the register budget of a combined kernel is its worst variant's
+#define V2_KERNEL(NAME, KIND, N3)                                                                   \
+extern "C" __global__ void __launch_bounds__(G2G_V2_THREADS, G2G_V2_MINWAVES)                         \
+NAME(const DevProb *probs, const V2Tile *tiles)                                                     \
+{                                                                                                   \
+    extern __shared__ __attribute__((aligned(16))) char g2g_lds[];                                  \
+    const V2Tile T = tiles[blockIdx.x];                                                             \
+    v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, T.tj, T.nsteps);                      \
 }
+V2_KERNEL(g2g_v2_hf2, 1, false)
+V2_KERNEL(g2g_v2_hf3, 1, true)
+V2_KERNEL(g2g_v2_pf2, 2, false)
+V2_KERNEL(g2g_v2_pf3, 2, true)

@@ -119,14 +119,11 @@ class Batch:
 def stdskl(trace: np.ndarray) -> np.ndarray:
     """stdskl() of the C ABI (host code in libg2g.so), reference src/gaps.cc:139."""
     L = lib()
-    n = len(trace)
-    buf = (_abi.Skl * max(n, 1))()
-    for i in range(n):
-        buf[i].m = int(trace[i, 0]); buf[i].n = int(trace[i, 1])
+    t = np.ascontiguousarray(trace, np.int32)
+    n = len(t)
     nout = C.c_int(0)
-    p = L.g2g_stdskl(buf, n, C.byref(nout))
-    out = np.zeros((nout.value, 2), np.int32)
-    for i in range(nout.value):
-        out[i, 0] = p[i].m; out[i, 1] = p[i].n
+    p = L.g2g_stdskl(C.cast(t.ctypes.data, C.POINTER(_abi.Skl)), n, C.byref(nout))
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), shape=(nout.value * 2,)).reshape(-1, 2).copy() \
+        if nout.value else np.zeros((0, 2), np.int32)
     L.g2g_free(p)
     return out
