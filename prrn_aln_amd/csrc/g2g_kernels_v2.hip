@@ -47,26 +47,71 @@ __device__ __forceinline__ void team_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-// GapLenSD, gfreq.h:67, on a packed list
+// ---- register-cached list heads ---------------------------------------------------------------------
+// Lists are short (1-4 entries is the common case), and a dependent LDS read costs more than a dozen ALU
+// ops, so the first four entries of every list a merge touches are read up front (independent reads, one
+// wait) and indexed with selects; longer lists fall through to LDS for index >= 4.
+struct DHead { unsigned e0, e1, e2, e3; const lu32 *p; };          // dynamic {glen,nins} list
+__device__ __forceinline__ DHead dh_load(const lu32 *p)
+{
+    DHead h; h.e0 = p[0]; h.e1 = p[1]; h.e2 = p[2]; h.e3 = p[3]; h.p = p; return h;
+}
+// nins of the entry that governs static gap length g: last k with glen[k] <= g (GapLenSD, gfreq.h:67).
+// Entries behind the terminator are garbage: the AND chain stops at the first failed comparison.
+__device__ __forceinline__ int dh_nins(int g, const DHead &h)
+{
+    const bool c1 = g >= (int) (h.e1 >> 16);
+    const bool c2 = c1 && g >= (int) (h.e2 >> 16);
+    const bool c3 = c2 && g >= (int) (h.e3 >> 16);
+    unsigned e = c2 ? h.e2 : (c1 ? h.e1 : h.e0);
+    if (c3) {                                                       // rare: more than three entries below g
+        int k = 3;
+        while (g >= (int) (h.p[k + 1] >> 16) && k < DL_GUARD) ++k;
+        e = h.p[k];
+    }
+    return (int) (e & 0xFFFFu);
+}
+template <class CL> struct SHead { int g0, g1, g2, g3; CL l; };    // static GFREQ list (glen part)
+template <class CL>
+__device__ __forceinline__ SHead<CL> sh_load(const CL l)
+{
+    SHead<CL> h; h.g0 = l.glen[0]; h.g1 = l.glen[1]; h.g2 = l.glen[2]; h.g3 = l.glen[3]; h.l = l; return h;
+}
+template <class CL>
+__device__ __forceinline__ int sh_glen(const SHead<CL> &h, int i)
+{
+    return i == 0 ? h.g0 : i == 1 ? h.g1 : i == 2 ? h.g2 : i == 3 ? h.g3 : h.l.glen[i];
+}
+
+// GapLenSD, gfreq.h:67, on a packed list (plain form, used by the boundary chains' helpers)
 __device__ __forceinline__ int p_gaplen(int g, const lu32 *dl)
 {
     int k = 0;
     while (g >= (int) (dl[k + 1] >> 16) && k < DL_GUARD) ++k;
     return g + (int) (dl[k] & 0xFFFFu);
 }
-// newgap(cf, dlc, df, dld), gfreq.cc:507-521
+// newgap(cf, dlc, df, dld), gfreq.cc:507-521.  The reference re-evaluates GapLenSD(cf) of the current cf
+// at the start of every df step; the value cannot change, so it is carried in `gi`.
 template <class CL, class DL>
 __device__ double p_newgap4(const CL cf, const lu32 *dlc, const DL df, const lu32 *dld)
 {
+    const DHead hc = dh_load(dlc), hd = dh_load(dld);
+    const SHead<CL> sc = sh_load(cf);
+    const SHead<DL> sd = sh_load(df);
     double g = 0;
     int ci = 0;
-    for (int di = 0; df.glen[di] >= 0; ++di) {
-        const int j = p_gaplen(df.glen[di], dld);
-        for ( ; cf.glen[ci] >= 0; ++ci) {
-            const int i = p_gaplen(cf.glen[ci], dlc);
-            if (i >= j) break;
+    int cg = sc.g0;
+    int gi = cg >= 0 ? cg + dh_nins(cg, hc) : 0;
+    for (int di = 0; ; ++di) {
+        const int dg = sh_glen(sd, di);
+        if (dg < 0) break;
+        const int j = dg + dh_nins(dg, hd);
+        while (cg >= 0 && gi < j) {
+            ++ci;
+            cg = sh_glen(sc, ci);
+            gi = cg >= 0 ? cg + dh_nins(cg, hc) : 0;
         }
-        if (cf.glen[ci] < 0) break;
+        if (cg < 0) break;
         g += cf.freq[ci] * df.freq[di];
     }
     return g;
@@ -75,49 +120,59 @@ __device__ double p_newgap4(const CL cf, const lu32 *dlc, const DL df, const lu3
 template <class CL>
 __device__ double p_newgap1(const DevProb &P, const CL acf, const lu32 *dla, int glb)
 {
-    if (acf.glen[0] < 0) return 0;
-    if (acf.glen[1] >= 0) {
-        for (int ci = 0; acf.glen[ci] >= 0; ++ci)          // newgap(cf, dlc, j), gfreq.cc:523-532
-            if (p_gaplen(acf.glen[ci], dla) >= glb) return P.weighted_gop * acf.freq[ci];
+    const SHead<CL> sc = sh_load(acf);
+    if (sc.g0 < 0) return 0;
+    const DHead h = dh_load(dla);
+    if (sc.g1 >= 0) {
+        for (int ci = 0; ; ++ci) {                          // newgap(cf, dlc, j), gfreq.cc:523-532
+            const int cg = sh_glen(sc, ci);
+            if (cg < 0) break;
+            if (cg + dh_nins(cg, h) >= glb) return P.weighted_gop * acf.freq[ci];
+        }
         return P.weighted_gop * 0.;
     }
-    return ((int) (dla[0] & 0xFFFFu) + acf.glen[0] >= glb) ? (P.weighted_gop * acf.freq[0]) : 0;
+    return ((int) (h.e0 & 0xFFFFu) + sc.g0 >= glb) ? (P.weighted_gop * acf.freq[0]) : 0;
 }
 template <class CL>
 __device__ double p_newgap2(const DevProb &P, const CL adf, int glb, const lu32 *dla)
 {
-    if (adf.glen[0] < 0) return 0;
-    if (adf.glen[1] >= 0) {                                 // newgap(df, i, dld), gfreq.cc:534-545
+    const SHead<CL> sd = sh_load(adf);
+    if (sd.g0 < 0) return 0;
+    const DHead h = dh_load(dla);
+    if (sd.g1 >= 0) {                                       // newgap(df, i, dld), gfreq.cc:534-545
         double g = 0;
-        int k = 0;
-        for (int di = 0; adf.glen[di] >= 0; ++di) {
-            while (adf.glen[di] >= (int) (dla[k + 1] >> 16) && k < DL_GUARD) ++k;
-            if (glb < adf.glen[di] + (int) (dla[k] & 0xFFFFu)) break;
+        for (int di = 0; ; ++di) {
+            const int dg = sh_glen(sd, di);
+            if (dg < 0) break;
+            if (glb < dg + dh_nins(dg, h)) break;
             g += adf.freq[di];
         }
         return P.weighted_gop * g;
     }
-    return (glb >= (int) (dla[0] & 0xFFFFu) + adf.glen[0]) ? (P.weighted_gop * adf.freq[0]) : 0;
+    return (glb >= (int) (h.e0 & 0xFFFFu) + sd.g0) ? (P.weighted_gop * adf.freq[0]) : 0;
 }
 // newdelta(dlt, df, dln, 1), gfreq.cc:570-587; up to two destinations (the record itself and, when that
-// record wins the cell, the new H).  dst may alias src (stores trail the loads they could affect).
+// record wins the cell, the new H).  The source list is read through its cached head, i.e. before any
+// store: when dst aliases src (F updated in place) this is the out-of-place result, which equals the
+// reference's in-place one (an entry is overwritten only after the scan has moved past it, and the first
+// entry's glen is always 0).
 template <class CL>
 __device__ void p_newdelta(lu32 *dst, lu32 *dst2, const CL df, const lu32 *src)
 {
-    int kd = 0, ks = 0;
+    const DHead h = dh_load(src);
+    const SHead<CL> sd = sh_load(df);
+    int kd = 0;
     unsigned tg = 0, tn = 0;
-    for (int di = 0; df.glen[di] >= 0; ++di) {
-        const int g = df.glen[di];
-        if (g >= (int) (src[ks] >> 16)) {
-            while (g >= (int) (src[ks + 1] >> 16) && ks < DL_GUARD) ++ks;
-            const unsigned sn = src[ks] & 0xFFFFu;
-            if (sn > tn) {
-                const unsigned e = (tg << 16) | tn;
-                dst[kd] = e; if (dst2) dst2[kd] = e;
-                ++kd;
-                tn = sn;
-                tg = (unsigned) (g + 1);
-            }
+    for (int di = 0; ; ++di) {
+        const int g = sh_glen(sd, di);
+        if (g < 0) break;
+        const unsigned sn = (unsigned) dh_nins(g, h);
+        if (sn > tn) {
+            const unsigned e = (tg << 16) | tn;
+            dst[kd] = e; if (dst2) dst2[kd] = e;
+            ++kd;
+            tn = sn;
+            tg = (unsigned) (g + 1);
         }
     }
     const unsigned e = (tg << 16) | tn;
