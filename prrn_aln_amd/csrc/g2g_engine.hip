@@ -107,8 +107,10 @@ struct g2g_batch {
     size_t lds2;                    // dynamic LDS bytes of the v2 launch
     size_t lds2p;                   // ... of the v2 prologue launch
     int v2_maxrows;                 // longest a-range among the v2 problems
-    V2Tile *d_tiles;                // v2 tiles ordered by wavefront index i + j
-    std::vector<int> wave_off;      // tiles of (wavefront k, variant v): [wave_off[4k+v], wave_off[4k+v+1])
+    V2Tile *d_tiles;                // v2 tiles: per variant (hf2, hf3, pf2, pf3) a queue ordered by wavefront i + j
+    int var_off[5];                 // variant v owns tiles [var_off[v], var_off[v+1])
+    int *d_flags;                   // [0..3] queue heads, [4..] tile-completion flags (generation numbers)
+    int nflags, gen;
     long long ntiles;
     float fwd_ms, tb_ms;
 };
@@ -278,7 +280,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         // v2 kernel (gap-profile engines): packed 16-bit gap lengths and an LDS budget decide eligibility
         d.v2_ok = 0;
         if ((d.kind == 1 || d.kind == 2) && !getenv("G2G_FORCE_V1") && p->a.len + p->b.len < 65000 &&
-            v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist) <= V2_LDS_MAX) {
+            v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist) + 4 * G2G_V2_THREADS <= V2_LDS_MAX) {
             const size_t recsz = (16 + 4 * (size_t) (d.capa + (d.kind == 2 ? d.capb : 0)) + 15) & ~(size_t) 15;
             d.v2_ok = 1;
             d.v2_rowstride = p->b.len + 3;
@@ -328,11 +330,13 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         b->d_idx1 = (int *) (b->d_arena + idx_off);
         b->d_idx2 = b->d_idx1 + (n > 0 ? n : 1);
     }
-    // v2 tiles: (strip i of R rows) x (block j of G2G_V2_TILE_COLS columns), grouped by wavefront i + j
-    b->d_tiles = 0; b->ntiles = 0; b->lds2p = 0; b->v2_maxrows = 1;
+    // v2 tiles: (strip i of R rows) x (block j of G2G_V2_TILE_COLS columns); per kernel variant one queue
+    // ordered by wavefront i + j; one completion flag per tile slot (empty slots count as done for ever)
+    b->d_tiles = 0; b->ntiles = 0; b->lds2p = 0; b->v2_maxrows = 1; b->d_flags = 0; b->nflags = 0; b->gen = 0;
     {
         const int R = G2G_V2_THREADS / 8, C = G2G_V2_TILE_COLS;
-        std::vector<std::vector<V2Tile> > byk;           // index 4 * wavefront + variant (hf2, hf3, pf2, pf3)
+        std::vector<std::vector<std::vector<V2Tile> > > q(4);    // [variant][wavefront] -> tiles
+        std::vector<int> flags(12, 0);                    // 0-3 queue heads, 4-11 incident report
         for (int i = 0; i < n; ++i) {
             const DevProb &d = b->dp[i];
             if (d.kind < 0 || !d.v2_ok) continue;
@@ -341,11 +345,14 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             b->v2_maxrows = std::max(b->v2_maxrows, d.a.right - d.a.left);
             const int al = d.a.left, ar = d.a.right, bl_ = d.b.left, br = d.b.right;
             const int nstrip = (ar - al + R - 1) / R, nblk = (br - bl_ + C - 1) / C;
+            const int var = (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
+            const int fbase = (int) flags.size();
+            flags.resize(flags.size() + (size_t) nstrip * nblk, 0x7fffffff);
             for (int ti = 0; ti < nstrip; ++ti) {
                 const int m0 = al + ti * R;
                 for (int tj = 0; tj < nblk; ++tj) {
                     const int c0 = bl_ + tj * C, c1 = std::min(c0 + C, br);
-                    int cbase = std::max(std::max(m0 + d.lw, bl_), c0);
+                    const int cbase = std::max(std::max(m0 + d.lw, bl_), c0);
                     int nsteps = 0;
                     for (int t = 0; t < R && m0 + t < ar; ++t) {
                         const int m = m0 + t;
@@ -353,23 +360,33 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
                         if (hi > lo) nsteps = std::max(nsteps, hi - cbase + t);
                     }
                     if (!nsteps) continue;
-                    const int k = 4 * (ti + tj) + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
-                    if ((int) byk.size() <= k) byk.resize((k / 4 + 1) * 4);
-                    V2Tile T = {i, ti, tj, nsteps};
-                    byk[k].push_back(T);
+                    V2Tile T;
+                    T.prob = i; T.ti = ti; T.tj = tj; T.nsteps = nsteps;
+                    T.self = fbase + ti * nblk + tj;
+                    T.dep_up = ti > 0 ? T.self - nblk : -1;
+                    T.dep_left = tj > 0 ? T.self - 1 : -1;
+                    T.dep_diag = (ti > 0 && tj > 0) ? T.self - nblk - 1 : -1;
+                    T.dep_war = (ti > 1 && tj + 1 < nblk) ? T.self - 2 * nblk + 1 : -1;
+                    flags[T.self] = 0;
+                    const int k = ti + tj;
+                    if ((int) q[var].size() <= k) q[var].resize(k + 1);
+                    q[var][k].push_back(T);
                 }
             }
         }
         std::vector<V2Tile> all;
-        b->wave_off.assign(1, 0);
-        for (size_t k = 0; k < byk.size(); ++k) {
-            all.insert(all.end(), byk[k].begin(), byk[k].end());
-            b->wave_off.push_back((int) all.size());
+        for (int v = 0; v < 4; ++v) {
+            b->var_off[v] = (int) all.size();
+            for (size_t k = 0; k < q[v].size(); ++k) all.insert(all.end(), q[v][k].begin(), q[v][k].end());
         }
+        b->var_off[4] = (int) all.size();
         b->ntiles = (long long) all.size();
+        b->nflags = (int) flags.size();
         if (!all.empty()) {
             hipError_t e2 = hipMalloc((void **) &b->d_tiles, sizeof(V2Tile) * all.size());
             if (e2 == hipSuccess) e2 = hipMemcpy(b->d_tiles, all.data(), sizeof(V2Tile) * all.size(), hipMemcpyHostToDevice);
+            if (e2 == hipSuccess) e2 = hipMalloc((void **) &b->d_flags, sizeof(int) * flags.size());
+            if (e2 == hipSuccess) e2 = hipMemcpy(b->d_flags, flags.data(), sizeof(int) * flags.size(), hipMemcpyHostToDevice);
             if (e2 != hipSuccess) { g2g_set_error("tiles: %s", hipGetErrorString(e2)); hipFree(b->d_arena); delete b; return G2G_ERR_NOMEM; }
         }
     }
@@ -391,11 +408,11 @@ extern "C" int g2g_batch_run(g2g_batch *b)
     if (b->n == 0) return G2G_OK;
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     if (b->n2) {
-        if (b->lds2 > 64 * 1024) {
-            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_hf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2));
-            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_hf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2));
-            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_pf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2));
-            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_pf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2));
+        if (b->lds2 + 4 * G2G_V2_THREADS > 64 * 1024) {
+            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_hf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * G2G_V2_THREADS));
+            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_hf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * G2G_V2_THREADS));
+            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_pf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * G2G_V2_THREADS));
+            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_pf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * G2G_V2_THREADS));
         }
         hipLaunchKernelGGL(g2g_v2_prologue_kernel, dim3(b->n2), dim3(192), b->lds2p, ctx->stream,
                            (const DevProb *) b->d_probs, (const int *) b->d_idx2);
@@ -403,23 +420,27 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         hipLaunchKernelGGL(g2g_v2_sim_kernel, dim3(b->v2_maxrows, b->n2), dim3(256), 0, ctx->stream,
                            (const DevProb *) b->d_probs, (const int *) b->d_idx2);
         HIPCHK(hipGetLastError());
+        if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[g2g] prologue+sim done: %s\n", hipGetErrorString(e3)); fflush(stderr); }
         // one launch per tile wavefront: stream order is the dependency between wavefronts
-        typedef void (*v2k_t)(const DevProb *, const V2Tile *);
+        typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int);
         static const v2k_t v2k[4] = {g2g_v2_hf2, g2g_v2_hf3, g2g_v2_pf2, g2g_v2_pf3};
-        // the wavefronts of one variant are ordered by its stream; variants overlap each other
+        // one persistent launch per variant, each on its own stream (they are independent of each other)
+        ++b->gen;
+        HIPCHK(hipMemsetAsync(b->d_flags, 0, 12 * sizeof(int), ctx->stream));           // queue heads, incident report
         HIPCHK(hipEventRecord(ctx->vev[4], ctx->stream));
-        bool used[4] = {false, false, false, false};
-        for (int v = 0; v < 4; ++v) HIPCHK(hipStreamWaitEvent(ctx->vstream[v], ctx->vev[4], 0));
-        for (size_t k = 0; k + 1 < b->wave_off.size(); ++k) {
-            const int cnt = b->wave_off[k + 1] - b->wave_off[k];
-            if (!cnt) continue;
-            used[k & 3] = true;
-            hipLaunchKernelGGL(v2k[k & 3], dim3(cnt), dim3(G2G_V2_THREADS), b->lds2, ctx->vstream[k & 3],
-                               (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->wave_off[k]));
-        }
-        HIPCHK(hipGetLastError());
+        int ncu = 256;
+        { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) ncu = pr.multiProcessorCount; }
         for (int v = 0; v < 4; ++v) {
-            if (!used[v]) continue;
+            const int cnt = b->var_off[v + 1] - b->var_off[v];
+            if (!cnt) continue;
+            HIPCHK(hipStreamWaitEvent(ctx->vstream[v], ctx->vev[4], 0));
+            const int grid = std::min(cnt, ncu * 8);
+            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] variant %d: %d tiles, grid %d, lds %zu, gen %d\n", v, cnt, grid, b->lds2, b->gen); fflush(stderr); }
+            hipLaunchKernelGGL(v2k[v], dim3(grid), dim3(G2G_V2_THREADS), b->lds2 + 4 * G2G_V2_THREADS, ctx->vstream[v],
+                               (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v]), cnt,
+                               b->d_flags + v, b->d_flags, b->gen, (int) b->lds2);
+            HIPCHK(hipGetLastError());
+            if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->vstream[v]); fprintf(stderr, "[g2g] variant %d done: %s\n", v, hipGetErrorString(e3)); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[v], ctx->vstream[v]));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[v], 0));
         }
@@ -434,6 +455,16 @@ extern "C" int g2g_batch_run(g2g_batch *b)
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (b->d_flags) {
+        int rep[12];
+        HIPCHK(hipMemcpy(rep, b->d_flags, sizeof rep, hipMemcpyDeviceToHost));
+        if (rep[4]) {
+            char msg[128];
+            snprintf(msg, sizeof msg, "%d tile waits timed out (first: queue slot %d on flag %d)", rep[4], rep[5], rep[6]);
+            g2g_set_error("v2 scheduler: %s", msg);
+            return G2G_ERR_DEVICE;
+        }
+    }
     HIPCHK(hipEventElapsedTime(&b->fwd_ms, ctx->ev[0], ctx->ev[1]));
     HIPCHK(hipEventElapsedTime(&b->tb_ms, ctx->ev[1], ctx->ev[2]));
     return G2G_OK;
@@ -485,6 +516,7 @@ extern "C" void g2g_batch_free(g2g_batch *b)
     hipSetDevice(b->ctx->device);
     if (b->d_arena) hipFree(b->d_arena);
     if (b->d_tiles) hipFree(b->d_tiles);
+    if (b->d_flags) hipFree(b->d_flags);
     delete b;
 }
 

@@ -21,7 +21,10 @@
 
 #define TEAM 8
 #define DL_END 0xFFFFu                       // packed terminator glen (INT_MAX in the reference)
-#define DL_GUARD 4096                        // no list is this long: a corrupted one must not hang the wave
+#ifndef G2G_SPIN_MAX
+#define G2G_SPIN_MAX (1 << 22)
+#endif
+#define DL_GUARD 128                         // no list is this long: a corrupted one must not hang the wave
 
 // Everything below lives in LDS and says so in its pointer types (address space 3): generic pointers
 // would compile to flat_load/flat_store instead of ds_read/ds_write.
@@ -502,7 +505,9 @@ __device__ __forceinline__ void list_g2l(li32 *gl, lf64 *fr, const DevSide &s, i
 // i + j (over every DP of the batch) run in one launch; a big DP is spread over many workgroups instead
 // of bounding the sweep time.  What crosses tile borders lives in HBM:
 //   rowH/rowG/rowG2[3][col]  the last row's corners of a strip (3 buffers: strip i writes i % 3, reads
-//                            (i + 2) % 3; the top boundary chain is "strip -1" and writes buffer 2)
+//                            (i + 2) % 3; the top boundary chain is "strip -1" and writes buffer 2).
+//                            Tile (i, j) overwrites what tile (i-2, j+1) still reads as its first diagonal
+//                            corner, hence the extra write-after-read dependency dep_war.
 //   cbH/cbF/cbF2[row]        each row's H corner and F records at the block's right edge
 //   colH[row]                the left boundary chain
 template <int KIND, bool NOLL3>
@@ -772,16 +777,58 @@ g2g_v2_sim_kernel(const DevProb *probs, const int *idx)
     for (int n = nlo + threadIdx.x; n < nhi; n += blockDim.x) out[n] = sim2(P, m, n);
 }
 
-struct V2Tile { int prob, ti, tj, nsteps; };
+// self / dep_*: indices into the batch's tile-completion flags (-1: no such neighbour)
+struct V2Tile { int prob, ti, tj, nsteps, self, dep_up, dep_left, dep_diag, dep_war; };
 
-// one kernel per (record type, Noll): the register budget of a combined kernel is its worst variant's
+// One PERSISTENT kernel per (record type, Noll) -- the register budget of a combined kernel would be its
+// worst variant's.  Workgroups pull tiles from a queue ordered by tile wavefront (i + j) and wait on
+// completion flags of the three tiles they depend on, so a tile starts as soon as ITS neighbours are done
+// instead of when a whole wavefront launch has drained.  Dependencies always sit earlier in the queue,
+// i.e. are finished or being worked on by a resident workgroup: waiting cannot deadlock for any grid size.
+// Cross-workgroup visibility follows the agent-scope release/acquire recipe of the CDNA guide (G16).
+// Every spin is bounded (a kernel that never ends can take the whole node down): on a time-out the wait
+// gives up, the incident is counted in dbg[0] and the host reports the batch as failed.
+__device__ __forceinline__ void v2_wait_flag(const int *flag, int gen, int *dbg, int tile)
+{
+    for (int it = 0; it < G2G_SPIN_MAX; ++it) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gen) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    atomicAdd(dbg, 1);
+    dbg[1] = tile; dbg[2] = (int) (flag - dbg);
+}
+// NOTE on control flow: nothing in this loop is done by "thread 0 only".  With one-lane branches next to
+// the barriers the structurizer rotates the loop so that lane 0 leaves it to run its blocks while the
+// other lanes of its wave go round again -- they then re-read a stale tile index for ever.  So the queue
+// pop, the polling, the fences and the flag store are all executed uniformly (redundantly) by every lane:
+// each thread adds (tid == 0) to the queue head, parks its result in LDS, and slot 0 is the tile.
 #define V2_KERNEL(NAME, KIND, N3)                                                                   \
 extern "C" __global__ void __launch_bounds__(G2G_V2_THREADS, G2G_V2_MINWAVES)                         \
-NAME(const DevProb *probs, const V2Tile *tiles)                                                     \
+NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, int lds_tile_off) \
 {                                                                                                   \
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];                                  \
-    const V2Tile T = tiles[blockIdx.x];                                                             \
-    v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, T.tj, T.nsteps);                      \
+    li32 *s_vals = (li32 *) ((lchar *) g2g_lds + lds_tile_off);   /* tail of the dynamic LDS */      \
+    for (;;) {                                                                                      \
+        s_vals[threadIdx.x] = atomicAdd(qhead, threadIdx.x == 0 ? 1 : 0);                           \
+        __syncthreads();                                                                            \
+        const int t = __builtin_amdgcn_readfirstlane(s_vals[0]);                                    \
+        __syncthreads();                                                                            \
+        if (t >= ntiles) break;                                                                     \
+        const V2Tile T = tiles[t];                                                                  \
+        if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 4, t);                         \
+        if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 4, t);                     \
+        if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 4, t);                     \
+        if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 4, t);                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                          \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
+        __syncthreads();                                                                            \
+        v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, T.tj, T.nsteps);                  \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
+        __syncthreads();                                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                                          \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
+        __hip_atomic_store(done + T.self, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         \
+    }                                                                                               \
 }
 V2_KERNEL(g2g_v2_hf2, 1, false)
 V2_KERNEL(g2g_v2_hf3, 1, true)
