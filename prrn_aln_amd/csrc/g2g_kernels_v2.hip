@@ -20,6 +20,12 @@
 #include <hip/hip_runtime.h>
 
 #define TEAM 8
+#ifdef G2G_V2_STAMP
+__device__ unsigned long long g2g_stamp_acc[16];
+#define STAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += t_ - stamp_t; stamp_t = t_; }
+#else
+#define STAMP(k)
+#endif
 #define DL_END 0xFFFFu                       // packed terminator glen (INT_MAX in the reference)
 #ifndef G2G_SPIN_MAX
 #define G2G_SPIN_MAX (1 << 22)
@@ -336,7 +342,11 @@ struct CellDst { LRec h, g, g2, f, f2; };                 // records it writes
 template <int KIND, bool NOLL3>
 __device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList> &L, int m, int n, int lane,
                         const CellSrc &S, const CellDst &D, bool do_vert, bool do_hori, uint8_t *tr,
-                        double dab, double pua, double pub)
+                        double dab, double pua, double pub
+#ifdef G2G_V2_STAMP
+                        , unsigned long long *stamp_acc, unsigned long long &stamp_t
+#endif
+                        )
 {
     const DevSide &a = P.a, &b = P.b;
     const int capa = G.capa;
@@ -362,6 +372,7 @@ __device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList
         if (on && jk != 2) r = p_newgap2(P, jk == 0 ? L.at : L.ar, lglb(rc), ldla(rc));
     }
     const double r8 = r;                                 // lane 6's horizontal2 cost (Noll 3)
+    STAMP(2)
     const double c_d0 = __shfl(r, 0, TEAM), c_d1 = __shfl(r, 1, TEAM);
     const double c_gnpv = __shfl(r, 2, TEAM), c_gopv = __shfl(r, 3, TEAM);
     const double c_gnph = __shfl(r, 4, TEAM), c_goph = __shfl(r, 5, TEAM);
@@ -426,6 +437,7 @@ __device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList
     }
     if (!(mxval > hval)) win = 0;                      // diagonal wins ties (fwd2c.h:453)
     if (!do_vert && win == 1) win = 0;                 // (the black G can never win)
+    STAMP(3)
     // ---- phase B: list updates, one per lane; the winner's lists are also written to the new H ----
     team_sync();
     const LRec gs = g_from_h ? S.hu : S.gu, gs2 = g2_from_h ? S.hu : S.g2u;
@@ -470,6 +482,7 @@ __device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList
         }
         if (go) p_incdelta(d1, d2, sp);
     }
+    STAMP(4)
     // scalars of the produced records (lane 0 writes; glb per fwd2c.cc:169,173,177)
     const int glb_g = (KIND == 1 && do_vert) ? lglb(gs) + 1 : 0;
     const int glb_g2 = (KIND == 1 && NOLL3 && do_vert) ? lglb(gs2) + 1 : 0;
@@ -588,8 +601,13 @@ __device__ void v2_tile(const DevProb &P, lchar *lds, int ti, int tj, int nsteps
     int rslot = (RC - team % RC) % RC;                     // ring slot of column cbase + s - team
     int wslot = 1 % RC;                                    // ring slot of column cbase + s + 1
     const bool stage_regs = G.ndw <= 4 * TEAM;            // record fits 4 dwords per lane (128 B)
+#ifdef G2G_V2_STAMP
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
+        STAMP(7)
         const int n = cbase + s - team;
         const bool active = row_ok && n >= lo && n < hi;
         double sim_nx = 0, bc_nx = 0;
@@ -679,9 +697,15 @@ __device__ void v2_tile(const DevProb &P, lchar *lds, int ti, int tj, int nsteps
             const int d = m + n;
             diag_rows(d, a.left, a.right, b.left, b.right, P.lw, P.up, &mlo, &mhi);
             uint8_t *tr = P.trace + (size_t) (d - P.d0) * P.tstride + (m - mlo);
+            STAMP(1)
             const double pua = a.nils ? unpa(P, m, n) : pua_row;
             const double pub = bc_cur * a_efq * -P.u;                       // unp1(bsi, asi), maln.h:185-187
-            v2_cell<KIND, NOLL3>(P, G, L, m, n, lane, S, D, do_vert, do_hori, tr, sim_cur, pua, pub);
+            v2_cell<KIND, NOLL3>(P, G, L, m, n, lane, S, D, do_vert, do_hori, tr, sim_cur, pua, pub
+#ifdef G2G_V2_STAMP
+                                 , stamp_acc, stamp_t
+#endif
+                                 );
+            STAMP(5)
             if (team == 0 && (pf_h || pf_gu)) {                             // park the prefetched neighbours
                 const LRec hslot = (n & 1) ? G.extra(EX_H1) : G.extra(EX_H0);   // corner n+2 shares corner n's slot
 #pragma unroll
@@ -727,8 +751,12 @@ __device__ void v2_tile(const DevProb &P, lchar *lds, int ti, int tj, int nsteps
         }
         if (++rslot == RC) rslot = 0;
         if (++wslot == RC) wslot = 0;
+        STAMP(6)
         __syncthreads();
     }
+#ifdef G2G_V2_STAMP
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g2g_stamp_acc[k + (threadIdx.x == 0 ? 0 : 8)], stamp_acc[k]);
+#endif
 }
 
 // boundary chains of every DP: one small workgroup each (wave 0: top row, wave 1: left column)
