@@ -522,6 +522,7 @@ extern "C" void g2g_batch_free(g2g_batch *b)
 
 #ifdef G2G_V2_STAMP
 extern "C" void g2g_stamps(unsigned long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g2g_stamp_acc), sizeof(unsigned long long) * 16); }
+extern "C" void g2g_waits(unsigned long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g2g_wait_acc), sizeof(unsigned long long) * 4); }
 #endif
 extern "C" int g2g_forward_batch(g2g_ctx *ctx, int n, const g2g_problem *const *prob, g2g_result *res)
 {

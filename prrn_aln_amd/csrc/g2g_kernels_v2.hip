@@ -825,6 +825,16 @@ __device__ __forceinline__ void v2_wait_flag(const int *flag, int gen, int *dbg,
     atomicAdd(dbg, 1);
     dbg[1] = tile; dbg[2] = (int) (flag - dbg);
 }
+#ifdef G2G_V2_STAMP
+__device__ unsigned long long g2g_wait_acc[4];
+#define V2_WAIT_T0 const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#define V2_WAIT_T1 const unsigned long long w1_ = __builtin_amdgcn_s_memtime();
+#define V2_WAIT_T2 if (threadIdx.x == 0) { const unsigned long long w2_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g2g_wait_acc[0], w1_ - w0_); atomicAdd(&g2g_wait_acc[1], w2_ - w1_); }
+#else
+#define V2_WAIT_T0
+#define V2_WAIT_T1
+#define V2_WAIT_T2
+#endif
 // NOTE on control flow: nothing in this loop is done by "thread 0 only".  With one-lane branches next to
 // the barriers the structurizer rotates the loop so that lane 0 leaves it to run its blocks while the
 // other lanes of its wave go round again -- they then re-read a stale tile index for ever.  So the queue
@@ -843,6 +853,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         __syncthreads();                                                                            \
         if (t >= ntiles) break;                                                                     \
         const V2Tile T = tiles[t];                                                                  \
+        V2_WAIT_T0                                                                                  \
         if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 4, t);                         \
         if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 4, t);                     \
         if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 4, t);                     \
@@ -850,7 +861,9 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                          \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
+        V2_WAIT_T1                                                                                  \
         v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, T.tj, T.nsteps);                  \
+        V2_WAIT_T2                                                                                  \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                                          \
