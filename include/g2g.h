@@ -121,6 +121,9 @@ typedef struct g2g_result {
     int32_t   status;               /* G2G_OK or error for this item                              */
     g2g_skl  *trace;                /* Vmf::traceback(-1) order: end corner first, origin last
                                        (vmf.cc:105-120); free with g2g_free()                     */
+    int64_t   rr[2];                /* what forwardB(pp) reports without a Vmf (HomScoreC, fwd2c.h:664-668,
+                                       468-469,477-480): diagonal n-m on which the path leaves the first row,
+                                       and b.left - a.left + b.right - a.right                      */
 } g2g_result;
 
 typedef struct g2g_ctx g2g_ctx;
@@ -188,6 +191,8 @@ const g2g_problem *g2g_pwdm_problem(const g2g_pwdm *p);
    traceback, stdskl, end check with the sh = -100 retry.  *skl is malloc'ed: skl[0..*nskl) corners
    ascending (the reference's skl[1..n]); caller g2g_free()s.  Batched form = one randiv sweep. */
 int        g2g_align2(g2g_ctx *ctx, g2g_pwdm *p, double *scr, g2g_skl **skl, int *nskl);
+/* <-> VTYPE HomScore(mSeq* seqs[], PwdM* pwdm, long rr[]) (src/maln2.cc:1837): score only; rr may be NULL. */
+int        g2g_homscore(g2g_ctx *ctx, g2g_pwdm *p, double *scr, int64_t rr[2]);
 int        g2g_align2_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *p, double *scr,
                             g2g_skl **skl, int *nskl, int *status);
 

@@ -42,7 +42,7 @@ class Problem(C.Structure):
 
 class Result(C.Structure):
     _fields_ = [("score", C.c_double), ("cells", C.c_int64), ("ntrace", C.c_int32),
-                ("status", C.c_int32), ("trace", C.POINTER(Skl))]
+                ("status", C.c_int32), ("trace", C.POINTER(Skl)), ("rr", C.c_int64 * 2)]
 
 
 class Params(C.Structure):

@@ -62,5 +62,6 @@ def bind_level1(L):
     L.g2g_pwdm_problem.restype = C.POINTER(_abi.Problem)
     L.g2g_pwdm_problem.argtypes = [C.c_void_p]
     L.g2g_align2.argtypes = [C.c_void_p, C.c_void_p, _abi.c_f64p, C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int)]
+    L.g2g_homscore.argtypes = [C.c_void_p, C.c_void_p, _abi.c_f64p, C.POINTER(C.c_int64)]
     L.g2g_align2_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), _abi.c_f64p,
                                    C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int), C.POINTER(C.c_int)]

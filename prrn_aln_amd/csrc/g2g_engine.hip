@@ -99,6 +99,7 @@ struct g2g_batch {
     std::vector<long long> cells;
     std::vector<size_t> out_off;    // per problem: offset of {score, ntrace, otrace} block
     std::vector<int> tcap;
+    std::vector<long long> rr1;     // b.left - a.left + b.right - a.right per problem
     char *d_arena;
     size_t arena_bytes, in_bytes;
     DevProb *d_probs;
@@ -216,7 +217,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     HIPCHK(hipSetDevice(ctx->device));
     g2g_batch *b = new g2g_batch();
     b->ctx = ctx; b->n = n; b->d_arena = 0; b->d_probs = 0; b->fwd_ms = b->tb_ms = 0;
-    b->dp.resize(n); b->status.assign(n, G2G_OK); b->cells.assign(n, 0); b->out_off.assign(n, 0); b->tcap.assign(n, 0);
+    b->dp.resize(n); b->status.assign(n, G2G_OK); b->cells.assign(n, 0); b->out_off.assign(n, 0); b->tcap.assign(n, 0); b->rr1.assign(n, 0);
     Blob bl;
     size_t probs_off = bl.put(0, 0);
     bl.h.resize(probs_off + sizeof(DevProb) * (size_t) (n > 0 ? n : 1));
@@ -294,6 +295,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             d.v2_rowoff = OFF<long long>(take(sizeof(long long) * ((size_t) (ar - al) + 2)));
             d.v2_sim = OFF<double>(take(sizeof(double) * (size_t) cells + 64));
         }
+        b->rr1[i] = (long long) (bl_ - al) + (br - ar);
         d.tcap = (ar - al) + (br - bl_) + 4;
         b->tcap[i] = d.tcap;
         b->out_off[i] = take(sizeof(double) + sizeof(int) * 2 + sizeof(int2) * (size_t) d.tcap);
@@ -485,8 +487,11 @@ extern "C" int g2g_batch_fetch(g2g_batch *b, g2g_result *res)
         std::vector<char> tmp(bytes);
         HIPCHK(hipMemcpy(tmp.data(), b->d_arena + b->out_off[i], bytes, hipMemcpyDeviceToHost));
         memcpy(&res[i].score, tmp.data(), sizeof(double));
-        int nt;
+        int nt, rr0;
         memcpy(&nt, tmp.data() + sizeof(double), sizeof(int));
+        memcpy(&rr0, tmp.data() + sizeof(double) + sizeof(int), sizeof(int));
+        res[i].rr[0] = rr0;
+        res[i].rr[1] = b->rr1[i];
         if (nt < 2 || nt > b->tcap[i]) { res[i].status = G2G_ERR_DEVICE; continue; }
         res[i].ntrace = nt;
         res[i].trace = (g2g_skl *) malloc(sizeof(g2g_skl) * nt);

@@ -728,6 +728,26 @@ extern "C" int g2g_align2_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *pw, double
     return status ? G2G_OK : worst;
 }
 
+extern "C" int g2g_homscore(g2g_ctx *ctx, g2g_pwdm *p, double *scr, int64_t rr[2])
+{
+    if (!ctx || !p || !scr) return G2G_ERR_ARG;
+    const g2g_group &a = *p->a, &b = *p->b;
+    if (a.left == a.right || b.left == b.right) {            // maln2.cc:1843-1849
+        if (rr) { rr[0] = b.left - a.left; rr[1] = b.right - a.right; }
+        *scr = 0;
+        return G2G_OK;
+    }
+    const g2g_problem *pp = &p->prob;
+    g2g_result r;
+    int rc = g2g_forward_batch(ctx, 1, &pp, &r);
+    if (rc) return rc;
+    if (r.status) return r.status;
+    g2g_free(r.trace);
+    *scr = r.score;
+    if (rr) { rr[0] = r.rr[0]; rr[1] = r.rr[1]; }
+    return G2G_OK;
+}
+
 extern "C" int g2g_align2(g2g_ctx *ctx, g2g_pwdm *p, double *scr, g2g_skl **skl, int *nskl)
 {
     if (!p) return G2G_ERR_ARG;

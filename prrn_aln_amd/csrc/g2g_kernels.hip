@@ -605,6 +605,7 @@ extern "C" __global__ void g2g_traceback_kernel(const DevProb *probs, int nprob)
     if (P.kind < 0) return;
     const DevSide &a = P.a, &b = P.b;
     int cnt = 0;
+    int rr0 = b.left - a.left, rr0_set = 0;            // forwardB without Vmf: ptr = start diagonal
     int2 *out = P.otrace;
     out[cnt++] = make_int2(a.right, b.right);           // fwd2c.h:476
     int m = a.right - 1, n = b.right - 1;
@@ -613,6 +614,7 @@ extern "C" __global__ void g2g_traceback_kernel(const DevProb *probs, int nprob)
         if (m < a.left || n < b.left) break;            // reached an initB boundary corner: ptr = origin
         const uint8_t t = trace_at(P, m, n);
         const int dc = t & T_DIRMASK;
+        if (m == a.left && !rr0_set) { rr0 = n - m; rr0_set = 1; }   // `else if (m == a->left) h->ptr = n - m`
         if ((dc == 2 || dc == 4 || dc == 6) && cnt < P.tcap - 1) out[cnt++] = make_int2(m, n);
         if (dc == 1 || dc == 2) { --m; --n; }
         else if (dc == 3 || dc == 4) {                  // H copied G or G2: walk the vertical run
@@ -633,4 +635,5 @@ extern "C" __global__ void g2g_traceback_kernel(const DevProb *probs, int nprob)
     }
     out[cnt++] = make_int2(a.left, b.left);             // origin record, fwd2c.h:144
     *P.ntrace = cnt;
+    P.ntrace[1] = rr0;
 }

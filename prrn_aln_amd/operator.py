@@ -148,3 +148,14 @@ def align2_batch(ctx, pwds: Sequence[PwdM]):
 
 def align2(ctx, pwd: PwdM):
     return align2_batch(ctx, [pwd])[0]
+
+
+def HomScore(ctx, pwd: PwdM):
+    """<-> VTYPE HomScore(seqs, pwdm, rr) (reference src/maln2.cc:1837): (score, (rr0, rr1))."""
+    L = lib()
+    scr = C.c_double(0)
+    rr = (C.c_int64 * 2)()
+    rc = L.g2g_homscore(ctx._h, pwd._h, C.byref(scr), rr)
+    if rc:
+        raise G2GError("g2g_homscore rc=%d: %s" % (rc, last_error()))
+    return scr.value, (rr[0], rr[1])

@@ -37,6 +37,19 @@ def test_align2_matches_reference_goldens(ctx):
     assert not bad, bad
 
 
+def test_homscore_matches_reference_goldens(ctx):
+    bad = []
+    for f in GOLD:
+        d = dict(np.load(f))
+        alp = params_from_golden(d)
+        ga, gb = groups_from_golden(d, alp)
+        pw = op.PwdM([ga, gb], alp)
+        scr, rr = op.HomScore(ctx, pw)
+        if scr != d["homscore"][0] or list(rr) != d["homscore_rr"].tolist():
+            bad.append((os.path.basename(f), scr, float(d["homscore"][0]), rr, d["homscore_rr"].tolist()))
+    assert not bad, bad
+
+
 def test_sweep_batch_vs_oracle_and_properties(ctx):
     """A whole (small) sweep as one batch: every DP bit-equal to the oracle; skeleton properties hold."""
     fam = make_family(40, 160, 21)
