@@ -8,12 +8,14 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <chrono>
 #include "../../include/g2g.h"
 #include "g2g_device.h"
 #include "g2g_internal.h"
 
 #include "g2g_kernels.hip"          // one translation unit: kernels + launcher (no -fgpu-rdc needed)
 #include "g2g_kernels_v2.hip"
+#include "g2g_kernels_v3.hip"
 
 static thread_local std::string g_err;
 void g2g_set_error(const char *fmt, const char *a)
@@ -108,9 +110,11 @@ struct g2g_batch {
     size_t lds2;                    // dynamic LDS bytes of the v2 launch
     size_t lds2p;                   // ... of the v2 prologue launch
     int v2_maxrows;                 // longest a-range among the v2 problems
-    V2Tile *d_tiles;                // v2 tiles: per variant (hf2, hf3, pf2, pf3) a queue ordered by wavefront i + j
-    int var_off[5];                 // variant v owns tiles [var_off[v], var_off[v+1])
-    int *d_flags;                   // [0..3] queue heads, [4..] tile-completion flags (generation numbers)
+    V2Tile *d_tiles;                // tiles: per variant (v2: hf2, hf3, pf2, pf3; v3: the same four) a queue ordered by wavefront i + j
+    int var_off[13];                // variant v owns tiles [var_off[v], var_off[v+1])
+    V3Lds v3lds[8];                 // LDS plan of the v3 variants
+    int v3_cols;                    // columns per v3 tile
+    int *d_flags;                   // [0..11] queue heads, [12..15] incident report, [16..] tile-completion flags (generation numbers)
     int nflags, gen;
     long long ntiles;
     float fwd_ms, tb_ms;
@@ -125,6 +129,55 @@ static size_t v2_lds_bytes(int kind, int noll, int capa, int capb, int mla, int 
     return ((noll == 3 ? 9 : 6) * R + 5) * recsz + 16 * R + lists + 16;
 }
 static const size_t V2_LDS_MAX = 160 * 1024;
+
+// LDS plan of the v3 kernel (g2g_kernels_v3.hip) for one problem with C-column tiles: ring rows, the black
+// list, staging scalars, and the static-list pools of a strip's rows / a block's columns
+static V3Lds v3_layout(int rows_bytes, int ca4max, int apool, int bpool, int C)
+{
+    V3Lds L;
+    int o = 0;
+    auto take = [&](int bytes) { int r = o; o = (o + bytes + 15) & ~15; return r; };
+    L.rows = take(rows_bytes);
+    L.black = take(4 * (ca4max + 4));
+    L.stsc = take(4 * 28);
+    L.aglen = take(4 * (apool + 4));
+    L.afreq = take(8 * (apool + 4));
+    L.boff = take(bpool ? 4 * 3 * C : 0);
+    L.bglen = take(bpool ? 4 * (bpool + 4) : 0);
+    L.bfreq = take(bpool ? 8 * (bpool + 4) : 0);
+    L.svals = take(4 * 64);
+    L.sink = take(4 * 64);
+    L.total = o;
+    return L;
+}
+struct V3Need { int rows_bytes, ca4, apool, bpool, total; };
+static V3Need v3_need(const DevProb &d, const g2g_problem *p, int C, bool areg = false)
+{
+    V3Need n;
+    const int capb = d.kind == 2 ? d.capb : 0;
+    n.ca4 = (d.capa + 3) & ~3;
+    const int lsz = n.ca4 + ((capb + 3) & ~3);
+    n.rows_bytes = 65 * v3_pitch(d.noll == 3 ? 9 : 6, lsz) * 4;
+    n.apool = 0; n.bpool = 0;
+    const int al = p->a.left, ar = p->a.right, bl = p->b.left, br = p->b.right;
+    for (int m0 = al; m0 < ar; m0 += 64) {
+        const int me = std::min(m0 + 64, ar);
+        int c = 0;
+        for (int v = 0; v < 3; ++v) c += p->a.gfq.off[v][me + 1] - p->a.gfq.off[v][m0 + 1];
+        n.apool = std::max(n.apool, c);
+    }
+    if (d.kind == 2)
+        for (int c0 = bl; c0 < br; c0 += C) {
+            const int c1 = std::min(c0 + C, br);
+            int c = 0;
+            for (int v = 0; v < 3; ++v) c += p->b.gfq.off[v][c1 + 1] - p->b.gfq.off[v][c0 + 1];
+            n.bpool = std::max(n.bpool, c);
+        }
+    if (d.kind == 2 && !n.bpool) n.bpool = 1;
+    if (areg) n.apool = 0;                                  // the rows' static lists live in registers
+    n.total = v3_layout(n.rows_bytes, n.ca4, n.apool, n.bpool, C).total;
+    return n;
+}
 
 static int kind_of(int alnmode)
 {
@@ -217,6 +270,8 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     HIPCHK(hipSetDevice(ctx->device));
     g2g_batch *b = new g2g_batch();
     b->ctx = ctx; b->n = n; b->d_arena = 0; b->d_probs = 0; b->fwd_ms = b->tb_ms = 0;
+    b->v3_cols = 256;
+    if (const char *e = getenv("G2G_V3_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v3_cols = c; }
     b->dp.resize(n); b->status.assign(n, G2G_OK); b->cells.assign(n, 0); b->out_off.assign(n, 0); b->tcap.assign(n, 0); b->rr1.assign(n, 0);
     Blob bl;
     size_t probs_off = bl.put(0, 0);
@@ -280,10 +335,14 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         d.trace = OFF<uint8_t>(take((size_t) (d.d1 - d.d0 + 1) * tmax));
         // v2 kernel (gap-profile engines): packed 16-bit gap lengths and an LDS budget decide eligibility
         d.v2_ok = 0;
-        if ((d.kind == 1 || d.kind == 2) && !getenv("G2G_FORCE_V1") && p->a.len + p->b.len < 65000 &&
-            v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist) + 4 * G2G_V2_THREADS <= V2_LDS_MAX) {
+        if ((d.kind == 1 || d.kind == 2) && !getenv("G2G_FORCE_V1") && p->a.len + p->b.len < 65000) {
+            if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_AREG") && d.kind == 1 && d.a.maxlist <= G2G_V3_NA &&
+                v3_need(d, p, b->v3_cols, true).total <= (int) V2_LDS_MAX) d.v2_ok = 3;
+            else if (!getenv("G2G_FORCE_V2") && (d.kind == 1 || getenv("G2G_V3_PF")) && v3_need(d, p, b->v3_cols).total <= (int) V2_LDS_MAX) d.v2_ok = 2;
+            else if (v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist) + 4 * G2G_V2_THREADS <= V2_LDS_MAX) d.v2_ok = 1;
+        }
+        if (d.v2_ok) {
             const size_t recsz = (16 + 4 * (size_t) (d.capa + (d.kind == 2 ? d.capb : 0)) + 15) & ~(size_t) 15;
-            d.v2_ok = 1;
             d.v2_rowstride = p->b.len + 3;
             d.v2_rowH = OFF<void>(take(3 * recsz * (size_t) d.v2_rowstride));
             d.v2_rowG = OFF<void>(take(3 * recsz * (size_t) d.v2_rowstride));
@@ -326,7 +385,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         for (int i = 0; i < n; ++i) {
             const DevProb &d = b->dp[i];
             if (d.kind < 0) continue;
-            if (d.v2_ok) { i2[b->n2++] = i; b->lds2 = std::max(b->lds2, v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist)); }
+            if (d.v2_ok) { i2[b->n2++] = i; if (d.v2_ok == 1) b->lds2 = std::max(b->lds2, v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist)); }
             else i1[b->n1++] = i;
         }
         b->d_idx1 = (int *) (b->d_arena + idx_off);
@@ -336,9 +395,10 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     // ordered by wavefront i + j; one completion flag per tile slot (empty slots count as done for ever)
     b->d_tiles = 0; b->ntiles = 0; b->lds2p = 0; b->v2_maxrows = 1; b->d_flags = 0; b->nflags = 0; b->gen = 0;
     {
-        const int R = G2G_V2_THREADS / 8, C = G2G_V2_TILE_COLS;
-        std::vector<std::vector<std::vector<V2Tile> > > q(4);    // [variant][wavefront] -> tiles
-        std::vector<int> flags(12, 0);                    // 0-3 queue heads, 4-11 incident report
+        std::vector<std::vector<std::vector<V2Tile> > > q(12);   // [variant][wavefront] -> tiles
+        std::vector<int> flags(16, 0);                    // 0-11 queue heads, 12-15 incident report
+        V3Need need[8];
+        memset(need, 0, sizeof need);
         for (int i = 0; i < n; ++i) {
             const DevProb &d = b->dp[i];
             if (d.kind < 0 || !d.v2_ok) continue;
@@ -346,8 +406,15 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             b->lds2p = std::max(b->lds2p, 5 * recsz + 64);
             b->v2_maxrows = std::max(b->v2_maxrows, d.a.right - d.a.left);
             const int al = d.a.left, ar = d.a.right, bl_ = d.b.left, br = d.b.right;
+            const int R = d.v2_ok >= 2 ? 64 : G2G_V2_THREADS / 8, C = d.v2_ok >= 2 ? b->v3_cols : G2G_V2_TILE_COLS;
             const int nstrip = (ar - al + R - 1) / R, nblk = (br - bl_ + C - 1) / C;
-            const int var = (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
+            const int var = (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
+            if (d.v2_ok >= 2) {
+                const V3Need nd = v3_need(d, prob[i], C, d.v2_ok == 3);
+                V3Need &x = need[var - 4];
+                x.rows_bytes = std::max(x.rows_bytes, nd.rows_bytes); x.ca4 = std::max(x.ca4, nd.ca4);
+                x.apool = std::max(x.apool, nd.apool); x.bpool = std::max(x.bpool, nd.bpool);
+            }
             const int fbase = (int) flags.size();
             flags.resize(flags.size() + (size_t) nstrip * nblk, 0x7fffffff);
             for (int ti = 0; ti < nstrip; ++ti) {
@@ -377,11 +444,12 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             }
         }
         std::vector<V2Tile> all;
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < 12; ++v) {
             b->var_off[v] = (int) all.size();
             for (size_t k = 0; k < q[v].size(); ++k) all.insert(all.end(), q[v][k].begin(), q[v][k].end());
         }
-        b->var_off[4] = (int) all.size();
+        b->var_off[12] = (int) all.size();
+        for (int v = 0; v < 8; ++v) b->v3lds[v] = v3_layout(need[v].rows_bytes, need[v].ca4, need[v].apool, need[v].bpool, b->v3_cols);
         b->ntiles = (long long) all.size();
         b->nflags = (int) flags.size();
         if (!all.empty()) {
@@ -426,9 +494,11 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         // one launch per tile wavefront: stream order is the dependency between wavefronts
         typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int);
         static const v2k_t v2k[4] = {g2g_v2_hf2, g2g_v2_hf3, g2g_v2_pf2, g2g_v2_pf3};
+        typedef void (*v3k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V3Lds, int);
+        static const v3k_t v3k[8] = {g2g_v3_hf2, g2g_v3_hf3, g2g_v3_pf2, g2g_v3_pf3, g2g_v3r_hf2, g2g_v3r_hf3, 0, 0};
         // one persistent launch per variant, each on its own stream (they are independent of each other)
         ++b->gen;
-        HIPCHK(hipMemsetAsync(b->d_flags, 0, 12 * sizeof(int), ctx->stream));           // queue heads, incident report
+        HIPCHK(hipMemsetAsync(b->d_flags, 0, 16 * sizeof(int), ctx->stream));           // queue heads, incident report
         HIPCHK(hipEventRecord(ctx->vev[4], ctx->stream));
         int ncu = 256;
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) ncu = pr.multiProcessorCount; }
@@ -446,6 +516,27 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipEventRecord(ctx->vev[v], ctx->vstream[v]));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[v], 0));
         }
+        for (int v = 0; v < 8; ++v) {
+            const int cnt = b->var_off[v + 5] - b->var_off[v + 4];
+            if (!cnt || !v3k[v]) continue;
+            if (const char *e = getenv("G2G_ONLY_VAR")) if (atoi(e) != v) continue;       // profiling aid
+            hipStream_t vs = ctx->vstream[v & 3];
+            const V3Lds &LO = b->v3lds[v];
+            if (LO.total > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *) v3k[v], hipFuncAttributeMaxDynamicSharedMemorySize, LO.total));
+            HIPCHK(hipStreamWaitEvent(vs, ctx->vev[4], 0));
+            int wpc = (int) (V2_LDS_MAX / (size_t) LO.total);              // resident tiles per CU (LDS-bound)
+            if (wpc < 1) wpc = 1; if (wpc > 16) wpc = 16;
+            if (const char *e = getenv("G2G_V3_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc = w; }
+            const int grid = std::min(cnt, ncu * wpc);
+            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v3 variant %d: %d tiles, grid %d, lds %d (rows %d, apool@%d, bpool@%d), cols %d, gen %d\n", v, cnt, grid, LO.total, LO.black, LO.aglen, LO.bglen, b->v3_cols, b->gen); fflush(stderr); }
+            hipLaunchKernelGGL(v3k[v], dim3(grid), dim3(64), (size_t) LO.total, vs,
+                               (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v + 4]), cnt,
+                               b->d_flags + 4 + v, b->d_flags, b->gen, LO, b->v3_cols);
+            HIPCHK(hipGetLastError());
+            if (getenv("G2G_DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v3 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
+            HIPCHK(hipEventRecord(ctx->vev[v & 3], vs));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[v & 3], 0));
+        }
     }
     if (b->n1) {
         hipLaunchKernelGGL(g2g_forward_kernel, dim3(b->n1), dim3(G2G_FWD_THREADS), 0, ctx->stream,
@@ -458,11 +549,11 @@ extern "C" int g2g_batch_run(g2g_batch *b)
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (b->d_flags) {
-        int rep[12];
+        int rep[16];
         HIPCHK(hipMemcpy(rep, b->d_flags, sizeof rep, hipMemcpyDeviceToHost));
-        if (rep[4]) {
+        if (rep[12]) {
             char msg[128];
-            snprintf(msg, sizeof msg, "%d tile waits timed out (first: queue slot %d on flag %d)", rep[4], rep[5], rep[6]);
+            snprintf(msg, sizeof msg, "%d tile waits timed out (first: queue slot %d on flag %d)", rep[12], rep[13], rep[14]);
             g2g_set_error("v2 scheduler: %s", msg);
             return G2G_ERR_DEVICE;
         }

@@ -61,9 +61,15 @@ __device__ __forceinline__ void team_sync()
 // ops, so the first four entries of every list a merge touches are read up front (independent reads, one
 // wait) and indexed with selects; longer lists fall through to LDS for index >= 4.
 struct DHead { unsigned e0, e1, e2, e3; const lu32 *p; };          // dynamic {glen,nins} list
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+// AL: the list starts on a 16-byte boundary (v3 layout) -- one ds_read_b128
+template <bool AL = false>
 __device__ __forceinline__ DHead dh_load(const lu32 *p)
 {
-    DHead h; h.e0 = p[0]; h.e1 = p[1]; h.e2 = p[2]; h.e3 = p[3]; h.p = p; return h;
+    DHead h;
+    if (AL) { const v4u32 v = *(const LDS v4u32 *) p; h.e0 = v.x; h.e1 = v.y; h.e2 = v.z; h.e3 = v.w; }
+    else { h.e0 = p[0]; h.e1 = p[1]; h.e2 = p[2]; h.e3 = p[3]; }
+    h.p = p; return h;
 }
 // nins of the entry that governs static gap length g: last k with glen[k] <= g (GapLenSD, gfreq.h:67).
 // Entries behind the terminator are garbage: the AND chain stops at the first failed comparison.
@@ -73,11 +79,13 @@ __device__ __forceinline__ int dh_nins(int g, const DHead &h)
     const bool c2 = c1 && g >= (int) (h.e2 >> 16);
     const bool c3 = c2 && g >= (int) (h.e3 >> 16);
     unsigned e = c2 ? h.e2 : (c1 ? h.e1 : h.e0);
+#ifndef G2G_EXP_NOSLOW
     if (c3) {                                                       // rare: more than three entries below g
         int k = 3;
         while (g >= (int) (h.p[k + 1] >> 16) && k < DL_GUARD) ++k;
         e = h.p[k];
     }
+#endif
     return (int) (e & 0xFFFFu);
 }
 template <class CL> struct SHead { int g0, g1, g2, g3; CL l; };    // static GFREQ list (glen part)
@@ -101,10 +109,10 @@ __device__ __forceinline__ int p_gaplen(int g, const lu32 *dl)
 }
 // newgap(cf, dlc, df, dld), gfreq.cc:507-521.  The reference re-evaluates GapLenSD(cf) of the current cf
 // at the start of every df step; the value cannot change, so it is carried in `gi`.
-template <class CL, class DL>
+template <class CL, class DL, bool AL = false>
 __device__ double p_newgap4(const CL cf, const lu32 *dlc, const DL df, const lu32 *dld)
 {
-    const DHead hc = dh_load(dlc), hd = dh_load(dld);
+    const DHead hc = dh_load<AL>(dlc), hd = dh_load<AL>(dld);
     const SHead<CL> sc = sh_load(cf);
     const SHead<DL> sd = sh_load(df);
     double g = 0;
@@ -126,12 +134,12 @@ __device__ double p_newgap4(const CL cf, const lu32 *dlc, const DL df, const lu3
     return g;
 }
 // newgap1 / newgap2, maln.h:296-308 (+ newgapc/newgapd :280-291)
-template <class CL>
+template <class CL, bool AL = false>
 __device__ double p_newgap1(const DevProb &P, const CL acf, const lu32 *dla, int glb)
 {
     const SHead<CL> sc = sh_load(acf);
     if (sc.g0 < 0) return 0;
-    const DHead h = dh_load(dla);
+    const DHead h = dh_load<AL>(dla);
     if (sc.g1 >= 0) {
         for (int ci = 0; ; ++ci) {                          // newgap(cf, dlc, j), gfreq.cc:523-532
             const int cg = sh_glen(sc, ci);
@@ -142,12 +150,12 @@ __device__ double p_newgap1(const DevProb &P, const CL acf, const lu32 *dla, int
     }
     return ((int) (h.e0 & 0xFFFFu) + sc.g0 >= glb) ? (P.weighted_gop * acf.freq[0]) : 0;
 }
-template <class CL>
+template <class CL, bool AL = false>
 __device__ double p_newgap2(const DevProb &P, const CL adf, int glb, const lu32 *dla)
 {
     const SHead<CL> sd = sh_load(adf);
     if (sd.g0 < 0) return 0;
-    const DHead h = dh_load(dla);
+    const DHead h = dh_load<AL>(dla);
     if (sd.g1 >= 0) {                                       // newgap(df, i, dld), gfreq.cc:534-545
         double g = 0;
         for (int di = 0; ; ++di) {
@@ -165,10 +173,10 @@ __device__ double p_newgap2(const DevProb &P, const CL adf, int glb, const lu32 
 // store: when dst aliases src (F updated in place) this is the out-of-place result, which equals the
 // reference's in-place one (an entry is overwritten only after the scan has moved past it, and the first
 // entry's glen is always 0).
-template <class CL>
+template <class CL, bool AL = false>
 __device__ void p_newdelta(lu32 *dst, lu32 *dst2, const CL df, const lu32 *src)
 {
-    const DHead h = dh_load(src);
+    const DHead h = dh_load<AL>(src);
     const SHead<CL> sd = sh_load(df);
     int kd = 0;
     unsigned tg = 0, tn = 0;
@@ -854,10 +862,10 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         if (t >= ntiles) break;                                                                     \
         const V2Tile T = tiles[t];                                                                  \
         V2_WAIT_T0                                                                                  \
-        if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 4, t);                         \
-        if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 4, t);                     \
-        if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 4, t);                     \
-        if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 4, t);                       \
+        if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 12, t);                         \
+        if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 12, t);                     \
+        if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 12, t);                     \
+        if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 12, t);                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                          \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \

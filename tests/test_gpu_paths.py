@@ -1,0 +1,86 @@
+"""Every forward-kernel generation and tile geometry against the reference goldens and the oracle.
+
+The engine picks a kernel per problem (g2g_engine.hip: v3r = one lane per cell with the rows' static lists in
+registers, v3 = the same with the lists in LDS, v2 = 8-lane teams, v1 = anti-diagonal sweep with the state
+in HBM).  The selection can be forced through environment variables that are read at batch-prepare time; each
+forced configuration must reproduce the reference bit for bit.  Narrow tiles (G2G_V3_COLS) make even the small
+golden DPs span several column blocks and strips."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oraclelib
+from prrn_aln_amd import _abi, engine, operator as op, sweep
+from prrn_aln_amd.synth import make_family
+
+pytestmark = pytest.mark.gpu
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+CONFIGS = {
+    "default": {},
+    "v3r_cols32": {"G2G_V3_COLS": "32"},
+    "v3lds_all": {"G2G_NO_AREG": "1", "G2G_V3_PF": "1"},
+    "v3lds_all_cols32": {"G2G_NO_AREG": "1", "G2G_V3_PF": "1", "G2G_V3_COLS": "32"},
+    "v3_pf": {"G2G_V3_PF": "1", "G2G_V3_COLS": "64"},
+    "v2": {"G2G_FORCE_V2": "1"},
+    "v1": {"G2G_FORCE_V1": "1"},
+}
+ALLVARS = sorted({k for c in CONFIGS.values() for k in c})
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = engine.Context()
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def L():
+    return oraclelib.load()
+
+
+def _setenv(monkeypatch, cfg):
+    for k in ALLVARS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in cfg.items():
+        monkeypatch.setenv(k, v)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_goldens_every_path(ctx, monkeypatch, name):
+    _setenv(monkeypatch, CONFIGS[name])
+    ds = [dict(np.load(f)) for f in GOLD]
+    hs = [_abi.problem_from_arrays(d) for d in ds]
+    res = ctx.forward_batch(hs)
+    bad = []
+    for f, d, (scr, cells, tr, st) in zip(GOLD, ds, res):
+        if st != 0 or scr != d["scr"][0] or not np.array_equal(tr, d["vmf_trace"]):
+            bad.append((os.path.basename(f), st, scr, float(d["scr"][0])))
+    assert not bad, bad
+
+
+FAMILIES = [
+    ("prot_ls1", dict(n_seq=24, length=700, seed=11), dict()),
+    ("prot_ls3", dict(n_seq=20, length=650, seed=12, max_indel=25), dict(ls=3)),
+]
+
+
+@pytest.mark.parametrize("name", ["v3r_cols32", "v3lds_all", "v3_pf", "v2"])
+@pytest.mark.parametrize("fam", FAMILIES, ids=[f[0] for f in FAMILIES])
+def test_large_divisions_every_path(ctx, L, monkeypatch, name, fam):
+    """Group-vs-rest divisions of a 650-700 column family (many strips and blocks) per forced path."""
+    _setenv(monkeypatch, CONFIGS[name])
+    _, fkw, akw = fam
+    sw = sweep.Sweep(make_family(**fkw), op.AlnParam(**akw), limit=10)
+    res = op.align2_batch(ctx, sw.pwds)
+    for pw, (scr, skl, st) in zip(sw.pwds, res):
+        assert st == 0
+
+        class H:
+            c = pw.problem
+        oscr, ocells, otr = oraclelib.forward(L, H)
+        assert scr == oscr, (name, pw.alnmode, scr, oscr)
+        assert np.array_equal(skl, oraclelib.stdskl(L, otr))
