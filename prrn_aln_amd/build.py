@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "libg2g.so")
 
 # -ffp-contract=off: device AND host doubles must never be fused into FMAs (bit-exact parity with the
 # reference CPU path, SURVEY.md §7 "Hard parts").
-FLAGS = ["--offload-arch=gfx950", "-DG2G_FWD_THREADS=512", "-DG2G_V2_THREADS=256", "-DG2G_V2_MINWAVES=3", "-DG2G_V2_TILE_COLS=512", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+FLAGS = ["--offload-arch=gfx950", "-mllvm", "-amdgpu-promote-alloca-to-vector-limit=4096", "-DG2G_FWD_THREADS=512", "-DG2G_V2_THREADS=256", "-DG2G_V2_MINWAVES=3", "-DG2G_V2_TILE_COLS=512", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wno-unused-value", "-Wno-unused-result"]
 
 

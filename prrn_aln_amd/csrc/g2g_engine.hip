@@ -270,7 +270,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     HIPCHK(hipSetDevice(ctx->device));
     g2g_batch *b = new g2g_batch();
     b->ctx = ctx; b->n = n; b->d_arena = 0; b->d_probs = 0; b->fwd_ms = b->tb_ms = 0;
-    b->v3_cols = 256;
+    b->v3_cols = 128;
     if (const char *e = getenv("G2G_V3_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v3_cols = c; }
     b->dp.resize(n); b->status.assign(n, G2G_OK); b->cells.assign(n, 0); b->out_off.assign(n, 0); b->tcap.assign(n, 0); b->rr1.assign(n, 0);
     Blob bl;
@@ -336,7 +336,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         // v2 kernel (gap-profile engines): packed 16-bit gap lengths and an LDS budget decide eligibility
         d.v2_ok = 0;
         if ((d.kind == 1 || d.kind == 2) && !getenv("G2G_FORCE_V1") && p->a.len + p->b.len < 65000) {
-            if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_AREG") && d.kind == 1 && d.a.maxlist <= G2G_V3_NA &&
+            if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_AREG") && (d.kind == 1 || getenv("G2G_V3_PF")) && d.a.maxlist <= G2G_V3_NA &&
                 v3_need(d, p, b->v3_cols, true).total <= (int) V2_LDS_MAX) d.v2_ok = 3;
             else if (!getenv("G2G_FORCE_V2") && (d.kind == 1 || getenv("G2G_V3_PF")) && v3_need(d, p, b->v3_cols).total <= (int) V2_LDS_MAX) d.v2_ok = 2;
             else if (v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist) + 4 * G2G_V2_THREADS <= V2_LDS_MAX) d.v2_ok = 1;
@@ -495,7 +495,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int);
         static const v2k_t v2k[4] = {g2g_v2_hf2, g2g_v2_hf3, g2g_v2_pf2, g2g_v2_pf3};
         typedef void (*v3k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V3Lds, int);
-        static const v3k_t v3k[8] = {g2g_v3_hf2, g2g_v3_hf3, g2g_v3_pf2, g2g_v3_pf3, g2g_v3r_hf2, g2g_v3r_hf3, 0, 0};
+        static const v3k_t v3k[8] = {g2g_v3_hf2, g2g_v3_hf3, g2g_v3_pf2, g2g_v3_pf3, g2g_v3r_hf2, g2g_v3r_hf3, g2g_v3r_pf2, g2g_v3r_pf3};
         // one persistent launch per variant, each on its own stream (they are independent of each other)
         ++b->gen;
         HIPCHK(hipMemsetAsync(b->d_flags, 0, 16 * sizeof(int), ctx->stream));           // queue heads, incident report

@@ -521,6 +521,45 @@ __device__ __forceinline__ void list_g2l(li32 *gl, lf64 *fr, const DevSide &s, i
     for (int k = lane; k < e - o; k += nl) { gl[k] = sg[k]; fr[k] = sf[k]; }
 }
 
+// ---- a wave-uniform private copy of the DP descriptor -------------------------------------------------
+// The descriptor lives in HBM next to buffers the kernel writes, so the compiler must assume every store may
+// change it: left alone, the sweep re-reads its fields with vector loads -- and a full vmcnt(0) wait -- in the
+// middle of every step.  The fields the sweep uses are therefore copied once per tile into scalar registers.
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ double uni(double x)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+template <class T> __device__ __forceinline__ T *uni(T *p)
+{
+    const unsigned long long v = (unsigned long long) p;
+    const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) v);
+    const unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (v >> 32));
+    return (T *) (((unsigned long long) hi << 32) | lo);
+}
+__device__ __forceinline__ void uni_side(DevSide &d, const DevSide &s)
+{
+    d.many = uni(s.many); d.len = uni(s.len); d.left = uni(s.left); d.right = uni(s.right); d.nils = uni(s.nils);
+    d.nelm = uni(s.nelm); d.felm = uni(s.felm); d.hetero = uni(s.hetero); d.maxlist = uni(s.maxlist);
+    d.seq = uni(s.seq); d.weight = uni(s.weight); d.pseq = uni(s.pseq); d.thk = uni(s.thk);
+    for (int v = 0; v < 3; ++v) { d.off[v] = uni(s.off[v]); d.glen[v] = uni(s.glen[v]); d.freq[v] = uni(s.freq[v]); }
+    d.gapdens = uni(s.gapdens); d.postgapdens = uni(s.postgapdens);
+}
+__device__ __forceinline__ void uni_prob(DevProb &d, const DevProb &s)
+{
+    d.kind = uni(s.kind); d.noll = uni(s.noll); d.sim2_kind = uni(s.sim2_kind); d.crg2_kind = uni(s.crg2_kind);
+    d.codonk1 = uni(s.codonk1); d.lw = uni(s.lw); d.up = uni(s.up); d.width = uni(s.width);
+    d.basic_gop = uni(s.basic_gop); d.weighted_gop = uni(s.weighted_gop); d.u = uni(s.u);
+    d.u2divu1 = uni(s.u2divu1); d.v2divv1 = uni(s.v2divv1);
+    d.simmtx = uni(s.simmtx); d.simdim = uni(s.simdim); d.capa = uni(s.capa); d.capb = uni(s.capb);
+    uni_side(d.a, s.a); uni_side(d.b, s.b);
+    d.v2_rowH = uni(s.v2_rowH); d.v2_rowG = uni(s.v2_rowG); d.v2_rowG2 = uni(s.v2_rowG2); d.v2_colH = uni(s.v2_colH);
+    d.v2_cbH = uni(s.v2_cbH); d.v2_cbF = uni(s.v2_cbF); d.v2_cbF2 = uni(s.v2_cbF2);
+    d.v2_rowstride = uni(s.v2_rowstride); d.v2_sim = uni(s.v2_sim); d.v2_rowoff = uni(s.v2_rowoff);
+    d.trace = uni(s.trace); d.tstride = uni(s.tstride); d.d0 = uni(s.d0); d.d1 = uni(s.d1);
+    d.score = uni(s.score);
+}
+
 // ---- one TILE = (strip of R rows) x (block of G2G_V2_TILE_COLS columns) by one workgroup ------------
 // Tiles of a DP depend on their upper, left and upper-left neighbours only, so all tiles with the same
 // i + j (over every DP of the batch) run in one launch; a big DP is spread over many workgroups instead
@@ -532,8 +571,10 @@ __device__ __forceinline__ void list_g2l(li32 *gl, lf64 *fr, const DevSide &s, i
 //   cbH/cbF/cbF2[row]        each row's H corner and F records at the block's right edge
 //   colH[row]                the left boundary chain
 template <int KIND, bool NOLL3>
-__device__ void v2_tile(const DevProb &P, lchar *lds, int ti, int tj, int nsteps)
+__device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nsteps)
 {
+    DevProb P;
+    uni_prob(P, Pmem);
     const DevSide &a = P.a, &b = P.b;
     const int tid = threadIdx.x, lane = tid & (TEAM - 1), team = tid / TEAM;
     V2Geom G;

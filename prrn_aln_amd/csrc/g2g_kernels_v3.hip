@@ -25,14 +25,20 @@
 
 struct RS { double val; int dir, glb; };                  // record scalars
 __device__ __forceinline__ RS rs_black() { RS r; r.val = NEVSEL; r.dir = 0; r.glb = 0; return r; }
+// lane t <- lane t-1 over the whole wave: one DPP move per dword (wave_shr:1), no LDS crossbar round trip
+__device__ __forceinline__ int dpp_up1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ RS rs_up(const RS &x)
 {
-    RS r; r.val = __shfl_up(x.val, 1); r.dir = __shfl_up(x.dir, 1); r.glb = __shfl_up(x.glb, 1); return r;
+    RS r;
+    r.val = __hiloint2double(dpp_up1(__double2hiint(x.val)), dpp_up1(__double2loint(x.val)));
+    r.dir = dpp_up1(x.dir); r.glb = dpp_up1(x.glb);
+    return r;
 }
 __device__ __forceinline__ RS rs_sel(bool c, const RS &x, const RS &y)
 {
     RS r; r.val = c ? x.val : y.val; r.dir = c ? x.dir : y.dir; r.glb = c ? x.glb : y.glb; return r;
 }
+
 
 // byte offsets of the LDS regions of a v3 launch (host: v3_lds_plan)
 struct V3Lds { int rows, black, stsc, aglen, afreq, boff, bglen, bfreq, svals, sink, total; };
@@ -45,26 +51,31 @@ G2G_HD inline int v3_pitch(int nslot, int lsz)            // dwords per LDS row:
 }
 
 
+#ifndef G2G_V3_HF_UNROLL
+#define G2G_V3_HF_UNROLL 16               // _hf merge loops fully unrolled (faster than s_set_gpr_idx indexing); _pf loops stay rolled (code size)
+#endif
 // ---- static lists in REGISTERS ------------------------------------------------------------------------
 // A lane's row never changes inside a tile, so the row's three static lists (s/t/r views, <= NA entries
 // each incl. the terminator) are loaded into registers once per tile.  Every loop over such a list runs
 // with the SAME index in all lanes (fully unrolled, lanes that are done are masked by selects, the wave
 // leaves when no lane is live), so the register arrays are only ever indexed by constants: no LDS traffic,
 // no dependent-load chain, no divergent control flow in the merge loops.
-template <int N> struct RList { int g[N]; double f[N]; };
+// (separate plain arrays, not a struct of arrays: the backend promotes an array to registers -- indexed through
+// s_set_gpr_idx by a uniform loop counter -- only when the array is an alloca of its own; build flag
+// -amdgpu-promote-alloca-to-vector-limit raises the budget so that all six fit)
 template <int N>
-__device__ __forceinline__ void rl_load(RList<N> &r, const DevSide &s, int view, int pos, bool ok)
+__device__ __forceinline__ void rl_load(int (&g)[N], double (&f)[N], const DevSide &s, int view, int pos, bool ok)
 {
     const int o = ok ? s.off[view][pos + 1] : 0, len = ok ? s.off[view][pos + 2] - o : 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const bool v = i < len;
-        r.g[i] = v ? s.glen[view][o + i] : -1;
-        r.f[i] = v ? s.freq[view][o + i] : 0.;
+        g[i] = v ? s.glen[view][o + i] : -1;
+        f[i] = v ? s.freq[view][o + i] : 0.;
     }
 }
 __device__ __forceinline__ bool wave_none(bool live) { return __ballot(live) == 0; }
-template <int N> struct ARegs { RList<N> s, t, r; };
+template <int N> struct ARegs { const int (&sg)[N]; const double (&sf)[N]; const int (&tg)[N]; const double (&tf)[N]; const int (&rg)[N]; const double (&rf)[N]; };
 
 // ---- one cell by one lane ---------------------------------------------------------------------------
 struct Costs { double d0, d1, gnpv, gopv, gnph, goph, gnpv2, gnph2; };
@@ -323,31 +334,31 @@ __device__ __forceinline__ void v3_cell_hf(const DevProb &P, const ARegs<N> &A, 
     const DHead h_fl = dh_load<true>(fll), h_hl = dh_load<true>(hll);
     const DHead h_g2u = dh_load<true>(NOLL3 ? g2ul : gul), h_f2l = dh_load<true>(NOLL3 ? f2ll : fll);
     // ---- gap-open costs: one fused loop over the static entries ---------------------------------------
-    const bool ms = A.s.g[0] >= 0 && A.s.g[1] >= 0, mt = A.t.g[0] >= 0 && A.t.g[1] >= 0, mr = A.r.g[0] >= 0 && A.r.g[1] >= 0;
+    const bool ms = A.sg[0] >= 0 && A.sg[1] >= 0, mt = A.tg[0] >= 0 && A.tg[1] >= 0, mr = A.rg[0] >= 0 && A.rg[1] >= 0;
     NG s_d = {mt, 0.}, s_gu = {ms && do_vert, 0.}, s_hu = {ms && do_vert, 0.}, s_g2 = {ms && do_vert && NOLL3, 0.};
     NG s_fl = {mr && do_hori, 0.}, s_hl = {mr && do_hori, 0.}, s_f2 = {mr && do_hori && NOLL3, 0.};
-#pragma unroll
+#pragma unroll G2G_V3_HF_UNROLL
     for (int i = 0; i < N; ++i) {
         if (wave_none(s_d.live || s_gu.live || s_hu.live || s_fl.live || s_hl.live || (NOLL3 && (s_g2.live || s_f2.live)))) break;
-        ng2_step(s_d, h_hd, hd.glb, A.t.g[i], A.t.f[i]);
-        ng1_step(s_gu, h_gu, gu.glb, A.s.g[i], A.s.f[i]);
-        ng1_step(s_hu, h_hu, hu.glb, A.s.g[i], A.s.f[i]);
-        ng2_step(s_fl, h_fl, fl.glb, A.r.g[i], A.r.f[i]);
-        ng2_step(s_hl, h_hl, hl.glb, A.r.g[i], A.r.f[i]);
+        ng2_step(s_d, h_hd, hd.glb, A.tg[i], A.tf[i]);
+        ng1_step(s_gu, h_gu, gu.glb, A.sg[i], A.sf[i]);
+        ng1_step(s_hu, h_hu, hu.glb, A.sg[i], A.sf[i]);
+        ng2_step(s_fl, h_fl, fl.glb, A.rg[i], A.rf[i]);
+        ng2_step(s_hl, h_hl, hl.glb, A.rg[i], A.rf[i]);
         if (NOLL3) {
-            ng1_step(s_g2, h_g2u, g2u.glb, A.s.g[i], A.s.f[i]);
-            ng2_step(s_f2, h_f2l, f2l.glb, A.r.g[i], A.r.f[i]);
+            ng1_step(s_g2, h_g2u, g2u.glb, A.sg[i], A.sf[i]);
+            ng2_step(s_f2, h_f2l, f2l.glb, A.rg[i], A.rf[i]);
         }
     }
     Costs c;
     c.d1 = 0;
-    c.d0 = ng2_fin(P, s_d, h_hd, hd.glb, A.t.g[0], A.t.g[1], A.t.f[0]);
-    c.gnpv = ng1_fin(P, s_gu, h_gu, gu.glb, A.s.g[0], A.s.g[1], A.s.f[0]);
-    c.gopv = ng1_fin(P, s_hu, h_hu, hu.glb, A.s.g[0], A.s.g[1], A.s.f[0]);
-    c.gnph = ng2_fin(P, s_fl, h_fl, fl.glb, A.r.g[0], A.r.g[1], A.r.f[0]);
-    c.goph = ng2_fin(P, s_hl, h_hl, hl.glb, A.r.g[0], A.r.g[1], A.r.f[0]);
-    c.gnpv2 = NOLL3 ? ng1_fin(P, s_g2, h_g2u, g2u.glb, A.s.g[0], A.s.g[1], A.s.f[0]) : 0;
-    c.gnph2 = NOLL3 ? ng2_fin(P, s_f2, h_f2l, f2l.glb, A.r.g[0], A.r.g[1], A.r.f[0]) : 0;
+    c.d0 = ng2_fin(P, s_d, h_hd, hd.glb, A.tg[0], A.tg[1], A.tf[0]);
+    c.gnpv = ng1_fin(P, s_gu, h_gu, gu.glb, A.sg[0], A.sg[1], A.sf[0]);
+    c.gopv = ng1_fin(P, s_hu, h_hu, hu.glb, A.sg[0], A.sg[1], A.sf[0]);
+    c.gnph = ng2_fin(P, s_fl, h_fl, fl.glb, A.rg[0], A.rg[1], A.rf[0]);
+    c.goph = ng2_fin(P, s_hl, h_hl, hl.glb, A.rg[0], A.rg[1], A.rf[0]);
+    c.gnpv2 = NOLL3 ? ng1_fin(P, s_g2, h_g2u, g2u.glb, A.sg[0], A.sg[1], A.sf[0]) : 0;
+    c.gnph2 = NOLL3 ? ng2_fin(P, s_f2, h_f2l, f2l.glb, A.rg[0], A.rg[1], A.rf[0]) : 0;
     const Dec d = v3_decide<1, NOLL3>(P, c, hd, hu, gu, g2u, hl, fl, f2l, do_vert, do_hori, dab, pua, pub);
     const int win = d.win;
     // ---- list updates: the newdeltas of G (G2) and of a diagonal H share one loop over the t list -----
@@ -355,12 +366,12 @@ __device__ __forceinline__ void v3_cell_hf(const DevProb &P, const ARegs<N> &A, 
     const DHead h_gs = dh_sel(d.g_from_h, h_hu, h_gu), h_gs2 = dh_sel(d.g2_from_h, h_hu, h_g2u);
     ND n_g = {0, 0, 0, do_vert}, n_h = {0, 0, 0, win == 0}, n_g2 = {0, 0, 0, do_vert && NOLL3};
     lu32 *const g_d2 = win == 1 ? dh : nul, *const g2_d2 = win == 2 ? dh : nul;
-#pragma unroll
+#pragma unroll G2G_V3_HF_UNROLL
     for (int i = 0; i < N; ++i) {
         if (wave_none(n_g.on || n_h.on || (NOLL3 && n_g2.on))) break;
-        nd_step(n_g, h_gs, A.t.g[i], dg, g_d2, sink);
-        nd_step(n_h, h_hd, A.t.g[i], dh, nul, sink);
-        if (NOLL3) nd_step(n_g2, h_gs2, A.t.g[i], dg2, g2_d2, sink);
+        nd_step(n_g, h_gs, A.tg[i], dg, g_d2, sink);
+        nd_step(n_h, h_hd, A.tg[i], dh, nul, sink);
+        if (NOLL3) nd_step(n_g2, h_gs2, A.tg[i], dg2, g2_d2, sink);
     }
     nd_fin(n_g, do_vert, dg, g_d2, sink);
     nd_fin(n_h, win == 0, dh, nul, sink);
@@ -368,6 +379,156 @@ __device__ __forceinline__ void v3_cell_hf(const DevProb &P, const ARegs<N> &A, 
     incdelta_h(do_hori, dh_sel(d.f_from_h, h_hl, h_fl), df, win == 3 ? dh : nul, sink);
     if (NOLL3) incdelta_h(do_hori, dh_sel(d.f2_from_h, h_hl, h_f2l), df2, win == 4 ? dh : nul, sink);
     v3_outputs<1, NOLL3>(d, d.g_from_h ? hu.glb : gu.glb, d.g2_from_h ? hu.glb : g2u.glb, do_vert, do_hori, oH, oG, oG2, oF, oF2, trb);
+}
+
+// ---- the _pf cell: the row's static lists in registers, the column's in LDS ---------------------------
+// Fwd2c<_pf>::gapopen needs six merges of a static list of a against a static list of b, each stretched by the
+// record's dynamic lists (newgap, gfreq.cc:507-521).  A two-pointer merge walks one list with a data-dependent
+// index; that one is always taken to be b's (short, in LDS, its first four entries cached in registers), while
+// a's list is the uniform outer loop.  For the merges whose reference form has a's list inside (cf = a.s), the
+// loops are interchanged: entry ci of cf then consumes every entry di of df it is the match of, in di order, so
+// the products are added in exactly the reference's order.
+struct BHead { int g0, g1, g2, g3; double f0, f1, f2, f3; LList l; };
+__device__ __forceinline__ BHead bh_load(const LList l)
+{
+    BHead h;
+    h.g0 = l.glen[0]; h.g1 = l.glen[1]; h.g2 = l.glen[2]; h.g3 = l.glen[3];
+    h.f0 = l.freq[0]; h.f1 = l.freq[1]; h.f2 = l.freq[2]; h.f3 = l.freq[3];
+    h.l = l; return h;
+}
+__device__ __forceinline__ int bh_glen(const BHead &h, const int i) { return i == 0 ? h.g0 : i == 1 ? h.g1 : i == 2 ? h.g2 : i == 3 ? h.g3 : h.l.glen[i]; }
+__device__ __forceinline__ double bh_freq(const BHead &h, const int i) { return i == 0 ? h.f0 : i == 1 ? h.f1 : i == 2 ? h.f2 : i == 3 ? h.f3 : h.l.freq[i]; }
+// cf = a's list (outer, registers), df = b's list (inner): newgap4(a.s, dla, b.t|b.r, dlb)
+struct MY { int di, dg, j; bool live; double g; };
+__device__ __forceinline__ void my_init(MY &s, const bool on, const BHead &df, const DHead &dd)
+{
+    s.di = 0; s.dg = df.g0; s.j = s.dg >= 0 ? s.dg + dh_nins(s.dg, dd) : 0; s.live = on; s.g = 0;
+}
+__device__ __forceinline__ void my_step(MY &s, const int cg, const double cff, const DHead &hc, const BHead &df, const DHead &dd)
+{
+    s.live = s.live && cg >= 0;
+    const int gi = cg + dh_nins(cg, hc);
+    bool adv = s.live && s.dg >= 0 && s.j <= gi;
+    while (__ballot(adv)) {
+        if (adv) {
+            s.g += cff * bh_freq(df, s.di);
+            ++s.di;
+            s.dg = bh_glen(df, s.di);
+            s.j = s.dg >= 0 ? s.dg + dh_nins(s.dg, dd) : 0;
+        }
+        adv = adv && s.dg >= 0 && s.j <= gi;
+    }
+    s.live = s.live && s.dg >= 0;
+}
+// df = a's list (outer, registers), cf = b's list (inner): newgap4(b.s, dlb, a.t|a.r, dla)
+struct MX { int ci, cg, gi; bool live; double g; };
+__device__ __forceinline__ void mx_init(MX &s, const bool on, const BHead &cf, const DHead &hc)
+{
+    s.ci = 0; s.cg = cf.g0; s.gi = s.cg >= 0 ? s.cg + dh_nins(s.cg, hc) : 0; s.live = on; s.g = 0;
+}
+__device__ __forceinline__ void mx_step(MX &s, const int dg, const double dff, const DHead &hd_, const BHead &cf, const DHead &hc)
+{
+    s.live = s.live && dg >= 0;
+    const int j = dg + dh_nins(dg, hd_);
+    bool adv = s.live && s.cg >= 0 && s.gi < j;
+    while (__ballot(adv)) {
+        if (adv) {
+            ++s.ci;
+            s.cg = bh_glen(cf, s.ci);
+            s.gi = s.cg >= 0 ? s.cg + dh_nins(s.cg, hc) : 0;
+        }
+        adv = adv && s.cg >= 0 && s.gi < j;
+    }
+    s.live = s.live && s.cg >= 0;
+    s.g = s.live ? s.g + bh_freq(cf, s.ci) * dff : s.g;
+}
+
+template <bool NOLL3, int N>
+__device__ __forceinline__ void v3_cell_pf(const DevProb &P, const int ca4, const ARegs<N> &A, const CellLists<LList> &L, lu32 *sink,
+    const RS &hd, const lu32 *hdl, const RS &hu, const lu32 *hul, const RS &gu, const lu32 *gul,
+    const RS &g2u, const lu32 *g2ul, const RS &hl, const lu32 *hll, const RS &fl, const lu32 *fll,
+    const RS &f2l, const lu32 *f2ll,
+    lu32 *dh, lu32 *dg, lu32 *dg2, lu32 *df, lu32 *df2,
+    const bool do_vert, const bool do_hori, const double dab, const double pua, const double pub,
+    RS &oH, RS &oG, RS &oG2, RS &oF, RS &oF2, int &trb)
+{
+    // list heads: the records' dynamic lists (a side, b side) and the column's three static lists
+    const DHead a_hd = dh_load<true>(hdl), b_hd = dh_load<true>(hdl + ca4);
+    const DHead a_gu = dh_load<true>(gul), b_gu = dh_load<true>(gul + ca4);
+    const DHead a_hu = dh_load<true>(hul), b_hu = dh_load<true>(hul + ca4);
+    const DHead a_fl = dh_load<true>(fll), b_fl = dh_load<true>(fll + ca4);
+    const DHead a_hl = dh_load<true>(hll), b_hl = dh_load<true>(hll + ca4);
+    const DHead a_g2 = dh_load<true>(NOLL3 ? g2ul : gul), b_g2 = dh_load<true>((NOLL3 ? g2ul : gul) + ca4);
+    const DHead a_f2 = dh_load<true>(NOLL3 ? f2ll : fll), b_f2 = dh_load<true>((NOLL3 ? f2ll : fll) + ca4);
+    const BHead bs = bh_load(L.bs), bt = bh_load(L.bt), br = bh_load(L.br);
+    // ---- gap-open costs: all merges in one uniform loop over the row's static entries -------------------
+    MY y_d, y_gu, y_hu, y_g2;
+    MX x_d, x_fl, x_hl, x_f2;
+    my_init(y_d, true, bt, b_hd); my_init(y_gu, do_vert, br, b_gu); my_init(y_hu, do_vert, br, b_hu);
+    mx_init(x_d, true, bs, b_hd); mx_init(x_fl, do_hori, bs, b_fl); mx_init(x_hl, do_hori, bs, b_hl);
+    if (NOLL3) { my_init(y_g2, do_vert, br, b_g2); mx_init(x_f2, do_hori, bs, b_f2); }
+#pragma unroll 1
+    for (int i = 0; i < N; ++i) {
+        if (wave_none(y_d.live || y_gu.live || y_hu.live || x_d.live || x_fl.live || x_hl.live || (NOLL3 && (y_g2.live || x_f2.live)))) break;
+        my_step(y_d, A.sg[i], A.sf[i], a_hd, bt, b_hd);
+        mx_step(x_d, A.tg[i], A.tf[i], a_hd, bs, b_hd);
+        my_step(y_gu, A.sg[i], A.sf[i], a_gu, br, b_gu);
+        my_step(y_hu, A.sg[i], A.sf[i], a_hu, br, b_hu);
+        mx_step(x_fl, A.rg[i], A.rf[i], a_fl, bs, b_fl);
+        mx_step(x_hl, A.rg[i], A.rf[i], a_hl, bs, b_hl);
+        if (NOLL3) {
+            my_step(y_g2, A.sg[i], A.sf[i], a_g2, br, b_g2);
+            mx_step(x_f2, A.rg[i], A.rf[i], a_f2, bs, b_f2);
+        }
+    }
+    Costs c;
+    c.d0 = y_d.g * P.basic_gop; c.d1 = x_d.g * P.basic_gop;
+    c.gnpv = y_gu.g * P.basic_gop; c.gopv = y_hu.g * P.basic_gop;
+    c.gnph = x_fl.g * P.basic_gop; c.goph = x_hl.g * P.basic_gop;
+    c.gnpv2 = NOLL3 ? y_g2.g * P.basic_gop : 0; c.gnph2 = NOLL3 ? x_f2.g * P.basic_gop : 0;
+    const Dec d = v3_decide<2, NOLL3>(P, c, hd, hu, gu, g2u, hl, fl, f2l, do_vert, do_hori, dab, pua, pub);
+    const int win = d.win;
+    // ---- list updates (update(), fwd2c.cc:216-231) -------------------------------------------------------
+    lu32 *const nul = (lu32 *) 0;
+    // a side: newdelta over a.t for G (G2) and a diagonal H; incdelta for F (F2)
+    {
+        const DHead h_gs = dh_sel(d.g_from_h, a_hu, a_gu), h_gs2 = dh_sel(d.g2_from_h, a_hu, a_g2);
+        ND n_g = {0, 0, 0, do_vert}, n_h = {0, 0, 0, win == 0}, n_g2 = {0, 0, 0, do_vert && NOLL3};
+        lu32 *const g_d2 = win == 1 ? dh : nul, *const g2_d2 = win == 2 ? dh : nul;
+#pragma unroll 1
+        for (int i = 0; i < N; ++i) {
+            if (wave_none(n_g.on || n_h.on || (NOLL3 && n_g2.on))) break;
+            nd_step(n_g, h_gs, A.tg[i], dg, g_d2, sink);
+            nd_step(n_h, a_hd, A.tg[i], dh, nul, sink);
+            if (NOLL3) nd_step(n_g2, h_gs2, A.tg[i], dg2, g2_d2, sink);
+        }
+        nd_fin(n_g, do_vert, dg, g_d2, sink);
+        nd_fin(n_h, win == 0, dh, nul, sink);
+        if (NOLL3) nd_fin(n_g2, do_vert, dg2, g2_d2, sink);
+        incdelta_h(do_hori, dh_sel(d.f_from_h, a_hl, a_fl), df, win == 3 ? dh : nul, sink);
+        if (NOLL3) incdelta_h(do_hori, dh_sel(d.f2_from_h, a_hl, a_f2), df2, win == 4 ? dh : nul, sink);
+    }
+    // b side: newdelta over b.t for F (F2) and a diagonal H; incdelta for G (G2).  The loop index is uniform
+    // (entry k of every lane's column list); lists are as long as the longest one in the wave.
+    {
+        const DHead h_fs = dh_sel(d.f_from_h, b_hl, b_fl), h_fs2 = dh_sel(d.f2_from_h, b_hl, b_f2);
+        ND n_f = {0, 0, 0, do_hori}, n_h = {0, 0, 0, win == 0}, n_f2 = {0, 0, 0, do_hori && NOLL3};
+        lu32 *const f_d2 = win == 3 ? dh + ca4 : nul, *const f2_d2 = win == 4 ? dh + ca4 : nul;
+#pragma unroll 1
+        for (int k = 0; k < DL_GUARD; ++k) {
+            if (wave_none(n_f.on || n_h.on || (NOLL3 && n_f2.on))) break;
+            const int g = bh_glen(bt, k);
+            nd_step(n_f, h_fs, g, df + ca4, f_d2, sink);
+            nd_step(n_h, b_hd, g, dh + ca4, nul, sink);
+            if (NOLL3) nd_step(n_f2, h_fs2, g, df2 + ca4, f2_d2, sink);
+        }
+        nd_fin(n_f, do_hori, df + ca4, f_d2, sink);
+        nd_fin(n_h, win == 0, dh + ca4, nul, sink);
+        if (NOLL3) nd_fin(n_f2, do_hori, df2 + ca4, f2_d2, sink);
+        incdelta_h(do_vert, dh_sel(d.g_from_h, b_hu, b_gu), dg + ca4, win == 1 ? dh + ca4 : nul, sink);
+        if (NOLL3) incdelta_h(do_vert, dh_sel(d.g2_from_h, b_hu, b_g2), dg2 + ca4, win == 2 ? dh + ca4 : nul, sink);
+    }
+    v3_outputs<2, NOLL3>(d, 0, 0, do_vert, do_hori, oH, oG, oG2, oF, oF2, trb);
 }
 
 // record image in HBM: {f64 val; i32 dir; i32 glb; u32 dla[capa]; u32 dlb[capb]} (the v2 format, which the
@@ -386,8 +547,10 @@ __device__ __forceinline__ void v3_rec_store(unsigned *dst, int capa, int capb, 
 }
 
 template <int KIND, bool NOLL3, int NA>
-__device__ void v3_tile(const DevProb &P, lchar *lds, const V3Lds LO, const int ti, const int tj, const int nsteps, const int C)
+__device__ void v3_tile(const DevProb &Pmem, lchar *lds, const V3Lds LO, const int ti, const int tj, const int nsteps, const int C)
 {
+    DevProb P;
+    uni_prob(P, Pmem);
     const DevSide &a = P.a, &b = P.b;
     const int lane = threadIdx.x;                          // blockDim.x == 64
     const int capa = P.capa, capb = (KIND == 2) ? P.capb : 0;
@@ -438,9 +601,12 @@ __device__ void v3_tile(const DevProb &P, lchar *lds, const V3Lds LO, const int 
     }
     // ---- static lists of the strip's rows / the block's columns: contiguous pool ranges -> LDS --------
     CellLists<LList> L;
-    ARegs<(NA > 0 ? NA : 2)> A;
+    constexpr int NN = NA > 0 ? NA : 2;
+    int a_sg[NN], a_tg[NN], a_rg[NN];
+    double a_sf[NN], a_tf[NN], a_rf[NN];
+    const ARegs<NN> A = {a_sg, a_sf, a_tg, a_tf, a_rg, a_rf};
     if (NA > 0) {
-        rl_load(A.s, a, 0, m, row_ok); rl_load(A.t, a, 1, m, row_ok); rl_load(A.r, a, 2, m, row_ok);
+        rl_load(a_sg, a_sf, a, 0, m, row_ok); rl_load(a_tg, a_tf, a, 1, m, row_ok); rl_load(a_rg, a_rf, a, 2, m, row_ok);
         L.as.glen = (li32 *) (lds + LO.aglen); L.as.freq = (lf64 *) (lds + LO.afreq);
         L.at = L.ar = L.bs = L.bt = L.br = L.as;
     } else {
@@ -534,10 +700,46 @@ __device__ void v3_tile(const DevProb &P, lchar *lds, const V3Lds LO, const int 
     const bool do_vert = m > a.left;
     const bool wr_rows = mend < a.right;                   // a strip below will read this strip's last row
     team_sync();
+    // Software pipeline of the HBM traffic.  Whatever a step loads (next column's score, the strip above's records
+    // two columns ahead) is consumed at the TOP of the next step, and whatever a step produces for HBM (trace byte,
+    // the last row's records) is stored at the top of the next step too, right after that consumption: the only
+    // vmcnt wait of a step then covers operations that have had a whole step to complete.
+    unsigned st_h = 0, st_g = 0, st_g2 = 0;
+    bool st_prev = false;                                  // staging registers hold column n0 + 1
+    bool p_act = false; int p_trb = 0; size_t p_tri = 0;    // the previous step's trace byte
+    const int ull = __builtin_amdgcn_readfirstlane(llast);
+    int lhi = m0 + llast + P.up + 1; if (lhi > b.right) lhi = b.right; if (lhi > c1) lhi = c1;
+    int llo = m0 + llast + P.lw; if (llo < b.left) llo = b.left; if (llo < c0) llo = c0;
+    // strip boundary: the last row's newest corner goes to HBM for the strip below, one dword per lane
+    auto flush_rows = [&](const int nl) {                  // nl: the last row's column in the step being flushed
+        if (nl >= llo && nl < lhi) {
+            const int col = nl + 1;
+            const int j = lane - 4;
+#pragma unroll
+            for (int x = 0; x < (NOLL3 ? 3 : 2); ++x) {
+                const RS &r = (x == 0) ? oH : (x == 1) ? oG : oG2;
+                const int slot = (x == 0) ? SLOT_H(col) : (x == 1) ? SLOT_G(col) : SLOT_G2(col);
+                const unsigned v0 = (unsigned) __builtin_amdgcn_readlane(__double2loint(r.val), ull);
+                const unsigned v1 = (unsigned) __builtin_amdgcn_readlane(__double2hiint(r.val), ull);
+                const unsigned v2 = (unsigned) __builtin_amdgcn_readlane(r.dir, ull), v3 = (unsigned) __builtin_amdgcn_readlane(r.glb, ull);
+                unsigned v = lane == 0 ? v0 : lane == 1 ? v1 : lane == 2 ? v2 : v3;
+                if (lane >= 4 && lane < ndw) {
+                    const lu32 *p = V3_L(llast + 1, slot);
+                    v = (j < capa) ? p[j] : (j < capa + capb) ? p[ca4 + j - capa] : 0;
+                }
+                unsigned *dst = (x == 0) ? rowHc : (x == 1) ? rowGc : rowG2c;
+                if (lane < ndw) dst[(size_t) col * ndw + lane] = v;
+            }
+        }
+    };
     for (int s = 0; s < nsteps; ++s) {
         const int n = cbase + s - lane;
         const int n0 = cbase + s;                          // lane 0's column
         const bool active = row_ok && n >= lo && n < hi;
+        // -- top of the step: consume last step's loads, issue last step's stores
+        if (st_prev) stage_store(n0 + 1, vert0, st_h, st_g, st_g2);
+        if (p_act) P.trace[p_tri] = (uint8_t) p_trb;
+        if (wr_rows && s > 0) flush_rows(n0 - 1 - llast);
         // -- hand-over from the row above: what lane t-1 produced one step ago is my upper neighbour, what it
         // produced two steps ago (= my previous upper neighbour) is my diagonal neighbour
         hd = hu;
@@ -559,23 +761,14 @@ __device__ void v3_tile(const DevProb &P, lchar *lds, const V3Lds LO, const int 
                 g2u = rs_sel(lane == 0, t, g2u);
             }
         }
-        // -- prefetches: next column's score/thickness; the strip above's records two columns ahead of lane 0
+        // -- loads for the next step: next column's score/thickness; the strip above's records two columns ahead
         double sim_nx = 0, bc_nx = 0;
         if (active) {
-#ifndef G2G_EXP_NOSIM
             if (!have) { sim_cur = simrow[n]; bc_cur = thk_at(b, n)[0]; }
             if (n + 1 < hi) { sim_nx = simrow[n + 1]; bc_nx = thk_at(b, n + 1)[0]; }
-#else
-            sim_nx = 1.5 * (n & 7); bc_nx = 0.5;
-#endif
         }
-        unsigned st_h = 0, st_g = 0, st_g2 = 0;
-#ifdef G2G_EXP_NOSTAGE
-        const bool st_on = false;
-#else
-        const bool st_on = n0 + 1 < hi0 && n0 + 2 <= c1;
-#endif
-        if (st_on) stage_load(n0 + 2, vert0, st_h, st_g, st_g2);
+        st_prev = n0 + 1 < hi0 && n0 + 2 <= c1;
+        if (st_prev) stage_load(n0 + 2, vert0, st_h, st_g, st_g2);
         RS myH = oH, myG = oG, myG2 = oG2;                 // (the produced records of this step)
         if (active) {
             const bool do_hori = n > b.left;
@@ -606,7 +799,10 @@ __device__ void v3_tile(const DevProb &P, lchar *lds, const V3Lds LO, const int 
             const double pua = a.nils ? unpa(P, m, n) : pua_row;
             const double pub = bc_cur * a_efq * -P.u;                       // unp1(bsi, asi), maln.h:185-187
             int trb = 0;
-            if (KIND == 1 && NA > 0)
+            if (KIND == 2 && NA > 0)
+                v3_cell_pf<NOLL3, (NA > 0 ? NA : 2)>(P, ca4, A, L, (lu32 *) (lds + LO.sink) + lane, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
+                                 dh, dg, dg2, df, df2, do_vert, do_hori, sim_cur, pua, pub, myH, myG, myG2, oF, oF2, trb);
+            else if (KIND == 1 && NA > 0)
                 v3_cell_hf<NOLL3, (NA > 0 ? NA : 2)>(P, A, (lu32 *) (lds + LO.sink) + lane, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
                                  dh, dg, dg2, df, df2, do_vert, do_hori, sim_cur, pua, pub, myH, myG, myG2, oF, oF2, trb);
             else
@@ -615,11 +811,8 @@ __device__ void v3_tile(const DevProb &P, lchar *lds, const V3Lds LO, const int 
             const int d = m + n;
             int mlo, mhi;
             diag_rows(d, a.left, a.right, b.left, b.right, P.lw, P.up, &mlo, &mhi);
-#ifndef G2G_EXP_NOTRACE
-            P.trace[(size_t) (d - P.d0) * P.tstride + (m - mlo)] = (uint8_t) trb;
-#else
-            if (trb == 12345) P.trace[0] = 1;
-#endif
+            p_tri = (size_t) (d - P.d0) * P.tstride + (m - mlo);
+            p_trb = trb;
             sim_cur = sim_nx; bc_cur = bc_nx; have = (n + 1 < hi);
             // block boundary: this row's corner and F records for the block on the right
             if (n == c1 - 1 && c1 < b.right) {
@@ -629,37 +822,12 @@ __device__ void v3_tile(const DevProb &P, lchar *lds, const V3Lds LO, const int 
             }
             if (m == a.right - 1 && n == b.right - 1) *P.score = myH.val;
         }
-        team_sync();
-        // -- strip boundary: the last row's new corner goes to HBM for the strip below, one dword per lane
-#ifndef G2G_EXP_NOWR
-        if (wr_rows) {
-            const int nl = n0 - llast;                     // the last row's column in this step
-            int lhi = m0 + llast + P.up + 1; if (lhi > b.right) lhi = b.right; if (lhi > c1) lhi = c1;
-            int llo = m0 + llast + P.lw; if (llo < b.left) llo = b.left; if (llo < c0) llo = c0;
-            if (nl >= llo && nl < lhi) {
-                const int col = nl + 1;
-                const int j = lane - 4;
-#pragma unroll
-                for (int x = 0; x < (NOLL3 ? 3 : 2); ++x) {
-                    const RS &r = (x == 0) ? myH : (x == 1) ? myG : myG2;
-                    const int slot = (x == 0) ? SLOT_H(col) : (x == 1) ? SLOT_G(col) : SLOT_G2(col);
-                    const unsigned v0 = (unsigned) __shfl(__double2loint(r.val), llast), v1 = (unsigned) __shfl(__double2hiint(r.val), llast);
-                    const unsigned v2 = (unsigned) __shfl(r.dir, llast), v3 = (unsigned) __shfl(r.glb, llast);
-                    unsigned v = lane == 0 ? v0 : lane == 1 ? v1 : lane == 2 ? v2 : v3;
-                    if (lane >= 4 && lane < ndw) {
-                        const lu32 *p = V3_L(llast + 1, slot);
-                        v = (j < capa) ? p[j] : (j < capa + capb) ? p[ca4 + j - capa] : 0;
-                    }
-                    unsigned *dst = (x == 0) ? rowHc : (x == 1) ? rowGc : rowG2c;
-                    if (lane < ndw) dst[(size_t) col * ndw + lane] = v;
-                }
-            }
-        }
-#endif
+        p_act = active;
         oH = myH; oG = myG; oG2 = myG2;
-        if (st_on) stage_store(n0 + 2, vert0, st_h, st_g, st_g2);
         team_sync();
     }
+    if (p_act) P.trace[p_tri] = (uint8_t) p_trb;
+    if (wr_rows) flush_rows(cbase + nsteps - 1 - llast);
 #undef V3_L
 }
 
@@ -703,3 +871,5 @@ V3_KERNEL(g2g_v3_pf2, 2, false, 0, 2)
 V3_KERNEL(g2g_v3_pf3, 2, true, 0, 2)
 V3_KERNEL(g2g_v3r_hf2, 1, false, G2G_V3_NA, G2G_V3R_WPE)
 V3_KERNEL(g2g_v3r_hf3, 1, true, G2G_V3_NA, 1)
+V3_KERNEL(g2g_v3r_pf2, 2, false, G2G_V3_NA, 1)
+V3_KERNEL(g2g_v3r_pf3, 2, true, G2G_V3_NA, 1)
