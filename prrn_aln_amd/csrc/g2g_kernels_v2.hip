@@ -903,10 +903,10 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         if (t >= ntiles) break;                                                                     \
         const V2Tile T = tiles[t];                                                                  \
         V2_WAIT_T0                                                                                  \
-        if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 12, t);                         \
-        if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 12, t);                     \
-        if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 12, t);                     \
-        if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 12, t);                       \
+        if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t);                         \
+        if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t);                     \
+        if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t);                     \
+        if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t);                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                          \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \

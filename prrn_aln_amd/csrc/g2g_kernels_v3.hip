@@ -51,6 +51,43 @@ G2G_HD inline int v3_pitch(int nslot, int lsz)            // dwords per LDS row:
 }
 
 
+
+// ---- branch-free list-head lookups ---------------------------------------------------------------------
+// A dynamic list {glen,nins} is ascending in glen and ends with the terminator glen = 0xFFFF; what follows the
+// terminator in memory is stale.  dhs_load() reads the four leading entries and overwrites everything behind the
+// terminator by terminators ("sanitised" head): a lookup is then three independent unsigned compares of the
+// packed key (g << 16 | 0xFFFF) against the packed entries -- no && chain (scalar mask logic), no branch per
+// lookup.  Lists with more than three entries below g fall back to a scan of LDS behind ONE wave-uniform test.
+__device__ __forceinline__ DHead dhs_load(const lu32 *p)
+{
+    const v4u32 v = *(const LDS v4u32 *) p;
+    const unsigned T = DL_END << 16;
+    DHead h;
+    h.e0 = v.x;
+    h.e1 = (v.x >= T) ? T : v.y;
+    h.e2 = (h.e1 >= T) ? T : v.z;
+    h.e3 = (h.e2 >= T) ? T : v.w;
+    h.p = p;
+    return h;
+}
+__device__ __forceinline__ int dhs_nins(const int g, const DHead &h)
+{
+    const unsigned key = ((unsigned) (g < 0 ? 0 : g) << 16) | 0xFFFFu;
+    unsigned e = h.e0;
+    e = key >= h.e1 ? h.e1 : e;
+    e = key >= h.e2 ? h.e2 : e;
+    const bool more = key >= h.e3;                          // (a terminator in e3 never compares below the key)
+    e = more ? h.e3 : e;
+    if (__ballot(more)) {                                   // rare: more than three entries below g
+        if (more) {
+            int k = 3;
+            while (key >= ((h.p[k + 1] & 0xFFFF0000u) ) && k < DL_GUARD) ++k;
+            e = h.p[k];
+        }
+    }
+    return (int) (e & 0xFFFFu);
+}
+
 #ifndef G2G_V3_HF_UNROLL
 #define G2G_V3_HF_UNROLL 16               // _hf merge loops fully unrolled (faster than s_set_gpr_idx indexing); _pf loops stay rolled (code size)
 #endif
@@ -396,8 +433,20 @@ __device__ __forceinline__ BHead bh_load(const LList l)
     h.f0 = l.freq[0]; h.f1 = l.freq[1]; h.f2 = l.freq[2]; h.f3 = l.freq[3];
     h.l = l; return h;
 }
-__device__ __forceinline__ int bh_glen(const BHead &h, const int i) { return i == 0 ? h.g0 : i == 1 ? h.g1 : i == 2 ? h.g2 : i == 3 ? h.g3 : h.l.glen[i]; }
-__device__ __forceinline__ double bh_freq(const BHead &h, const int i) { return i == 0 ? h.f0 : i == 1 ? h.f1 : i == 2 ? h.f2 : i == 3 ? h.f3 : h.l.freq[i]; }
+// entry i: selects over the cached four; beyond that one LDS read behind a wave-uniform test (a conditional load
+// inside the select chain would be compiled into a tree of divergent branches)
+__device__ __forceinline__ int bh_glen(const BHead &h, const int i)
+{
+    int g = i == 0 ? h.g0 : i == 1 ? h.g1 : i == 2 ? h.g2 : h.g3;
+    if (__ballot(i > 3)) { const int t = h.l.glen[i > 3 ? i : 0]; g = i > 3 ? t : g; }
+    return g;
+}
+__device__ __forceinline__ double bh_freq(const BHead &h, const int i)
+{
+    double f = i == 0 ? h.f0 : i == 1 ? h.f1 : i == 2 ? h.f2 : h.f3;
+    if (__ballot(i > 3)) { const double t = h.l.freq[i > 3 ? i : 0]; f = i > 3 ? t : f; }
+    return f;
+}
 // cf = a's list (outer, registers), df = b's list (inner): newgap4(a.s, dla, b.t|b.r, dlb)
 struct MY { int di, dg, j; bool live; double g; };
 __device__ __forceinline__ void my_init(MY &s, const bool on, const BHead &df, const DHead &dd)
@@ -844,10 +893,10 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         __syncthreads();                                                                            \
         if (t >= ntiles) break;                                                                     \
         const V2Tile T = tiles[t];                                                                  \
-        if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 12, t);                         \
-        if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 12, t);                     \
-        if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 12, t);                     \
-        if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 12, t);                       \
+        if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t);                         \
+        if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t);                     \
+        if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t);                     \
+        if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t);                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                          \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
