@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--limit", type=int, default=0, help="use only the first LIMIT divisions (debug)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="rehearsal on ONE GPU: run only rank 0's share of an N-rank job (prints a line marked rehearsal)")
     args = ap.parse_args()
 
     import numpy as np
@@ -116,7 +118,7 @@ def main():
     fam = make_family(args.nseq, args.length, args.seed)
     alp = op.AlnParam()
     sw = sweep.Sweep(fam, alp, weighted=True, limit=args.limit or None)
-    mine = sweep.shard(sw.order, world, rank)
+    mine = sweep.shard(sw.order, args.shard_of, 0) if args.shard_of > 1 and world == 1 else sweep.shard(sw.order, world, rank)
     ctx = engine.Context(local_rank)
     holders = [sw.pwds[k] for k in mine]
 
@@ -191,6 +193,9 @@ def main():
                          "kernel": "g2g_v2_hf2 + g2g_v2_pf2 (persistent tile kernels, concurrent) incl. g2g_v2_prologue_kernel and g2g_v2_sim_kernel", "kernel_ms": fwd_avg_ms, "traceback_ms": tb_ms / args.steps,
                          "bytes_per_cell": BYTES_PER_CELL[noll], "cells_per_launch": my_cells},
         }
+        if args.shard_of > 1 and world == 1:
+            line["rehearsal"] = "rank 0's share of a %d-rank job on one GPU: %d divisions, %.4g cells, %.1f ms per step" % (
+                args.shard_of, len(mine), my_cells, ms_per_step)
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(sw, args.cpu_seconds)
             if line["cpu_baseline"]["value"]:

@@ -116,6 +116,7 @@ struct g2g_batch {
     V3Lds v3lds[8];                 // LDS plan of the v3 variants
     V4Lds v4lds[2];                 // LDS plan of the v4 (_pf, 8 lanes per cell) variants
     int v4_cols;
+    int v2_cols;
     int v3_cols;                    // columns per v3 tile
     int *d_flags;                   // [0..15] queue heads, [16..19] incident report, [20..] tile-completion flags (generation numbers)
     int nflags, gen;
@@ -294,10 +295,8 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     HIPCHK(hipSetDevice(ctx->device));
     g2g_batch *b = new g2g_batch();
     b->ctx = ctx; b->n = n; b->d_arena = 0; b->d_probs = 0; b->fwd_ms = b->tb_ms = 0;
-    b->v3_cols = 128;
-    b->v4_cols = 64;
-    if (const char *e = getenv("G2G_V4_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v4_cols = c; }
-    if (const char *e = getenv("G2G_V3_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v3_cols = c; }
+    b->v3_cols = 128; b->v4_cols = 64; b->v2_cols = G2G_V2_TILE_COLS;
+
     b->dp.resize(n); b->status.assign(n, G2G_OK); b->cells.assign(n, 0); b->out_off.assign(n, 0); b->tcap.assign(n, 0); b->rr1.assign(n, 0);
     Blob bl;
     size_t probs_off = bl.put(0, 0);
@@ -319,6 +318,33 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         if (p->simmtx) d.simmtx = OFF<const double>(bl.put(p->simmtx, sizeof(double) * (size_t) p->simdim * p->simrows));
         pack_side(bl, p->a, d.a, d.kind, d.kind == 1 || d.kind == 2);
         pack_side(bl, p->b, d.b, d.kind, d.kind == 2);
+    }
+    // Tile widths.  Tiles of one DP run as a wavefront, at most min(strips, blocks) of them at a time: a sweep with
+    // hundreds of DPs fills the GPU with wide tiles (few block-boundary records, short fill/drain share), a rank
+    // that holds few DPs (the 8-GPU shard) needs narrow ones or its waves sit idle behind the dependencies.
+    {
+        int ncu = 256;
+        { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) ncu = pr.multiProcessorCount; }
+        auto pick = [&](int kind, int R, int cmax, int cmin, int slots) {
+            int C = cmax;
+            for (; C > cmin; C /= 2) {
+                long long par = 0;
+                for (int i = 0; i < n; ++i) {
+                    const DevProb &d = b->dp[i];
+                    if (d.kind != kind) continue;
+                    const int ns = (d.a.right - d.a.left + R - 1) / R, nb = (d.b.right - d.b.left + C - 1) / C;
+                    par += std::min(ns, nb);
+                }
+                if (4 * par >= 5 * (long long) slots) break;
+            }
+            return C;
+        };
+        b->v3_cols = pick(1, 64, 128, 32, ncu * 4);
+        b->v2_cols = pick(2, G2G_V2_THREADS / 8, G2G_V2_TILE_COLS, 64, ncu * 3);
+        b->v4_cols = 64;
+        if (const char *e = getenv("G2G_V2_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v2_cols = c; }
+        if (const char *e = getenv("G2G_V3_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v3_cols = c; }
+        if (const char *e = getenv("G2G_V4_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v4_cols = c; }
     }
     // index lists for the two forward kernels (filled below, once eligibility is known)
     const size_t idx_off = bl.put(0, 0);
@@ -419,7 +445,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         b->d_idx1 = (int *) (b->d_arena + idx_off);
         b->d_idx2 = b->d_idx1 + (n > 0 ? n : 1);
     }
-    // v2 tiles: (strip i of R rows) x (block j of G2G_V2_TILE_COLS columns); per kernel variant one queue
+    // v2 tiles: (strip i of R rows) x (block j of C columns, C chosen per batch); per kernel variant one queue
     // ordered by wavefront i + j; one completion flag per tile slot (empty slots count as done for ever)
     b->d_tiles = 0; b->ntiles = 0; b->lds2p = 0; b->v2_maxrows = 1; b->d_flags = 0; b->nflags = 0; b->gen = 0;
     {
@@ -436,7 +462,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             b->v2_maxrows = std::max(b->v2_maxrows, d.a.right - d.a.left);
             const int al = d.a.left, ar = d.a.right, bl_ = d.b.left, br = d.b.right;
             const int R = d.v2_ok == 4 ? V4_R : d.v2_ok >= 2 ? 64 : G2G_V2_THREADS / 8;
-            const int C = d.v2_ok == 4 ? b->v4_cols : d.v2_ok >= 2 ? b->v3_cols : G2G_V2_TILE_COLS;
+            const int C = d.v2_ok == 4 ? b->v4_cols : d.v2_ok >= 2 ? b->v3_cols : b->v2_cols;
             const int nstrip = (ar - al + R - 1) / R, nblk = (br - bl_ + C - 1) / C;
             const int var = d.v2_ok == 4 ? 12 + (d.noll == 3 ? 1 : 0) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
             if (d.v2_ok == 4) {
@@ -526,7 +552,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         HIPCHK(hipGetLastError());
         if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[g2g] prologue+sim done: %s\n", hipGetErrorString(e3)); fflush(stderr); }
         // one launch per tile wavefront: stream order is the dependency between wavefronts
-        typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int);
+        typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int, int);
         static const v2k_t v2k[4] = {g2g_v2_hf2, g2g_v2_hf3, g2g_v2_pf2, g2g_v2_pf3};
         typedef void (*v3k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V3Lds, int);
         static const v3k_t v3k[8] = {g2g_v3_hf2, g2g_v3_hf3, g2g_v3_pf2, g2g_v3_pf3, g2g_v3r_hf2, g2g_v3r_hf3, g2g_v3r_pf2, g2g_v3r_pf3};
@@ -544,7 +570,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] variant %d: %d tiles, grid %d, lds %zu, gen %d\n", v, cnt, grid, b->lds2, b->gen); fflush(stderr); }
             hipLaunchKernelGGL(v2k[v], dim3(grid), dim3(G2G_V2_THREADS), b->lds2 + 4 * G2G_V2_THREADS, ctx->vstream[v],
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v]), cnt,
-                               b->d_flags + v, b->d_flags, b->gen, (int) b->lds2);
+                               b->d_flags + v, b->d_flags, b->gen, (int) b->lds2, b->v2_cols);
             HIPCHK(hipGetLastError());
             if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->vstream[v]); fprintf(stderr, "[g2g] variant %d done: %s\n", v, hipGetErrorString(e3)); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[v], ctx->vstream[v]));

@@ -560,7 +560,7 @@ __device__ __forceinline__ void uni_prob(DevProb &d, const DevProb &s)
     d.score = uni(s.score);
 }
 
-// ---- one TILE = (strip of R rows) x (block of G2G_V2_TILE_COLS columns) by one workgroup ------------
+// ---- one TILE = (strip of R rows) x (block of C columns) by one workgroup ------------
 // Tiles of a DP depend on their upper, left and upper-left neighbours only, so all tiles with the same
 // i + j (over every DP of the batch) run in one launch; a big DP is spread over many workgroups instead
 // of bounding the sweep time.  What crosses tile borders lives in HBM:
@@ -571,7 +571,7 @@ __device__ __forceinline__ void uni_prob(DevProb &d, const DevProb &s)
 //   cbH/cbF/cbF2[row]        each row's H corner and F records at the block's right edge
 //   colH[row]                the left boundary chain
 template <int KIND, bool NOLL3>
-__device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nsteps)
+__device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nsteps, const int C)
 {
     DevProb P;
     uni_prob(P, Pmem);
@@ -603,8 +603,8 @@ __device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nst
     const int m_left_last = b.left - rrl;                  // last row whose corner (m, b.left) exists
     const LRec black = G.extra(EX_BLACK);
     const int m0 = a.left + ti * R, m = m0 + team;
-    const int c0 = b.left + tj * G2G_V2_TILE_COLS;
-    int c1 = c0 + G2G_V2_TILE_COLS; if (c1 > b.right) c1 = b.right;
+    const int c0 = b.left + tj * C;
+    int c1 = c0 + C; if (c1 > b.right) c1 = b.right;
     const bool row_ok = m < a.right;
     int nlo = m + P.lw; if (nlo < b.left) nlo = b.left;    // the row's range, fwd2c.h:373-374
     int nhi = m + P.up + 1; if (nhi > b.right) nhi = b.right;
@@ -891,7 +891,7 @@ __device__ unsigned long long g2g_wait_acc[4];
 // each thread adds (tid == 0) to the queue head, parks its result in LDS, and slot 0 is the tile.
 #define V2_KERNEL(NAME, KIND, N3)                                                                   \
 extern "C" __global__ void __launch_bounds__(G2G_V2_THREADS, G2G_V2_MINWAVES)                         \
-NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, int lds_tile_off) \
+NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, int lds_tile_off, int C) \
 {                                                                                                   \
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];                                  \
     li32 *s_vals = (li32 *) ((lchar *) g2g_lds + lds_tile_off);   /* tail of the dynamic LDS */      \
@@ -911,7 +911,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
         V2_WAIT_T1                                                                                  \
-        v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, T.tj, T.nsteps);                  \
+        v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, T.tj, T.nsteps, C);               \
         V2_WAIT_T2                                                                                  \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
