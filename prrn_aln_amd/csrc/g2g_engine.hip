@@ -544,12 +544,21 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_pf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * G2G_V2_THREADS));
             HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_pf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * G2G_V2_THREADS));
         }
-        hipLaunchKernelGGL(g2g_v2_prologue_kernel, dim3(b->n2), dim3(192), b->lds2p, ctx->stream,
+        // row offsets first (tiny), then the boundary chains (single-lane, latency-bound) on a side stream while the
+        // score kernel (fully parallel) fills the GPU on the main one
+        hipLaunchKernelGGL(g2g_v2_rowoff_kernel, dim3((b->n2 + 63) / 64), dim3(64), 0, ctx->stream,
+                           (const DevProb *) b->d_probs, (const int *) b->d_idx2, b->n2);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->vev[4], ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->vstream[3], ctx->vev[4], 0));
+        hipLaunchKernelGGL(g2g_v2_prologue_kernel, dim3(b->n2), dim3(128), b->lds2p, ctx->vstream[3],
                            (const DevProb *) b->d_probs, (const int *) b->d_idx2);
         HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->vev[3], ctx->vstream[3]));
         hipLaunchKernelGGL(g2g_v2_sim_kernel, dim3(b->v2_maxrows, b->n2), dim3(256), 0, ctx->stream,
                            (const DevProb *) b->d_probs, (const int *) b->d_idx2);
         HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[3], 0));
         if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[g2g] prologue+sim done: %s\n", hipGetErrorString(e3)); fflush(stderr); }
         // one launch per tile wavefront: stream order is the dependency between wavefronts
         typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int, int);
@@ -626,7 +635,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-    hipLaunchKernelGGL(g2g_traceback_kernel, dim3((b->n + 63) / 64), dim3(64), 0, ctx->stream, (const DevProb *) b->d_probs, b->n);
+    hipLaunchKernelGGL(g2g_traceback_kernel, dim3(b->n), dim3(64), 0, ctx->stream, (const DevProb *) b->d_probs, b->n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

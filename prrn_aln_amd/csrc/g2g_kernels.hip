@@ -597,43 +597,82 @@ __device__ __forceinline__ uint8_t trace_at(const DevProb &P, int m, int n)
     return P.trace[(size_t)(d - P.d0) * P.tstride + (m - mlo)];
 }
 
-extern "C" __global__ void g2g_traceback_kernel(const DevProb *probs, int nprob)
+// Backtrack: ONE WAVE per DP.  The walk itself is a dependent chain (each trace byte decides which byte is read
+// next), so what matters is the latency per step: the wave keeps a window of the trace in LDS -- 64 anti-diagonals
+// below the current cell x 64 rows around the expected path -- filled by all 64 lanes at once (lane L copies its
+// diagonal's segment), and lane 0 walks inside it until the path leaves the window.  (One lane per DP with 64 DPs
+// in a wave took 30 ms per sweep: every step was an HBM/L2 round trip, serialised over divergent lanes.)
+#define TB_W 64
+extern "C" __global__ void __launch_bounds__(64) g2g_traceback_kernel(const DevProb *probs, int nprob)
 {
-    const int ip = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint8_t win[TB_W][TB_W + 4];
+    __shared__ int wbase[TB_W];
+    const int ip = blockIdx.x;
     if (ip >= nprob) return;
     const DevProb &P = probs[ip];
     if (P.kind < 0) return;
-    const DevSide &a = P.a, &b = P.b;
-    int cnt = 0;
-    int rr0 = b.left - a.left, rr0_set = 0;            // forwardB without Vmf: ptr = start diagonal
+    const int lane = threadIdx.x;
+    const int al = P.a.left, ar = P.a.right, bl = P.b.left, br = P.b.right, lw = P.lw, up = P.up;
+    const int d0 = P.d0, tstride = P.tstride;
+    const uint8_t *trace = P.trace;
     int2 *out = P.otrace;
-    out[cnt++] = make_int2(a.right, b.right);           // fwd2c.h:476
-    int m = a.right - 1, n = b.right - 1;
-    const int guard = 4 * (a.right - a.left + b.right - b.left) + 16;
-    for (int it = 0; it < guard; ++it) {
-        if (m < a.left || n < b.left) break;            // reached an initB boundary corner: ptr = origin
-        const uint8_t t = trace_at(P, m, n);
-        const int dc = t & T_DIRMASK;
-        if (m == a.left && !rr0_set) { rr0 = n - m; rr0_set = 1; }   // `else if (m == a->left) h->ptr = n - m`
-        if ((dc == 2 || dc == 4 || dc == 6) && cnt < P.tcap - 1) out[cnt++] = make_int2(m, n);
-        if (dc == 1 || dc == 2) { --m; --n; }
-        else if (dc == 3 || dc == 4) {                  // H copied G or G2: walk the vertical run
-            const int ext = (t & T_SEL2) ? T_G2EXT : T_GEXT;
-            for (;;) {
-                const uint8_t u = trace_at(P, m, n);
-                --m;
-                if (!(u & ext) || m < a.left) break;
+    const int tcap = P.tcap;
+    // walker state (meaningful in lane 0, broadcast at every window change)
+    int m = ar - 1, n = br - 1, cnt = 0, state = 0, ext = 0, fin = 0;
+    int rr0 = bl - al, rr0_set = 0;
+    if (lane == 0) out[cnt++] = make_int2(ar, br);       // fwd2c.h:476
+    int budget = 4 * (ar - al + br - bl) + 16;
+    while (!fin) {
+        // ---- window: diagonals dtop, dtop-1, ..., dtop-63; rows around m - L/2 (a diagonal move changes d by 2) ----
+        const int dtop = m + n;
+        {
+            const int d = dtop - lane;
+            const int mb = m - (lane + 1) / 2 - TB_W / 2 + 4;
+            wbase[lane] = mb;
+            if (d >= d0) {
+                int mlo, mhi;
+                diag_rows(d, al, ar, bl, br, lw, up, &mlo, &mhi);
+                const uint8_t *src = trace + (size_t) (d - d0) * tstride;
+                for (int j = 0; j < TB_W; ++j) {
+                    const int mm = mb + j;
+                    win[lane][j] = (mm >= mlo && mm <= mhi) ? src[mm - mlo] : (uint8_t) 0;
+                }
             }
-        } else if (dc == 5 || dc == 6) {
-            const int ext = (t & T_SEL2) ? T_F2EXT : T_FEXT;
+        }
+        __syncthreads();
+        if (lane == 0) {
             for (;;) {
-                const uint8_t u = trace_at(P, m, n);
-                --n;
-                if (!(u & ext) || n < b.left) break;
+                if (--budget < 0) { fin = 1; break; }
+                if (state == 0 && (m < al || n < bl)) { fin = 1; break; }      // reached an initB boundary corner
+                const int L = dtop - (m + n);
+                if (L >= TB_W) break;
+                const int j = m - wbase[L];
+                if (j < 0 || j >= TB_W) break;
+                const uint8_t t = win[L][j];
+                if (state == 0) {
+                    const int dc = t & T_DIRMASK;
+                    if (m == al && !rr0_set) { rr0 = n - m; rr0_set = 1; }     // `else if (m == a->left) h->ptr = n - m`
+                    if ((dc == 2 || dc == 4 || dc == 6) && cnt < tcap - 1) out[cnt++] = make_int2(m, n);
+                    if (dc == 1 || dc == 2) { --m; --n; }
+                    else if (dc == 3 || dc == 4) { ext = (t & T_SEL2) ? T_G2EXT : T_GEXT; state = 1; }   // H copied G or G2
+                    else if (dc == 5 || dc == 6) { ext = (t & T_SEL2) ? T_F2EXT : T_FEXT; state = 2; }
+                    else { fin = 1; break; }                                   // never written: corrupt
+                }
+                if (state == 1) {                                              // walk the vertical run
+                    --m;
+                    if (!(t & ext) || m < al) state = 0;
+                } else if (state == 2) {
+                    --n;
+                    if (!(t & ext) || n < bl) state = 0;
+                }
             }
-        } else break;                                   // never written: corrupt
+        }
+        __syncthreads();
+        m = __shfl(m, 0); n = __shfl(n, 0); fin = __shfl(fin, 0);
     }
-    out[cnt++] = make_int2(a.left, b.left);             // origin record, fwd2c.h:144
-    *P.ntrace = cnt;
-    P.ntrace[1] = rr0;
+    if (lane == 0) {
+        out[cnt++] = make_int2(al, bl);                   // origin record, fwd2c.h:144
+        *P.ntrace = cnt;
+        P.ntrace[1] = rr0;
+    }
 }

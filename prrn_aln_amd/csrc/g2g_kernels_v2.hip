@@ -808,7 +808,8 @@ __device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nst
 #endif
 }
 
-// boundary chains of every DP: one small workgroup each (wave 0: top row, wave 1: left column)
+// boundary chains of every DP: one small workgroup each (wave 0: top row, wave 1: left column); they are
+// latency-bound single-lane chains and run on their own stream beside the (fully parallel) score kernel
 template <int KIND>
 __device__ void v2_prologue(const DevProb &P, lchar *lds)
 {
@@ -819,19 +820,26 @@ __device__ void v2_prologue(const DevProb &P, lchar *lds)
     unsigned *rowH2 = (unsigned *) P.v2_rowH + 2 * (size_t) P.v2_rowstride * G.ndw;
     if (threadIdx.x == 0) v2_chain_top<KIND>(P, G, G.row(0, 0), G.row(1, 0), rowH2);
     if (threadIdx.x == 64) v2_chain_left<KIND>(P, G, G.row(2, 0), G.row(3, 0), (unsigned *) P.v2_colH);
-    if (threadIdx.x == 128) {                               // row offsets of the column-score matrix
-        long long o = 0;
-        for (int m = P.a.left; m < P.a.right; ++m) {
-            int nlo = m + P.lw; if (nlo < P.b.left) nlo = P.b.left;
-            int nhi = m + P.up + 1; if (nhi > P.b.right) nhi = P.b.right;
-            P.v2_rowoff[m - P.a.left] = o;
-            if (nhi > nlo) o += nhi - nlo;
-        }
-        P.v2_rowoff[P.a.right - P.a.left] = o;
-    }
 }
 
-extern "C" __global__ void __launch_bounds__(192)
+// row offsets of the column-score matrix (needed by the score kernel, which then runs beside the chains)
+extern "C" __global__ void __launch_bounds__(64)
+g2g_v2_rowoff_kernel(const DevProb *probs, const int *idx, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevProb &P = probs[idx[i]];
+    long long o = 0;
+    for (int m = P.a.left; m < P.a.right; ++m) {
+        int nlo = m + P.lw; if (nlo < P.b.left) nlo = P.b.left;
+        int nhi = m + P.up + 1; if (nhi > P.b.right) nhi = P.b.right;
+        P.v2_rowoff[m - P.a.left] = o;
+        if (nhi > nlo) o += nhi - nlo;
+    }
+    P.v2_rowoff[P.a.right - P.a.left] = o;
+}
+
+extern "C" __global__ void __launch_bounds__(128)
 g2g_v2_prologue_kernel(const DevProb *probs, const int *idx)
 {
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];
