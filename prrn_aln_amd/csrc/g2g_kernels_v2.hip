@@ -94,10 +94,14 @@ __device__ __forceinline__ SHead<CL> sh_load(const CL l)
 {
     SHead<CL> h; h.g0 = l.glen[0]; h.g1 = l.glen[1]; h.g2 = l.glen[2]; h.g3 = l.glen[3]; h.l = l; return h;
 }
+// (the load behind index 3 sits behind a wave-uniform test: a conditional load inside the select chain is compiled
+// into a tree of divergent branches)
 template <class CL>
 __device__ __forceinline__ int sh_glen(const SHead<CL> &h, int i)
 {
-    return i == 0 ? h.g0 : i == 1 ? h.g1 : i == 2 ? h.g2 : i == 3 ? h.g3 : h.l.glen[i];
+    int g = i == 0 ? h.g0 : i == 1 ? h.g1 : i == 2 ? h.g2 : h.g3;
+    if (__ballot(i > 3)) { const int t = h.l.glen[i > 3 ? i : 0]; g = i > 3 ? t : g; }
+    return g;
 }
 
 // GapLenSD, gfreq.h:67, on a packed list (plain form, used by the boundary chains' helpers)
@@ -348,8 +352,8 @@ struct CellSrc { LRec hd, hu, gu, g2u, hl, fl, f2l; };   // records the cell rea
 struct CellDst { LRec h, g, g2, f, f2; };                 // records it writes
 
 template <int KIND, bool NOLL3>
-__device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList> &L, int m, int n, int lane,
-                        const CellSrc &S, const CellDst &D, bool do_vert, bool do_hori, uint8_t *tr,
+__device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList> &L_, int m, int n, int lane,
+                        const CellSrc &S_, const CellDst &D_, bool do_vert, bool do_hori, uint8_t *tr,
                         double dab, double pua, double pub
 #ifdef G2G_V2_STAMP
                         , unsigned long long *stamp_acc, unsigned long long &stamp_t
@@ -358,6 +362,11 @@ __device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList
 {
     const DevSide &a = P.a, &b = P.b;
     const int capa = G.capa;
+    // private VALUE copies: the per-lane operand selects below pick among these; selecting among members of a struct
+    // that lives behind a reference keeps the whole struct in scratch memory (it was: 378 GB of scratch writes per sweep)
+    CellLists<LList> L; L.as = L_.as; L.at = L_.at; L.ar = L_.ar; L.bs = L_.bs; L.bt = L_.bt; L.br = L_.br;
+    CellSrc S; S.hd = S_.hd; S.hu = S_.hu; S.gu = S_.gu; S.g2u = S_.g2u; S.hl = S_.hl; S.fl = S_.fl; S.f2l = S_.f2l;
+    CellDst D; D.h = D_.h; D.g = D_.g; D.g2 = D_.g2; D.f = D_.f; D.f2 = D_.f2;
     // ---- phase A: one independent cost per lane.  Lanes of a wave that take different branches are
     // serialised, so the jobs are expressed as ONE call with per-lane operands (select, then call):
     //   lane 0/1 diagonal (two merges for _pf), 2 vertical from G, 3 vertical from H, 4 horizontal from F,
@@ -634,9 +643,16 @@ __device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nst
         L.ar.glen = ag + 2 * mla; L.ar.freq = af + 2 * mla;
         L.bs = L.bt = L.br = L.as;
     }
+    // the view (s/t/r) of b this thread prefetches: chosen once with selects (a runtime index into the descriptor copy
+    // would force the copy into scratch memory)
+    const int pf_view = tid / TEAM;
+    const int *const pf_off = pf_view == 0 ? b.off[0] : pf_view == 1 ? b.off[1] : b.off[2];
+    const int *const pf_glen = pf_view == 0 ? b.glen[0] : pf_view == 1 ? b.glen[1] : b.glen[2];
+    const double *const pf_freq = pf_view == 0 ? b.freq[0] : pf_view == 1 ? b.freq[1] : b.freq[2];
     if (KIND == 2 && tid < 3 * TEAM) {                     // column ring: column cbase for step 0
         const int v = tid / TEAM;
-        list_g2l(bglen + (size_t) v * mlb, bfreq + (size_t) v * mlb, b, v, cbase, lane, TEAM);
+        const int o = pf_off[cbase + 1], e = pf_off[cbase + 2];
+        for (int k = lane; k < e - o; k += TEAM) { bglen[(size_t) v * mlb + k] = pf_glen[o + k]; bfreq[(size_t) v * mlb + k] = pf_freq[o + k]; }
     }
     // per-row constants and one-step-ahead register pipelines (column score, b's column thickness,
     // and -- for the strip's first row -- the upper neighbours' records): nothing that comes from HBM is
@@ -670,13 +686,13 @@ __device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nst
         const bool pf_on = KIND == 2 && tid < 3 * TEAM && cbase + s + 1 < c1;
         if (pf_on) {
             const int v = tid / TEAM, pos = cbase + s + 1;
-            const int o = b.off[v][pos + 1];
-            pf_n = b.off[v][pos + 2] - o;
+            const int o = pf_off[pos + 1];
+            pf_n = pf_off[pos + 2] - o;
             pf_base = (wslot * 3 + v) * mlb;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = lane + j * TEAM;
-                if (k < pf_n) { pf_g[j] = b.glen[v][o + k]; pf_f[j] = b.freq[v][o + k]; }
+                if (k < pf_n) { pf_g[j] = pf_glen[o + k]; pf_f[j] = pf_freq[o + k]; }
             }
         }
         if (active) {
@@ -794,8 +810,8 @@ __device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nst
                 if (k < pf_n) { bglen[pf_base + k] = pf_g[j]; bfreq[pf_base + k] = pf_f[j]; }
             }
             if (pf_n > 4 * TEAM) {                          // (lists longer than 32 entries: straight copy)
-                const int v = tid / TEAM, pos = cbase + s + 1, o = b.off[v][pos + 1];
-                for (int k = lane + 4 * TEAM; k < pf_n; k += TEAM) { bglen[pf_base + k] = b.glen[v][o + k]; bfreq[pf_base + k] = b.freq[v][o + k]; }
+                const int pos = cbase + s + 1, o = pf_off[pos + 1];
+                for (int k = lane + 4 * TEAM; k < pf_n; k += TEAM) { bglen[pf_base + k] = pf_glen[o + k]; bfreq[pf_base + k] = pf_freq[o + k]; }
             }
         }
         if (++rslot == RC) rslot = 0;
