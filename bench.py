@@ -190,7 +190,7 @@ def main():
                        "failed_items": bad},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "g2g_v2_hf2 + g2g_v2_pf2 (persistent tile kernels, concurrent) incl. g2g_v2_prologue_kernel and g2g_v2_sim_kernel", "kernel_ms": fwd_avg_ms, "traceback_ms": tb_ms / args.steps,
+                         "kernel": "g2g_v3r_hf2 + g2g_v2_pf2 (persistent tile kernels, concurrent) incl. g2g_v2_rowoff/prologue/sim kernels", "kernel_ms": fwd_avg_ms, "traceback_ms": tb_ms / args.steps,
                          "bytes_per_cell": BYTES_PER_CELL[noll], "cells_per_launch": my_cells},
         }
         if args.shard_of > 1 and world == 1:
