@@ -28,8 +28,10 @@ BYTES_PER_CELL = {2: 33, 3: 49}          # 2*Noll*sizeof(double) + 1 direction b
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(sw, budget_s):
-    """Reference (or port) CPU path on a bounded sample, 1 core.  Returns dict for the JSON line."""
+def cpu_baseline(sw, budget_s, gpu_scores=None):
+    """Reference (or port) CPU path on a bounded sample, 1 core.  Returns dict for the JSON line.  When the GPU scores
+    of this rank's divisions are given, the sampled divisions are also compared score by score (the second half of
+    the metric: score delta vs the reference)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     order = list(sw.order)
@@ -38,6 +40,7 @@ def cpu_baseline(sw, budget_s):
     cells = 0
     secs = 0.0
     used = []
+    ref_scr = {}
     try:
         import refdump
         if not refdump.available():
@@ -56,7 +59,7 @@ def cpu_baseline(sw, budget_s):
             gb = R.group(["b%d" % i for i in ib], rows(b), wb)
             sec, c, mode, scr = R.forward_timed(ga, gb)
             R.free(ga); R.free(gb)
-            cells += c; secs += sec; used.append(int(k))
+            cells += c; secs += sec; used.append(int(k)); ref_scr[int(k)] = scr
             if secs > budget_s:
                 break
     except Exception as e:            # no reference build on this box: time the C restatement instead
@@ -73,12 +76,17 @@ def cpu_baseline(sw, budget_s):
             L.g2g_oracle_forward(C.byref(q), C.byref(res))
             secs += time.perf_counter() - t
             L.g2g_oracle_free(res.trace)
-            cells += res.cells; used.append(int(k))
+            cells += res.cells; used.append(int(k)); ref_scr[int(k)] = res.score
             if secs > budget_s:
                 break
-    return {"value": cells / secs if secs else 0.0, "unit": "cells/s", "cores": 1, "kind": kind,
-            "sample": "%d of %d divisions spread over the size range (%.3g cells, %.1f s): forward fill + traceback only"
-                      % (len(used), len(sw), cells, secs)}
+    out = {"value": cells / secs if secs else 0.0, "unit": "cells/s", "cores": 1, "kind": kind,
+           "sample": "%d of %d divisions spread over the size range (%.3g cells, %.1f s): forward fill + traceback only"
+                     % (len(used), len(sw), cells, secs)}
+    if gpu_scores is not None:
+        both = [k for k in used if k in gpu_scores]
+        out["score_delta_vs_ref"] = {"divisions_compared": len(both),
+                                     "max_abs_delta": max([abs(gpu_scores[k] - ref_scr[k]) for k in both] or [0.0])}
+    return out
 
 
 def main():
@@ -197,7 +205,7 @@ def main():
             line["rehearsal"] = "rank 0's share of a %d-rank job on one GPU: %d divisions, %.4g cells, %.1f ms per step" % (
                 args.shard_of, len(mine), my_cells, ms_per_step)
         if not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(sw, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(sw, args.cpu_seconds, {int(k): float(o[0]) for k, o in zip(mine, out)})
             if line["cpu_baseline"]["value"]:
                 line["config"]["gpu_over_cpu_1core"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line))
