@@ -43,3 +43,22 @@ def test_multitile_vs_oracle(ctx, name, fam_kw, alp):
         assert scr == oscr, (name, pw.alnmode, scr, oscr)
         assert np.array_equal(skl, oraclelib.stdskl(L, otr))
     assert len(modes) >= 2
+
+
+def test_baseline_config2_shape(ctx):
+    """BASELINE configs[1]: two groups of ~32 proteins x 512 aa (one 64-sequence family split at its most balanced
+    tree branch), aligned once by align2 -- mode GPF_ALB (9), profile-profile DP; bit-exact vs the oracle."""
+    fam = make_family(n_seq=64, length=512, seed=1)
+    sw = sweep.Sweep(fam, op.AlnParam())
+    k = min(range(len(sw)), key=lambda i: abs(len(sw.branches[i]) - 32))
+    pw = sw.pwds[k]
+    assert pw.alnmode == 9 and min(pw.problem.a.many, pw.problem.b.many) >= 16
+    (scr, skl, st), = op.align2_batch(ctx, [pw])
+    assert st == 0
+    L = oraclelib.load()
+
+    class H:
+        c = pw.problem
+    oscr, ocells, otr = oraclelib.forward(L, H)
+    assert scr == oscr and ocells > 100000
+    assert np.array_equal(skl, oraclelib.stdskl(L, otr))
