@@ -1,0 +1,76 @@
+"""Edge cases of the DP path on the GPU: the smallest possible DPs (1 x 1 cells, single columns/rows), tiny and
+ragged groups, heavy-indel families, and the error behaviour of the boundary (bad arguments are reported per
+problem, the rest of the batch still runs).  Checker: the CPU oracle on the same flattened problem."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oraclelib
+from prrn_aln_amd import _abi, engine, operator as op, sweep
+from prrn_aln_amd.synth import make_family, DNA
+
+pytestmark = pytest.mark.gpu
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = engine.Context()
+    yield c
+    c.close()
+
+
+TINY = [
+    ("2x1", dict(n_seq=2, length=1, seed=1), {}),
+    ("3x1", dict(n_seq=3, length=1, seed=2), {}),
+    ("2x3", dict(n_seq=2, length=3, seed=3), {}),
+    ("5x2", dict(n_seq=5, length=2, seed=4, indel=0.3), {}),
+    ("9x8_ls3", dict(n_seq=9, length=8, seed=5, indel=0.2), dict(ls=3)),
+    ("24x3", dict(n_seq=24, length=3, seed=6, indel=0.25), {}),
+    ("30x12_gappy", dict(n_seq=30, length=12, seed=7, indel=0.2, max_indel=6), {}),
+    ("16x40_dna_ls3", dict(n_seq=16, length=40, seed=8, alphabet=DNA, indel=0.1, max_indel=8), dict(ls=3, molc=op.DNA, max_code=17)),
+]
+
+
+@pytest.mark.parametrize("name,fkw,akw", TINY, ids=[t[0] for t in TINY])
+def test_tiny_and_ragged_families(ctx, name, fkw, akw):
+    sw = None
+    for bump in range(20):                             # (a leaf that lost every residue is not a valid input: next seed)
+        fam = make_family(**dict(fkw, seed=fkw["seed"] + 100 * bump))
+        if min(len(s.replace("-", "")) for s in fam.msa) == 0:
+            continue
+        sw = sweep.Sweep(fam, op.AlnParam(**akw))
+        break
+    assert sw is not None
+    res = op.align2_batch(ctx, sw.pwds)
+    L = oraclelib.load()
+    for pw, (scr, skl, st) in zip(sw.pwds, res):
+        assert st == 0, (name, pw.alnmode, st)
+
+        class H:
+            c = pw.problem
+        oscr, ocells, otr = oraclelib.forward(L, H)
+        assert scr == oscr, (name, pw.alnmode, scr, oscr)
+        assert np.array_equal(skl, oraclelib.stdskl(L, otr))
+
+
+def test_bad_arguments_are_reported_per_problem(ctx):
+    """One broken problem does not poison the batch: it gets its own status, the others their results."""
+    ds = [dict(np.load(f)) for f in GOLD[:3]]
+    hs = [_abi.problem_from_arrays(d) for d in ds]
+    hs[1].c.lw, hs[1].c.up = 5, 4                      # empty band
+    res = ctx.forward_batch(hs)
+    assert res[1][3] != 0                              # G2G_ERR_ARG
+    for i in (0, 2):
+        scr, cells, tr, st = res[i]
+        assert st == 0 and scr == ds[i]["scr"][0] and np.array_equal(tr, ds[i]["vmf_trace"])
+    hs[1].c.lw, hs[1].c.up = int(ds[1]["wdw_lw"].ravel()[0]), int(ds[1]["wdw_up"].ravel()[0])
+    hs[1].c.alnmode = 1                                # rectangular NGP_ALN: not on this path
+    res = ctx.forward_batch(hs)
+    assert res[1][3] != 0 and res[0][3] == 0
+
+
+def test_empty_batch(ctx):
+    assert ctx.forward_batch([]) == []
