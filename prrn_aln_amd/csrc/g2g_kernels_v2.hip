@@ -79,13 +79,11 @@ __device__ __forceinline__ int dh_nins(int g, const DHead &h)
     const bool c2 = c1 && g >= (int) (h.e2 >> 16);
     const bool c3 = c2 && g >= (int) (h.e3 >> 16);
     unsigned e = c2 ? h.e2 : (c1 ? h.e1 : h.e0);
-#ifndef G2G_EXP_NOSLOW
     if (c3) {                                                       // rare: more than three entries below g
         int k = 3;
         while (g >= (int) (h.p[k + 1] >> 16) && k < DL_GUARD) ++k;
         e = h.p[k];
     }
-#endif
     return (int) (e & 0xFFFFu);
 }
 template <class CL> struct SHead { int g0, g1, g2, g3; CL l; };    // static GFREQ list (glen part)

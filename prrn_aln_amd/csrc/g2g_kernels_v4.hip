@@ -61,9 +61,6 @@ __device__ __forceinline__ void v4_cell(const DevProb &P, const int ca4, const i
         int k = 0, bg = bl.g0;
         int w = bg >= 0 ? bg + dh_nins(bg, hb) : 0;
         bool live = on;
-#ifdef G2G_V4_EXP_NOMERGE
-        live = false;
-#endif
 #pragma unroll G2G_V4_UNROLL
         for (int i = 0; i < N; ++i) {
             if (wave_none(live)) break;
@@ -111,9 +108,6 @@ __device__ __forceinline__ void v4_cell(const DevProb &P, const int ca4, const i
         lu32 *const d1 = (role == 1 ? dg : df) + o, *const d3 = (role == 1 ? dg2 : df2) + o, *const d2 = dh + o;
         lu32 *const d1b = (win == (role == 1 ? 1 : 3)) ? d2 : nul, *const d3b = (win == (role == 1 ? 2 : 4)) ? d2 : nul;
         ND n1 = {0, 0, 0, on1}, n2 = {0, 0, 0, win == 0}, n3 = {0, 0, 0, on1 && NOLL3};
-#ifdef G2G_V4_EXP_NOND
-        n1.on = n2.on = n3.on = false;
-#endif
 #pragma unroll G2G_V4_UNROLL
         for (int i = 0; i < N; ++i) {
             if (wave_none(n1.on || n2.on || (NOLL3 && n3.on))) break;
