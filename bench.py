@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--limit", type=int, default=0, help="use only the first LIMIT divisions (debug)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dna", action="store_true", help="non-default workload: DNA family, long-gap penalty (ls=3, Noll 3 kernels)")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="rehearsal on ONE GPU: run only rank 0's share of an N-rank job (prints a line marked rehearsal)")
     args = ap.parse_args()
@@ -123,8 +124,13 @@ def main():
     from prrn_aln_amd import engine, operator as op, sweep
     from prrn_aln_amd.synth import make_family
 
-    fam = make_family(args.nseq, args.length, args.seed)
-    alp = op.AlnParam()
+    if args.dna:
+        from prrn_aln_amd.synth import DNA
+        fam = make_family(args.nseq, args.length, args.seed, alphabet=DNA)
+        alp = op.AlnParam(ls=3, molc=op.DNA, max_code=17)
+    else:
+        fam = make_family(args.nseq, args.length, args.seed)
+        alp = op.AlnParam()
     sw = sweep.Sweep(fam, alp, weighted=True, limit=args.limit or None)
     mine = sweep.shard(sw.order, args.shard_of, 0) if args.shard_of > 1 and world == 1 else sweep.shard(sw.order, world, rank)
     ctx = engine.Context(local_rank)
@@ -176,6 +182,7 @@ def main():
         value = total_cells * args.steps / dt
         fwd_avg_ms = fwd_ms / args.steps
         noll = holders[0].problem.noll if holders else 2
+        line_tag = "NON-DEFAULT workload (DNA, ls=3): not the BASELINE metric" if args.dna else None
         ach = my_cells * BYTES_PER_CELL[noll] / (fwd_avg_ms * 1e-3) / 1e9 if fwd_avg_ms else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -201,6 +208,9 @@ def main():
                          "kernel": "g2g_v3r_hf2 + g2g_v2_pf2 (persistent tile kernels, concurrent) incl. g2g_v2_rowoff/prologue/sim kernels", "kernel_ms": fwd_avg_ms, "traceback_ms": tb_ms / args.steps,
                          "bytes_per_cell": BYTES_PER_CELL[noll], "cells_per_launch": my_cells},
         }
+        if line_tag:
+            line["config"]["note"] = line_tag
+            line["config"]["workload"] = line["config"]["workload"].replace("proteins", "DNA sequences").replace(" aa ", " nt ")
         if args.shard_of > 1 and world == 1:
             line["rehearsal"] = "rank 0's share of a %d-rank job on one GPU: %d divisions, %.4g cells, %.1f ms per step" % (
                 args.shard_of, len(mine), my_cells, ms_per_step)
