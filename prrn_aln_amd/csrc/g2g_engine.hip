@@ -112,9 +112,9 @@ struct g2g_batch {
     size_t lds2p;                   // ... of the v2 prologue launch
     int v2_maxrows;                 // longest a-range among the v2 problems
     V2Tile *d_tiles;                // tiles: per variant (v2: hf2, hf3, pf2, pf3; v3: the same four) a queue ordered by wavefront i + j
-    int var_off[15];                // variant v owns tiles [var_off[v], var_off[v+1])
+    int var_off[17];                // variant v owns tiles [var_off[v], var_off[v+1])
     V3Lds v3lds[8];                 // LDS plan of the v3 variants
-    V4Lds v4lds[2];                 // LDS plan of the v4 (_pf, 8 lanes per cell) variants
+    V4Lds v4lds[4];                 // LDS plan of the v4 (_pf, 8 lanes per cell) variants
     int v4_cols;
     int v2_cols;
     int v3_cols;                    // columns per v3 tile
@@ -154,7 +154,7 @@ static V3Lds v3_layout(int rows_bytes, int ca4max, int apool, int bpool, int C)
     L.total = o;
     return L;
 }
-static V4Lds v4_layout(int rows_bytes, int ca4max, int C)
+static V4Lds v4_layout(int rows_bytes, int ca4max, int C, int RC = V4_RC)
 {
     V4Lds L;
     int o = 0;
@@ -163,17 +163,17 @@ static V4Lds v4_layout(int rows_bytes, int ca4max, int C)
     L.black = take(4 * (ca4max + 4));
     L.stsc = take(4 * 28);
     L.boff = take(4 * 3 * (C + 2));
-    L.bring_g = take(4 * V4_RC * 3 * V4_MLB);
-    L.bring_f = take(8 * V4_RC * 3 * V4_MLB);
+    L.bring_g = take(4 * RC * 3 * V4_MLB);
+    L.bring_f = take(8 * RC * 3 * V4_MLB);
     L.svals = take(4 * 64);
     L.sink = take(4 * 64);
     L.total = o;
     return L;
 }
-static int v4_rows_bytes(const DevProb &d)
+static int v4_rows_bytes(const DevProb &d, int R = V4_R)
 {
     const int lsz = ((d.capa + 3) & ~3) + ((d.capb + 3) & ~3);
-    return (V4_R + 1) * v3_pitch(d.noll == 3 ? 9 : 6, lsz) * 4;
+    return (R + 1) * v3_pitch(d.noll == 3 ? 9 : 6, lsz) * 4;
 }
 struct V3Need { int rows_bytes, ca4, apool, bpool, total; };
 static V3Need v3_need(const DevProb &d, const g2g_problem *p, int C, bool areg = false)
@@ -388,7 +388,9 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         // v2 kernel (gap-profile engines): packed 16-bit gap lengths and an LDS budget decide eligibility
         d.v2_ok = 0;
         if ((d.kind == 1 || d.kind == 2) && !getenv("G2G_FORCE_V1") && p->a.len + p->b.len < 65000) {
-            if (!getenv("G2G_FORCE_V2") && getenv("G2G_V4") && !getenv("G2G_V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V3_NA && d.b.maxlist <= V4_MLB &&
+            if (!getenv("G2G_FORCE_V2") && getenv("G2G_V5") && !getenv("G2G_V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V3_NA && d.b.maxlist <= V4_MLB &&
+                v4_layout(v4_rows_bytes(d, V5_R), (d.capa + 3) & ~3, b->v4_cols, V5_RC).total <= (int) V2_LDS_MAX) d.v2_ok = 5;
+            else if (!getenv("G2G_FORCE_V2") && getenv("G2G_V4") && !getenv("G2G_V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V3_NA && d.b.maxlist <= V4_MLB &&
                 v4_layout(v4_rows_bytes(d), (d.capa + 3) & ~3, b->v4_cols).total <= (int) V2_LDS_MAX) d.v2_ok = 4;
             else if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_AREG") && (d.kind == 1 || getenv("G2G_V3_PF")) && d.a.maxlist <= G2G_V3_NA &&
                 v3_need(d, p, b->v3_cols, true).total <= (int) V2_LDS_MAX) d.v2_ok = 3;
@@ -449,9 +451,9 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     // ordered by wavefront i + j; one completion flag per tile slot (empty slots count as done for ever)
     b->d_tiles = 0; b->ntiles = 0; b->lds2p = 0; b->v2_maxrows = 1; b->d_flags = 0; b->nflags = 0; b->gen = 0;
     {
-        std::vector<std::vector<std::vector<V2Tile> > > q(14);   // [variant][wavefront] -> tiles
+        std::vector<std::vector<std::vector<V2Tile> > > q(16);   // [variant][wavefront] -> tiles
         std::vector<int> flags(20, 0);                    // 0-15 queue heads, 16-19 incident report
-        int v4rows[2] = {0, 0}, v4ca4[2] = {0, 0};
+        int v4rows[4] = {0, 0, 0, 0}, v4ca4[4] = {0, 0, 0, 0};
         V3Need need[8];
         memset(need, 0, sizeof need);
         for (int i = 0; i < n; ++i) {
@@ -461,12 +463,12 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             b->lds2p = std::max(b->lds2p, 5 * recsz + 64);
             b->v2_maxrows = std::max(b->v2_maxrows, d.a.right - d.a.left);
             const int al = d.a.left, ar = d.a.right, bl_ = d.b.left, br = d.b.right;
-            const int R = d.v2_ok == 4 ? V4_R : d.v2_ok >= 2 ? 64 : G2G_V2_THREADS / 8;
-            const int C = d.v2_ok == 4 ? b->v4_cols : d.v2_ok >= 2 ? b->v3_cols : b->v2_cols;
+            const int R = d.v2_ok == 5 ? V5_R : d.v2_ok == 4 ? V4_R : d.v2_ok >= 2 ? 64 : G2G_V2_THREADS / 8;
+            const int C = d.v2_ok >= 4 ? b->v4_cols : d.v2_ok >= 2 ? b->v3_cols : b->v2_cols;
             const int nstrip = (ar - al + R - 1) / R, nblk = (br - bl_ + C - 1) / C;
-            const int var = d.v2_ok == 4 ? 12 + (d.noll == 3 ? 1 : 0) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
-            if (d.v2_ok == 4) {
-                v4rows[var - 12] = std::max(v4rows[var - 12], v4_rows_bytes(d));
+            const int var = d.v2_ok >= 4 ? 12 + 2 * (d.v2_ok - 4) + (d.noll == 3 ? 1 : 0) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
+            if (d.v2_ok >= 4) {
+                v4rows[var - 12] = std::max(v4rows[var - 12], v4_rows_bytes(d, d.v2_ok == 5 ? V5_R : V4_R));
                 v4ca4[var - 12] = std::max(v4ca4[var - 12], (d.capa + 3) & ~3);
             } else if (d.v2_ok >= 2) {
                 const V3Need nd = v3_need(d, prob[i], C, d.v2_ok == 3);
@@ -503,12 +505,12 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             }
         }
         std::vector<V2Tile> all;
-        for (int v = 0; v < 14; ++v) {
+        for (int v = 0; v < 16; ++v) {
             b->var_off[v] = (int) all.size();
             for (size_t k = 0; k < q[v].size(); ++k) all.insert(all.end(), q[v][k].begin(), q[v][k].end());
         }
-        b->var_off[14] = (int) all.size();
-        for (int v = 0; v < 2; ++v) b->v4lds[v] = v4_layout(v4rows[v], v4ca4[v], b->v4_cols);
+        b->var_off[16] = (int) all.size();
+        for (int v = 0; v < 4; ++v) b->v4lds[v] = v4_layout(v4rows[v], v4ca4[v], b->v4_cols, v < 2 ? V4_RC : V5_RC);
         for (int v = 0; v < 8; ++v) b->v3lds[v] = v3_layout(need[v].rows_bytes, need[v].ca4, need[v].apool, need[v].bpool, b->v3_cols);
         b->ntiles = (long long) all.size();
         b->nflags = (int) flags.size();
@@ -606,12 +608,12 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipEventRecord(ctx->vev[v & 3], vs));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[v & 3], 0));
         }
-        for (int v = 0; v < 2; ++v) {
+        for (int v = 0; v < 4; ++v) {
             const int cnt = b->var_off[v + 13] - b->var_off[v + 12];
             if (!cnt) continue;
             typedef void (*v4k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V4Lds, int);
-            static const v4k_t v4k[2] = {g2g_v4_pf2, g2g_v4_pf3};
-            hipStream_t vs = ctx->vstream[2 + v];
+            static const v4k_t v4k[4] = {g2g_v4_pf2, g2g_v4_pf3, g2g_v5_pf2, g2g_v5_pf3};
+            hipStream_t vs = ctx->vstream[2 + (v & 1)];
             const V4Lds &LO = b->v4lds[v];
             if (LO.total > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *) v4k[v], hipFuncAttributeMaxDynamicSharedMemorySize, LO.total));
             HIPCHK(hipStreamWaitEvent(vs, ctx->vev[4], 0));
@@ -625,8 +627,8 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                                b->d_flags + 12 + v, b->d_flags, b->gen, LO, b->v4_cols);
             HIPCHK(hipGetLastError());
             if (getenv("G2G_DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v4 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
-            HIPCHK(hipEventRecord(ctx->vev[2 + v], vs));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[2 + v], 0));
+            HIPCHK(hipEventRecord(ctx->vev[2 + (v & 1)], vs));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[2 + (v & 1)], 0));
         }
     }
     if (b->n1) {

@@ -26,6 +26,8 @@ CONFIGS = {
     "v3_pf": {"G2G_V3_PF": "1", "G2G_V3_COLS": "64"},
     "v4": {"G2G_V4": "1"},
     "v4_cols16": {"G2G_V4": "1", "G2G_V4_COLS": "16"},
+    "v5": {"G2G_V5": "1"},
+    "v5_cols16": {"G2G_V5": "1", "G2G_V4_COLS": "16"},
     "v2": {"G2G_FORCE_V2": "1"},
     "v1": {"G2G_FORCE_V1": "1"},
 }
@@ -70,7 +72,7 @@ FAMILIES = [
 ]
 
 
-@pytest.mark.parametrize("name", ["v3r_cols32", "v3lds_all", "v3_pf", "v4", "v2"])
+@pytest.mark.parametrize("name", ["v3r_cols32", "v3lds_all", "v3_pf", "v4", "v5", "v2"])
 @pytest.mark.parametrize("fam", FAMILIES, ids=[f[0] for f in FAMILIES])
 def test_large_divisions_every_path(ctx, L, monkeypatch, name, fam):
     """Group-vs-rest divisions of a 650-700 column family (many strips and blocks) per forced path."""
