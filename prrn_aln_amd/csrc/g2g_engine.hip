@@ -577,7 +577,9 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             const int cnt = b->var_off[v + 1] - b->var_off[v];
             if (!cnt) continue;
             HIPCHK(hipStreamWaitEvent(ctx->vstream[v], ctx->vev[4], 0));
-            const int grid = std::min(cnt, ncu * 8);
+            int wpc2 = 8;
+            if (const char *e = getenv("G2G_V2_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc2 = w; }
+            const int grid = std::min(cnt, ncu * wpc2);
             if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] variant %d: %d tiles, grid %d, lds %zu, gen %d\n", v, cnt, grid, b->lds2, b->gen); fflush(stderr); }
             hipLaunchKernelGGL(v2k[v], dim3(grid), dim3(G2G_V2_THREADS), b->lds2 + 4 * G2G_V2_THREADS, ctx->vstream[v],
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v]), cnt,
