@@ -643,12 +643,14 @@ __device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nst
     }
     // the view (s/t/r) of b this thread prefetches: chosen once with selects (a runtime index into the descriptor copy
     // would force the copy into scratch memory)
-    const int pf_view = tid / TEAM;
+    // (the loader lanes sit in the LAST wave: the first wave already carries the staging of the strip above)
+    const int pf_tid = tid - ((int) blockDim.x - 64);
+    const int pf_view = pf_tid / TEAM;
     const int *const pf_off = pf_view == 0 ? b.off[0] : pf_view == 1 ? b.off[1] : b.off[2];
     const int *const pf_glen = pf_view == 0 ? b.glen[0] : pf_view == 1 ? b.glen[1] : b.glen[2];
     const double *const pf_freq = pf_view == 0 ? b.freq[0] : pf_view == 1 ? b.freq[1] : b.freq[2];
-    if (KIND == 2 && tid < 3 * TEAM) {                     // column ring: column cbase for step 0
-        const int v = tid / TEAM;
+    if (KIND == 2 && pf_tid >= 0 && pf_tid < 3 * TEAM) {   // column ring: column cbase for step 0
+        const int v = pf_view;
         const int o = pf_off[cbase + 1], e = pf_off[cbase + 2];
         for (int k = lane; k < e - o; k += TEAM) { bglen[(size_t) v * mlb + k] = pf_glen[o + k]; bfreq[(size_t) v * mlb + k] = pf_freq[o + k]; }
     }
@@ -681,9 +683,9 @@ __device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nst
         // prefetch the column the first row reaches next step into the ring (3 teams, one view each): the
         // loads are issued here, the LDS stores wait until the cell work of this step is done
         int pf_g[4]; double pf_f[4]; int pf_n = 0, pf_base = 0;
-        const bool pf_on = KIND == 2 && tid < 3 * TEAM && cbase + s + 1 < c1;
+        const bool pf_on = KIND == 2 && pf_tid >= 0 && pf_tid < 3 * TEAM && cbase + s + 1 < c1;
         if (pf_on) {
-            const int v = tid / TEAM, pos = cbase + s + 1;
+            const int v = pf_view, pos = cbase + s + 1;
             const int o = pf_off[pos + 1];
             pf_n = pf_off[pos + 2] - o;
             pf_base = (wslot * 3 + v) * mlb;
