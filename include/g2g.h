@@ -190,6 +190,27 @@ const g2g_problem *g2g_pwdm_problem(const g2g_pwdm *p);
 /* <-> SKL* align2(mSeq* seqs[], PwdM* pwdm, VTYPE* scr, Gsinfo*) (src/maln2.cc:1875): forward fill,
    traceback, stdskl, end check with the sh = -100 retry.  *skl is malloc'ed: skl[0..*nskl) corners
    ascending (the reference's skl[1..n]); caller g2g_free()s.  Batched form = one randiv sweep. */
+/* ---- f1: the sum-of-pairs score of the alignment a skeleton describes ---------------------------------
+ * <-> VTYPE PreSpScore::calcSpScore(Gsinfo*) (src/fspscore.cc:584-622) = SpScore<SPunit|SPunit_hf|SPunit_pf>::calcSkl
+ * (src/fspscore.h:202-254, calscr src/fspscore.cc:346-541) followed by PwdM::rescale (src/maln2.cc:245-252): the score is
+ * re-evaluated ALONG the path (column scores, unpaired-column penalties and the gap-open counts of the gap-profile
+ * algebra) and returned per unit pair weight; Prrn::onecycle takes fstat.val of the old and the new alignment as the
+ * acceptance delta.  On this path: NGP / HLF / RHF / GPF modes with Noll 2 (the naive NTV units and the long-gap
+ * bookkeeping `Gep1st` of -yl3 are not: G2G_ERR_MODE).  mch/mmc/unp of FSTAT (PwdM::stt2) are not computed.        */
+typedef struct {
+    double vab;          /* PwdM::Vab = scale * wa * wb (src/maln2.cc:234)                         */
+    double basic_gep;    /* PwdB::BasicGEP = -u * axbscale (src/aln2.cc:103)                       */
+    double diffu;        /* PwdB::diffu = LongGEP - BasicGEP (src/aln2.cc:105)                      */
+} g2g_spparams;
+typedef struct { double val, gap; int32_t status; int32_t reserved; } g2g_fstat;
+/* level 0: on a prepared batch (inputs resident in HBM); skl[i] = the standardised skeleton of problem i
+ * (g2g_stdskl output: corners ascending, first = (a.left, b.left), last = (a.right, b.right))              */
+int        g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl,
+                             g2g_fstat *out);
+/* level 1 */
+int        g2g_pwdm_spparams(const g2g_pwdm *p, g2g_spparams *sp);
+int        g2g_spscore_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *p, const g2g_skl *const *skl, const int *nskl,
+                             g2g_fstat *out);
 int        g2g_align2(g2g_ctx *ctx, g2g_pwdm *p, double *scr, g2g_skl **skl, int *nskl);
 /* <-> VTYPE HomScore(mSeq* seqs[], PwdM* pwdm, long rr[]) (src/maln2.cc:1837): score only; rr may be NULL. */
 int        g2g_homscore(g2g_ctx *ctx, g2g_pwdm *p, double *scr, int64_t rr[2]);

@@ -119,3 +119,11 @@ def problem_from_arrays(d: Dict[str, np.ndarray]) -> ProblemHolder:
             side.gapdens = _ptr(h.arr(g("gapdens"), np.float64), c_f64p)
             side.postgapdens = _ptr(h.arr(g("postgapdens"), np.float64), c_f64p)
     return h
+
+
+class SpParams(C.Structure):
+    _fields_ = [("vab", C.c_double), ("basic_gep", C.c_double), ("diffu", C.c_double)]
+
+
+class Fstat(C.Structure):
+    _fields_ = [("val", C.c_double), ("gap", C.c_double), ("status", C.c_int32), ("reserved", C.c_int32)]

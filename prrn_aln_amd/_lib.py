@@ -40,6 +40,7 @@ def lib():
     L.g2g_batch_arena_bytes.restype = C.c_size_t
     L.g2g_batch_arena_bytes.argtypes = [C.c_void_p]
     L.g2g_batch_free.argtypes = [C.c_void_p]
+    L.g2g_batch_spscore.argtypes = [C.c_void_p, C.POINTER(_abi.SpParams), C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int), C.POINTER(_abi.Fstat)]
     L.g2g_free.argtypes = [C.c_void_p]
     L.g2g_stdskl.restype = C.POINTER(_abi.Skl)
     L.g2g_stdskl.argtypes = [C.POINTER(_abi.Skl), C.c_int, C.POINTER(C.c_int)]
@@ -63,5 +64,7 @@ def bind_level1(L):
     L.g2g_pwdm_problem.argtypes = [C.c_void_p]
     L.g2g_align2.argtypes = [C.c_void_p, C.c_void_p, _abi.c_f64p, C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int)]
     L.g2g_homscore.argtypes = [C.c_void_p, C.c_void_p, _abi.c_f64p, C.POINTER(C.c_int64)]
+    L.g2g_pwdm_spparams.argtypes = [C.c_void_p, C.POINTER(_abi.SpParams)]
+    L.g2g_spscore_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int), C.POINTER(_abi.Fstat)]
     L.g2g_align2_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), _abi.c_f64p,
                                    C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int), C.POINTER(C.c_int)]

@@ -715,6 +715,50 @@ extern "C" void g2g_batch_free(g2g_batch *b)
 extern "C" void g2g_stamps(unsigned long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g2g_stamp_acc), sizeof(unsigned long long) * 16); }
 extern "C" void g2g_waits(unsigned long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g2g_wait_acc), sizeof(unsigned long long) * 4); }
 #endif
+
+// f1: PreSpScore::calcSpScore on the problems of a prepared batch (their inputs are resident in HBM)
+extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl, g2g_fstat *out)
+{
+    if (!b || !sp || !skl || !nskl || !out) return G2G_ERR_ARG;
+    g2g_ctx *ctx = b->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = b->n;
+    if (n == 0) return G2G_OK;
+    std::vector<int> off(n), cnt(n);
+    size_t tot = 0;
+    for (int i = 0; i < n; ++i) { off[i] = (int) tot; cnt[i] = (skl[i] && nskl[i] > 0) ? nskl[i] : 0; tot += cnt[i]; }
+    std::vector<g2g_skl> all(tot ? tot : 1);
+    for (int i = 0; i < n; ++i) if (cnt[i]) memcpy(&all[off[i]], skl[i], sizeof(g2g_skl) * cnt[i]);
+    const size_t b_skl = sizeof(g2g_skl) * all.size(), b_int = sizeof(int) * n, b_sp = sizeof(g2g_spparams) * n, b_out = sizeof(double) * 2 * n;
+    char *d = 0;
+    const size_t o_skl = 0, o_off = (b_skl + 15) & ~(size_t) 15, o_cnt = o_off + ((b_int + 15) & ~(size_t) 15),
+                 o_sp = o_cnt + ((b_int + 15) & ~(size_t) 15), o_out = o_sp + ((b_sp + 15) & ~(size_t) 15),
+                 o_st = o_out + ((b_out + 15) & ~(size_t) 15), total = o_st + b_int;
+    HIPCHK(hipMalloc((void **) &d, total));
+    hipError_t e = hipMemcpyAsync(d + o_skl, all.data(), b_skl, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_off, off.data(), b_int, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_cnt, cnt.data(), b_int, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_sp, sp, b_sp, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(g2g_spscore_kernel, dim3(n), dim3(64), 0, ctx->stream, (const DevProb *) b->d_probs, n,
+                           (const SpParamsDev *) (d + o_sp), (const int2 *) (d + o_skl), (const int *) (d + o_off),
+                           (const int *) (d + o_cnt), (double *) (d + o_out), (int *) (d + o_st));
+        e = hipGetLastError();
+    }
+    std::vector<double> ho(2 * (size_t) n);
+    std::vector<int> hs(n);
+    if (e == hipSuccess) e = hipMemcpyAsync(ho.data(), d + o_out, b_out, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hs.data(), d + o_st, b_int, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d);
+    if (e != hipSuccess) { g2g_set_error("spscore: %s", hipGetErrorString(e)); return G2G_ERR_DEVICE; }
+    for (int i = 0; i < n; ++i) {
+        out[i].val = ho[2 * i]; out[i].gap = ho[2 * i + 1]; out[i].reserved = 0;
+        out[i].status = b->status[i] ? b->status[i] : hs[i] == 0 ? G2G_OK : hs[i] == -2 ? G2G_ERR_MODE : G2G_ERR_ARG;
+    }
+    return G2G_OK;
+}
+
 extern "C" int g2g_forward_batch(g2g_ctx *ctx, int n, const g2g_problem *const *prob, g2g_result *res)
 {
     g2g_batch *b = 0;

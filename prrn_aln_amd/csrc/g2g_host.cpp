@@ -472,6 +472,7 @@ struct g2g_pwdm {
     int swp;
     int alnmode, a_mode, b_mode, aprof, bprof;
     g2g_problem prob;
+    g2g_spparams sp;                 // PwdM::Vab and the PwdB gap-extension scalars calcSpScore needs
 };
 
 namespace {
@@ -640,11 +641,37 @@ extern "C" g2g_pwdm *g2g_pwdm_create(g2g_ctx *, const g2g_params *prm, g2g_group
     fill_side(b, q.b, ntv);
     q.a.weight = wta; q.b.weight = wtb;
     stripe(a, b, prm->sh, &q.lw, &q.up);
+    {   // resetuab, src/maln2.cc:227-234: Vab = scale * wa * wb with the weight sums of the profile-mode sides
+        const double wa = a_mode ? a.sumwt : 1, wb = b_mode ? b.sumwt : 1;
+        P->sp.vab = (double) (prm->scale * wa * wb);
+        P->sp.basic_gep = BasicGEP; P->sp.diffu = diffu;
+    }
     if (swapped) *swapped = swp;
     return P;
 }
 
 extern "C" void g2g_pwdm_free(g2g_pwdm *p) { delete p; }
+extern "C" int g2g_pwdm_spparams(const g2g_pwdm *p, g2g_spparams *sp)
+{
+    if (!p || !sp) return G2G_ERR_ARG;
+    *sp = p->sp;
+    return G2G_OK;
+}
+// <-> PreSpScore::calcSpScore(Gsinfo*) for every (PwdM, skeleton) pair, src/fspscore.cc:584-622
+extern "C" int g2g_spscore_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *p, const g2g_skl *const *skl, const int *nskl, g2g_fstat *out)
+{
+    if (!ctx || n < 0 || (n && (!p || !skl || !nskl || !out))) return G2G_ERR_ARG;
+    if (n == 0) return G2G_OK;
+    std::vector<const g2g_problem *> pp(n);
+    std::vector<g2g_spparams> sp(n);
+    for (int i = 0; i < n; ++i) { if (!p[i]) return G2G_ERR_ARG; pp[i] = &p[i]->prob; sp[i] = p[i]->sp; }
+    g2g_batch *b = 0;
+    int rc = g2g_batch_prepare(ctx, n, pp.data(), &b);
+    if (rc) return rc;
+    rc = g2g_batch_spscore(b, sp.data(), skl, nskl, out);
+    g2g_batch_free(b);
+    return rc;
+}
 extern "C" const g2g_problem *g2g_pwdm_problem(const g2g_pwdm *p) { return p ? &p->prob : 0; }
 
 // <-> stdskl(SKL**), reference src/gaps.cc:139-174: order the raw traceback by (m, n), drop repeats and

@@ -676,3 +676,126 @@ extern "C" __global__ void __launch_bounds__(64) g2g_traceback_kernel(const DevP
         P.ntrace[1] = rr0;
     }
 }
+
+// ---- f1: SpScore<recd_t>::calcSkl (reference src/fspscore.h:202-254; calscr src/fspscore.cc:346-363, 472-541) --------
+// The sum-of-pairs score of the alignment a standardised skeleton describes, re-evaluated along the path: column scores
+// (sim2), unpaired-column penalties and the gap-open COUNTS (raw newgap) of the gap-profile algebra, then
+// PwdM::wgop + PwdM::rescale (maln.h:321-325, maln2.cc:245-252).  A dependent chain per alignment (every column
+// updates the dynamic gap lists the next one reads): one wave per alignment, lane 0 walks; alignments run in parallel.
+// The lists live in the first slot of the v1 state arrays of the problem (free once the forward sweep is over).
+struct SpParamsDev { double vab, basic_gep, diffu; };
+template <int KIND>
+__device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int ni, int &apos, int &bpos, int &glb,
+                          const DList dla, const DList dlb, double &scr, double &tgap)
+{
+    const DevSide &a = P.a, &b = P.b;
+    if (KIND == 0) {
+        if (mi == ni) {
+            while (mi--) { ++apos; ++bpos; scr += sim2(P, apos, bpos); }
+        } else if (mi) {
+            const double efq = thk_at(b, bpos)[2];
+            tgap += sp.vab * efq;
+            double unp = mi * sp.basic_gep;                                       // UnpPenalty, aln.h:275-279
+            if (mi > P.codonk1) unp = unp + sp.diffu * (mi - P.codonk1);
+            scr += unp * efq;
+            apos += mi;
+        } else if (ni) {
+            const double efq = thk_at(a, apos)[2];
+            tgap += sp.vab * efq;
+            double unp = ni * sp.basic_gep;
+            if (ni > P.codonk1) unp = unp + sp.diffu * (ni - P.codonk1);
+            scr += unp * efq;
+            bpos += ni;
+        }
+    } else if (KIND == 1) {
+        if (mi == ni) {
+            while (mi--) {
+                ++apos; ++bpos;
+                scr += sim2(P, apos, bpos);
+                tgap += newgap_di(gfq_at(a, 1, apos), glb, dla);
+                newdelta(dla, gfq_at(a, 1, apos), dla);
+                glb = 0;
+            }
+        } else if (mi) {
+            while (mi--) {
+                ++apos;
+                scr += unpa(P, apos, bpos);
+                tgap += newgap_cj(gfq_at(a, 0, apos), dla, glb);
+                newdelta(dla, gfq_at(a, 1, apos), dla);
+                ++glb;
+            }
+        } else if (ni) {
+            while (ni--) {
+                ++bpos;
+                scr += unpb(P, bpos, apos);
+                tgap += newgap_di(gfq_at(a, 2, apos), glb, dla);
+                incdelta2(dla, dla);
+            }
+        }
+    } else {
+        if (mi == ni) {
+            while (mi--) {
+                ++apos; ++bpos;
+                scr += sim2(P, apos, bpos);
+                tgap += newgap4(gfq_at(a, 0, apos), dla, gfq_at(b, 1, bpos), dlb)
+                      + newgap4(gfq_at(b, 0, bpos), dlb, gfq_at(a, 1, apos), dla);
+                newdelta(dla, gfq_at(a, 1, apos), dla);
+                newdelta(dlb, gfq_at(b, 1, bpos), dlb);
+            }
+        } else if (mi) {
+            while (mi--) {
+                ++apos;
+                scr += unpa(P, apos, bpos);
+                tgap += newgap4(gfq_at(a, 0, apos), dla, gfq_at(b, 2, bpos), dlb);
+                newdelta(dla, gfq_at(a, 1, apos), dla);
+                incdelta2(dlb, dlb);
+            }
+        } else if (ni) {
+            while (ni--) {
+                ++bpos;
+                scr += unpb(P, bpos, apos);
+                tgap += newgap4(gfq_at(b, 0, bpos), dlb, gfq_at(a, 2, apos), dla);
+                newdelta(dlb, gfq_at(b, 1, bpos), dlb);
+                incdelta2(dla, dla);
+            }
+        }
+    }
+}
+template <int KIND>
+__device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *skl, int nskl, double *out)
+{
+    DList dla, dlb;
+    dla.p = P.dla[XH]; dla.s = P.width; dlb.p = P.dlb[XH]; dlb.s = P.width;
+    if (KIND >= 1) cleardelta(dla);
+    if (KIND == 2) cleardelta(dlb);
+    int m = skl[0].x, n = skl[0].y, glb = 0;
+    int apos = m - 1, bpos = n - 1;
+    double scr = 0, tgap = 0;
+    for (int k = 1; k < nskl; ++k) {
+        const int mi = skl[k].x - m, ni = skl[k].y - n, i = mi - ni;
+        if (!i || !mi || !ni) sp_calscr<KIND>(P, sp, mi, ni, apos, bpos, glb, dla, dlb, scr, tgap);
+        else if (i > 0) { sp_calscr<KIND>(P, sp, ni, ni, apos, bpos, glb, dla, dlb, scr, tgap); sp_calscr<KIND>(P, sp, i, 0, apos, bpos, glb, dla, dlb, scr, tgap); }
+        else { sp_calscr<KIND>(P, sp, mi, mi, apos, bpos, glb, dla, dlb, scr, tgap); sp_calscr<KIND>(P, sp, 0, -i, apos, bpos, glb, dla, dlb, scr, tgap); }
+        m = skl[k].x; n = skl[k].y;
+    }
+    scr += tgap * (KIND == 1 ? P.weighted_gop : P.basic_gop);                   // wgop(tgap, 0)
+    out[0] = scr / sp.vab;                                                       // rescale
+    out[1] = tgap / sp.vab;
+}
+extern "C" __global__ void __launch_bounds__(64)
+g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const int2 *skl, const int *skl_off, const int *nskl,
+                   double *out, int *status)
+{
+    const int ip = blockIdx.x;
+    if (ip >= nprob || threadIdx.x != 0) return;
+    const DevProb &P = probs[ip];
+    out[2 * ip] = 0; out[2 * ip + 1] = 0;
+    if (P.kind < 0) { status[ip] = -1; return; }
+    if (P.kind == 3 || P.noll != 2) { status[ip] = -2; return; }                // naive units / Gep1st: not on this path
+    if (nskl[ip] < 2) { status[ip] = -1; return; }
+    const int2 *s = skl + skl_off[ip];
+    if (P.kind == 0) sp_calcskl<0>(P, sp[ip], s, nskl[ip], out + 2 * ip);
+    else if (P.kind == 1) sp_calcskl<1>(P, sp[ip], s, nskl[ip], out + 2 * ip);
+    else sp_calcskl<2>(P, sp[ip], s, nskl[ip], out + 2 * ip);
+    status[ip] = 0;
+}

@@ -159,3 +159,40 @@ def HomScore(ctx, pwd: PwdM):
     if rc:
         raise G2GError("g2g_homscore rc=%d: %s" % (rc, last_error()))
     return scr.value, (rr[0], rr[1])
+
+
+def _skl_arrays(skls):
+    n = len(skls)
+    bufs = []
+    ptrs = (C.POINTER(_abi.Skl) * n)()
+    cnt = (C.c_int * n)()
+    for i, s in enumerate(skls):
+        s = np.ascontiguousarray(s, np.int32).reshape(-1, 2)
+        buf = (_abi.Skl * max(1, len(s)))()
+        C.memmove(buf, s.ctypes.data, s.nbytes)
+        bufs.append(buf)
+        ptrs[i] = C.cast(buf, C.POINTER(_abi.Skl))
+        cnt[i] = len(s)
+    return bufs, ptrs, cnt
+
+
+def spparams(pwd: PwdM) -> "_abi.SpParams":
+    sp = _abi.SpParams()
+    rc = lib().g2g_pwdm_spparams(pwd._h, C.byref(sp))
+    if rc:
+        raise G2GError("g2g_pwdm_spparams rc=%d" % rc)
+    return sp
+
+
+def calcSpScore_batch(ctx, pwds: Sequence[PwdM], skls):
+    """<-> PreSpScore::calcSpScore(GsI) (reference src/fspscore.cc:584): [(fstat.val, fstat.gap, status)] of the
+    alignments the standardised skeletons describe."""
+    L = lib()
+    n = len(pwds)
+    hs = (C.c_void_p * n)(*[p._h for p in pwds])
+    bufs, ptrs, cnt = _skl_arrays(skls)
+    out = (_abi.Fstat * max(1, n))()
+    rc = L.g2g_spscore_batch(ctx._h, n, hs, ptrs, cnt, out)
+    if rc:
+        raise G2GError("g2g_spscore_batch rc=%d: %s" % (rc, last_error()))
+    return [(out[i].val, out[i].gap, out[i].status) for i in range(n)]

@@ -22,6 +22,9 @@ def load():
                                            _abi.c_f64p, C.POINTER(C.c_int8)]
     L.g2g_oracle_homscore.restype = C.c_double
     L.g2g_oracle_homscore.argtypes = [C.POINTER(_abi.Problem), C.POINTER(C.c_long)]
+    L.g2g_oracle_spscore.restype = C.c_int
+    L.g2g_oracle_spscore.argtypes = [C.POINTER(_abi.Problem), C.POINTER(_abi.SpParams), C.POINTER(_abi.Skl), C.c_int,
+                                     C.POINTER(C.c_double)]
     L.g2g_oracle_stdskl.restype = C.POINTER(_abi.Skl)
     L.g2g_oracle_stdskl.argtypes = [C.POINTER(_abi.Skl), C.c_int, C.POINTER(C.c_int)]
     L.g2g_oracle_free.argtypes = [C.c_void_p]
@@ -56,3 +59,14 @@ def stdskl(L, trace: np.ndarray) -> np.ndarray:
     out = skl_to_np(p, nout.value)
     L.g2g_oracle_free(p)
     return out
+
+
+def spscore(L, holder, sp: "_abi.SpParams", skl: np.ndarray):
+    """SpScore::calcSkl on a standardised skeleton ((n,2) int array): (rc, val, gap)."""
+    n = len(skl)
+    buf = (_abi.Skl * n)()
+    for i in range(n):
+        buf[i].m, buf[i].n = int(skl[i][0]), int(skl[i][1])
+    out = (C.c_double * 2)()
+    rc = L.g2g_oracle_spscore(C.byref(holder.c), C.byref(sp), buf, n, out)
+    return rc, out[0], out[1]

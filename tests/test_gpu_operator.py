@@ -50,6 +50,44 @@ def test_homscore_matches_reference_goldens(ctx):
     assert not bad, bad
 
 
+def test_calcspscore_matches_reference_goldens(ctx):
+    """f1: PreSpScore::calcSpScore on the GPU, through level 1 (own PwdM scalars, own align2 skeleton), against the
+    reference's Gsinfo.fstat -- bit-exact val and gap; modes outside the path report G2G_ERR_MODE."""
+    pws, want, names = [], [], []
+    for f in GOLD:
+        d = dict(np.load(f))
+        alp = params_from_golden(d)
+        ga, gb = groups_from_golden(d, alp)
+        pws.append(op.PwdM([ga, gb], alp)); want.append(d); names.append(os.path.basename(f))
+    res = op.align2_batch(ctx, pws)
+    fs = op.calcSpScore_batch(ctx, pws, [skl for (_, skl, _) in res])
+    n_ok = 0
+    for name, d, (val, gap, st) in zip(names, want, fs):
+        if int(d["alnmode"][0]) in (6, 8, 9) and int(d["Noll"][0]) == 2:
+            assert st == 0, name
+            assert val == d["fstat_val"][0] and gap == d["fstat_gap"][0], (name, val, float(d["fstat_val"][0]))
+            n_ok += 1
+        else:
+            assert st == -2, name
+    assert n_ok >= 20
+
+
+def test_calcspscore_sweep_vs_oracle(ctx):
+    """... and on a sweep of larger divisions against the CPU restatement."""
+    fam = make_family(40, 160, 23)
+    sw = sweep.Sweep(fam, op.AlnParam())
+    res = op.align2_batch(ctx, sw.pwds)
+    fs = op.calcSpScore_batch(ctx, sw.pwds, [skl for (_, skl, _) in res])
+    L = oraclelib.load()
+    for pw, (scr, skl, st), (val, gap, fst) in zip(sw.pwds, res, fs):
+        class H:
+            c = pw.problem
+        rc, oval, ogap = oraclelib.spscore(L, H, op.spparams(pw), skl)
+        assert (fst == 0) == (rc == 0)
+        if rc == 0:
+            assert val == oval and gap == ogap
+
+
 def test_sweep_batch_vs_oracle_and_properties(ctx):
     """A whole (small) sweep as one batch: every DP bit-equal to the oracle; skeleton properties hold."""
     fam = make_family(40, 160, 21)

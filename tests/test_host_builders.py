@@ -56,6 +56,9 @@ def test_builders_match_reference(path):
     assert q.noll == d["Noll"][0] and q.codonk1 == d["codonk1"][0]
     assert (q.lw, q.up) == (d["wdw_lw"][0], d["wdw_up"][0])
     assert q.basic_gop == d["Basic_GOP"][0] and q.weighted_gop == d["Weighted_GOP"][0]
+    sp = op.spparams(pw)                               # scalars of PreSpScore::calcSpScore (f1)
+    assert sp.vab == d["Vab"][0] and sp.basic_gep == d["BasicGEP"][0]
+    assert sp.diffu == d["LongGEP"][0] - d["BasicGEP"][0]
     ref = _abi.problem_from_arrays(d).c
     assert q.u2divu1 == ref.u2divu1 and q.v2divv1 == ref.v2divv1 and q.u == ref.u
     for pfx, s in (("a_", q.a), ("b_", q.b)):

@@ -46,3 +46,28 @@ def test_oracle_homscore(L, path):
     s = L.g2g_oracle_homscore(C.byref(h.c), rr)
     assert s == d["homscore"][0]
     assert [rr[0], rr[1]] == d["homscore_rr"].tolist()
+
+
+SP_GOLD = [f for f in GOLD if int(np.load(f)["alnmode"][0]) in (6, 8, 9) and int(np.load(f)["Noll"][0]) == 2]
+
+
+def sp_from_golden(d):
+    return _abi.SpParams(float(d["Vab"][0]), float(d["BasicGEP"][0]), float(d["LongGEP"][0]) - float(d["BasicGEP"][0]))
+
+
+@pytest.mark.parametrize("path", SP_GOLD, ids=[os.path.basename(p)[:-4] for p in SP_GOLD])
+def test_oracle_spscore(L, path):
+    """f1: SpScore::calcSkl + rescale along the reference's own skeleton == the reference's Gsinfo.fstat (bit-exact)."""
+    d = dict(np.load(path))
+    h = _abi.problem_from_arrays(d)
+    rc, val, gap = oraclelib.spscore(L, h, sp_from_golden(d), d["align2_skl"])
+    assert rc == 0
+    assert val == d["fstat_val"][0] and gap == d["fstat_gap"][0]
+
+
+def test_oracle_spscore_scope(L):
+    assert len(SP_GOLD) >= 20
+    other = [f for f in GOLD if f not in SP_GOLD]
+    d = dict(np.load(other[0]))
+    rc, _, _ = oraclelib.spscore(L, _abi.problem_from_arrays(d), sp_from_golden(d), d["align2_skl"])
+    assert rc == -2                                  # naive units / long-gap bookkeeping: G2G_ERR_MODE
