@@ -174,6 +174,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # f1 (not part of the metric): PreSpScore::calcSpScore of every new alignment on the resident batch
+    sp_ms = None
+    try:
+        sps = [op.spparams(p) for p in holders]
+        t1 = time.perf_counter()
+        fst = batch.spscore(sps, [skl for (_, skl, _) in out])
+        sp_ms = 1e3 * (time.perf_counter() - t1)
+        sp_bad = sum(1 for (_, _, st) in fst if st != 0)
+    except Exception as e:                                   # never let the extra row break the benchmark line
+        sp_ms, sp_bad = None, str(e)
     bad = [mine[i] for i, (scr, skl, st) in enumerate(out) if st != 0 or len(skl) < 2]
     my_cells = int(sum(sw.cells[k] for k in mine))
     total_cells = int(sw.cells.sum())
@@ -208,6 +218,9 @@ def main():
                          "kernel": "g2g_v3r_hf2 + g2g_v2_pf2 (persistent tile kernels, concurrent) incl. g2g_v2_rowoff/prologue/sim kernels", "kernel_ms": fwd_avg_ms, "traceback_ms": tb_ms / args.steps,
                          "bytes_per_cell": BYTES_PER_CELL[noll], "cells_per_launch": my_cells},
         }
+        if sp_ms is not None:
+            line["config"]["calcSpScore_ms"] = sp_ms
+            line["config"]["calcSpScore_failed"] = sp_bad
         if line_tag:
             line["config"]["note"] = line_tag
             line["config"]["workload"] = line["config"]["workload"].replace("proteins", "DNA sequences").replace(" aa ", " nt ")

@@ -104,6 +104,27 @@ class Batch:
             raise G2GError("g2g_batch_fetch rc=%d: %s" % (rc, last_error()))
         return Context._results(res, self.n)
 
+    def spscore(self, sps, skls):
+        """f1 on the resident batch: PreSpScore::calcSpScore of problem i along skeleton skls[i] ((n,2) int arrays),
+        sps[i] = _abi.SpParams.  Returns [(val, gap, status)]."""
+        n = self.n
+        sp = (_abi.SpParams * max(1, n))(*sps)
+        bufs = []
+        ptrs = (C.POINTER(_abi.Skl) * max(1, n))()
+        cnt = (C.c_int * max(1, n))()
+        for i, s in enumerate(skls):
+            s = np.ascontiguousarray(s, np.int32).reshape(-1, 2)
+            buf = (_abi.Skl * max(1, len(s)))()
+            C.memmove(buf, s.ctypes.data, s.nbytes)
+            bufs.append(buf)
+            ptrs[i] = C.cast(buf, C.POINTER(_abi.Skl))
+            cnt[i] = len(s)
+        out = (_abi.Fstat * max(1, n))()
+        rc = lib().g2g_batch_spscore(self._h, sp, ptrs, cnt, out)
+        if rc:
+            raise G2GError("g2g_batch_spscore rc=%d: %s" % (rc, last_error()))
+        return [(out[i].val, out[i].gap, out[i].status) for i in range(n)]
+
     def free(self):
         if self._h:
             lib().g2g_batch_free(self._h)
