@@ -227,7 +227,7 @@ def main():
         if args.shard_of > 1 and world == 1:
             line["rehearsal"] = "rank 0's share of a %d-rank job on one GPU: %d divisions, %.4g cells, %.1f ms per step" % (
                 args.shard_of, len(mine), my_cells, ms_per_step)
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:                # (rank 0 at N = 1 only)
             line["cpu_baseline"] = cpu_baseline(sw, args.cpu_seconds, {int(k): float(o[0]) for k, o in zip(mine, out)})
             if line["cpu_baseline"]["value"]:
                 line["config"]["gpu_over_cpu_1core"] = value / line["cpu_baseline"]["value"]
