@@ -759,13 +759,62 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
     return G2G_OK;
 }
 
+// upper estimate of the arena bytes one problem takes in a batch (inputs + state + trace + column scores)
+static size_t problem_bytes(const g2g_problem *p)
+{
+    if (check_problem(p)) return 4096;
+    const int al = p->a.left, ar = p->a.right, bl = p->b.left, br = p->b.right;
+    long long cells = 0;
+    int tmax = 1;
+    for (int dd = al + bl; dd <= (ar - 1) + (br - 1); ++dd) {
+        int mlo, mhi;
+        diag_rows(dd, al, ar, bl, br, p->lw, p->up, &mlo, &mhi);
+        const int c = mhi - mlo + 1;
+        if (c > 0) cells += c;
+        if (c > tmax) tmax = c;
+    }
+    size_t bytes = (size_t) (ar - al + br - bl + 2) * tmax + 8 * (size_t) cells;          // trace + column scores
+    const g2g_side *sd[2] = {&p->a, &p->b};
+    for (int k = 0; k < 2; ++k) {
+        const size_t cols = (size_t) sd[k]->len + 2;
+        bytes += cols * sd[k]->many * (kind_of(p->alnmode) == 3 ? 17 : 1) + cols * 24 + cols * 8 * (size_t) (sd[k]->nelm > 0 ? sd[k]->nelm : 0);
+        if (sd[k]->has_gfq) for (int v = 0; v < 3; ++v) bytes += 12 * (size_t) sd[k]->gfq.off[v][sd[k]->len + 1] + 4 * cols;
+    }
+    const size_t lists = 8 * (size_t) ((p->a.has_gfq ? p->a.gfq.hetero + 1 : p->a.many) + (p->b.has_gfq ? p->b.gfq.hetero + 1 : p->b.many));
+    bytes += (size_t) (p->up - p->lw + 3) * 7 * (16 + lists);                                   // v1 state rows
+    bytes += (size_t) (p->b.len + 3 + ar - al + 3) * 9 * (16 + lists / 2 + 16);                 // strip / block boundary records
+    bytes += 8 * (size_t) (ar - al + 2) + 8 * (size_t) (ar - al + br - bl + 8) + 4096;
+    return bytes;
+}
+
+// alignC<recd_t> for n problems.  Batches are cut so that one arena stays below a budget (default: 70 % of the free
+// device memory, capped by G2G_ARENA_LIMIT_GB): a sweep over thousands of large divisions (BASELINE configs[4]:
+// 4093 divisions of a 2048 x 4096 nt family) does not fit 288 GB at once.
 extern "C" int g2g_forward_batch(g2g_ctx *ctx, int n, const g2g_problem *const *prob, g2g_result *res)
 {
-    g2g_batch *b = 0;
-    int rc = g2g_batch_prepare(ctx, n, prob, &b);
-    if (rc) return rc;
-    rc = g2g_batch_run(b);
-    if (!rc) rc = g2g_batch_fetch(b, res);
-    g2g_batch_free(b);
-    return rc;
+    if (!ctx || n < 0 || (n && (!prob || !res))) return G2G_ERR_ARG;
+    if (!ctx->ok) return G2G_ERR_NODEVICE;
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t budget = (size_t) 64 << 30;
+    { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr) budget = std::min(budget, (size_t) (0.7 * (double) fr)); }
+    if (const char *e = getenv("G2G_ARENA_LIMIT_GB")) { const double g = atof(e); if (g > 0) budget = (size_t) (g * (double) ((size_t) 1 << 30)); }
+    int lo = 0;
+    while (lo < n) {
+        size_t acc = 0;
+        int hi = lo;
+        while (hi < n) {
+            const size_t pb = problem_bytes(prob[hi]);
+            if (hi > lo && acc + pb > budget) break;
+            acc += pb; ++hi;
+        }
+        g2g_batch *b = 0;
+        int rc = g2g_batch_prepare(ctx, hi - lo, prob + lo, &b);
+        if (rc) return rc;
+        rc = g2g_batch_run(b);
+        if (!rc) rc = g2g_batch_fetch(b, res + lo);
+        g2g_batch_free(b);
+        if (rc) return rc;
+        lo = hi;
+    }
+    return G2G_OK;
 }

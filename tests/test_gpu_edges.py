@@ -74,3 +74,13 @@ def test_bad_arguments_are_reported_per_problem(ctx):
 
 def test_empty_batch(ctx):
     assert ctx.forward_batch([]) == []
+
+
+def test_batches_are_cut_to_the_memory_budget(ctx, monkeypatch):
+    """A tiny arena budget forces g2g_forward_batch to run the goldens in many chunks: same results."""
+    ds = [dict(np.load(f)) for f in GOLD]
+    hs = [_abi.problem_from_arrays(d) for d in ds]
+    monkeypatch.setenv("G2G_ARENA_LIMIT_GB", "0.002")
+    res = ctx.forward_batch(hs)
+    for d, (scr, cells, tr, st) in zip(ds, res):
+        assert st == 0 and scr == d["scr"][0] and np.array_equal(tr, d["vmf_trace"])
