@@ -117,6 +117,7 @@ struct g2g_batch {
     V4Lds v4lds[4];                 // LDS plan of the v4 (_pf, 8 lanes per cell) variants
     int v4_cols;
     int v2_cols;
+    int v2_threads;                 // workgroup size of the v2 kernels: 256 (32-row strips) or 128 (16-row strips)
     int v3_cols;                    // columns per v3 tile
     int *d_flags;                   // [0..15] queue heads, [16..19] incident report, [20..] tile-completion flags (generation numbers)
     int nflags, gen;
@@ -125,10 +126,10 @@ struct g2g_batch {
 };
 
 // LDS footprint of g2g_forward_kernel_v2 for one problem (see V2Geom): (slots * R + extras) records
-static size_t v2_lds_bytes(int kind, int noll, int capa, int capb, int mla, int mlb)
+static size_t v2_lds_bytes(int kind, int noll, int capa, int capb, int mla, int mlb, int threads = G2G_V2_THREADS)
 {
     const size_t recsz = (16 + 4 * (size_t) (capa + (kind == 2 ? capb : 0)) + 15) & ~(size_t) 15;
-    const size_t R = G2G_V2_THREADS / 8;
+    const size_t R = threads / 8;
     const size_t lists = (size_t) 12 * 3 * (R * mla + (kind == 2 ? (R + 2) * mlb : 0));   // glen i32 + freq f64
     return ((noll == 3 ? 9 : 6) * R + 5) * recsz + 16 * R + lists + 16;
 }
@@ -340,7 +341,12 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             return C;
         };
         b->v3_cols = pick(1, 64, 128, 32, ncu * 4);
-        b->v2_cols = pick(2, G2G_V2_THREADS / 8, G2G_V2_TILE_COLS, 64, ncu * 3);
+        // v2 (_pf): 16-row strips in 2-wave workgroups when the batch offers enough tiles (less barrier idling, 7 % faster
+        // on a full sweep), 32-row strips otherwise (half as many strips on a DP's critical path)
+        b->v2_threads = 128;
+        if (pick(2, 16, 128, 64, ncu * 6) != 128) b->v2_threads = 256;      // (measured crossover: between 1/4 and 1/8 of the bench sweep)
+        if (const char *e = getenv("G2G_V2_THREADS")) { const int t = atoi(e); if (t == 128 || t == 256) b->v2_threads = t; }
+        b->v2_cols = pick(2, b->v2_threads / 8, G2G_V2_TILE_COLS, 64, ncu * (768 / b->v2_threads));
         b->v4_cols = 64;
         if (const char *e = getenv("G2G_V2_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v2_cols = c; }
         if (const char *e = getenv("G2G_V3_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v3_cols = c; }
@@ -395,7 +401,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             else if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_AREG") && (d.kind == 1 || getenv("G2G_V3_PF")) && d.a.maxlist <= G2G_V3_NA &&
                 v3_need(d, p, b->v3_cols, true).total <= (int) V2_LDS_MAX) d.v2_ok = 3;
             else if (!getenv("G2G_FORCE_V2") && (d.kind == 1 || getenv("G2G_V3_PF")) && v3_need(d, p, b->v3_cols).total <= (int) V2_LDS_MAX) d.v2_ok = 2;
-            else if (v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist) + 4 * G2G_V2_THREADS <= V2_LDS_MAX) d.v2_ok = 1;
+            else if (v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist, b->v2_threads) + 4 * b->v2_threads <= V2_LDS_MAX) d.v2_ok = 1;
         }
         if (d.v2_ok) {
             const size_t recsz = (16 + 4 * (size_t) (d.capa + (d.kind == 2 ? d.capb : 0)) + 15) & ~(size_t) 15;
@@ -441,7 +447,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         for (int i = 0; i < n; ++i) {
             const DevProb &d = b->dp[i];
             if (d.kind < 0) continue;
-            if (d.v2_ok) { i2[b->n2++] = i; if (d.v2_ok == 1) b->lds2 = std::max(b->lds2, v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist)); }
+            if (d.v2_ok) { i2[b->n2++] = i; if (d.v2_ok == 1) b->lds2 = std::max(b->lds2, v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist, b->v2_threads)); }
             else i1[b->n1++] = i;
         }
         b->d_idx1 = (int *) (b->d_arena + idx_off);
@@ -463,7 +469,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             b->lds2p = std::max(b->lds2p, 5 * recsz + 64);
             b->v2_maxrows = std::max(b->v2_maxrows, d.a.right - d.a.left);
             const int al = d.a.left, ar = d.a.right, bl_ = d.b.left, br = d.b.right;
-            const int R = d.v2_ok == 5 ? V5_R : d.v2_ok == 4 ? V4_R : d.v2_ok >= 2 ? 64 : G2G_V2_THREADS / 8;
+            const int R = d.v2_ok == 5 ? V5_R : d.v2_ok == 4 ? V4_R : d.v2_ok >= 2 ? 64 : b->v2_threads / 8;
             const int C = d.v2_ok >= 4 ? b->v4_cols : d.v2_ok >= 2 ? b->v3_cols : b->v2_cols;
             const int nstrip = (ar - al + R - 1) / R, nblk = (br - bl_ + C - 1) / C;
             const int var = d.v2_ok >= 4 ? 12 + 2 * (d.v2_ok - 4) + (d.noll == 3 ? 1 : 0) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
@@ -540,11 +546,12 @@ extern "C" int g2g_batch_run(g2g_batch *b)
     if (b->n == 0) return G2G_OK;
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     if (b->n2) {
-        if (b->lds2 + 4 * G2G_V2_THREADS > 64 * 1024) {
-            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_hf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * G2G_V2_THREADS));
-            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_hf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * G2G_V2_THREADS));
-            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_pf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * G2G_V2_THREADS));
-            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_pf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * G2G_V2_THREADS));
+        const int T2 = b->v2_threads;
+        if (b->lds2 + 4 * T2 > 64 * 1024) {
+            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_hf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * T2));
+            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_hf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * T2));
+            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_pf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * T2));
+            HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_pf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * T2));
         }
         // row offsets first (tiny), then the boundary chains (single-lane, latency-bound) on a side stream while the
         // score kernel (fully parallel) fills the GPU on the main one
@@ -577,11 +584,11 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             const int cnt = b->var_off[v + 1] - b->var_off[v];
             if (!cnt) continue;
             HIPCHK(hipStreamWaitEvent(ctx->vstream[v], ctx->vev[4], 0));
-            int wpc2 = 8;
+            int wpc2 = 2048 / T2;              // workgroups per CU the grid provides (LDS decides how many are resident)
             if (const char *e = getenv("G2G_V2_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc2 = w; }
             const int grid = std::min(cnt, ncu * wpc2);
-            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] variant %d: %d tiles, grid %d, lds %zu, gen %d\n", v, cnt, grid, b->lds2, b->gen); fflush(stderr); }
-            hipLaunchKernelGGL(v2k[v], dim3(grid), dim3(G2G_V2_THREADS), b->lds2 + 4 * G2G_V2_THREADS, ctx->vstream[v],
+            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] variant %d: %d tiles, grid %d x %d threads, lds %zu, cols %d, gen %d\n", v, cnt, grid, T2, b->lds2, b->v2_cols, b->gen); fflush(stderr); }
+            hipLaunchKernelGGL(v2k[v], dim3(grid), dim3(T2), b->lds2 + 4 * T2, ctx->vstream[v],
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v]), cnt,
                                b->d_flags + v, b->d_flags, b->gen, (int) b->lds2, b->v2_cols);
             HIPCHK(hipGetLastError());
