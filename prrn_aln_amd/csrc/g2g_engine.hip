@@ -130,8 +130,8 @@ static size_t v2_lds_bytes(int kind, int noll, int capa, int capb, int mla, int 
 {
     const size_t recsz = (16 + 4 * (size_t) (capa + (kind == 2 ? capb : 0)) + 15) & ~(size_t) 15;
     const size_t R = threads / 8;
-    const size_t lists = (size_t) 12 * 3 * (R * mla + (kind == 2 ? (R + 2) * mlb : 0));   // glen i32 + freq f64
-    return ((noll == 3 ? 9 : 6) * R + 5) * recsz + 16 * R + lists + 16;
+    const size_t lists = (size_t) 10 * 3 * (R * mla + (kind == 2 ? (R + 2) * mlb : 0)) + 8;   // glen i16 + freq f64
+    return (((noll == 3 ? 9 : 6) * R + 5) * recsz + 16 * R + lists + 16 + 15) & ~(size_t) 15;
 }
 static const size_t V2_LDS_MAX = 160 * 1024;
 

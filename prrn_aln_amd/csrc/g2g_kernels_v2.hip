@@ -49,6 +49,10 @@ __device__ __forceinline__ lu32 *ldla(LRec r) { return (lu32 *) (r.p + 16); }
 __device__ __forceinline__ lu32 *ldlb(LRec r, int capa) { return (lu32 *) (r.p + 16) + capa; }
 // a static GFREQ list cached in LDS
 struct LList { const li32 *glen; const lf64 *freq; };
+// v2 keeps the gap lengths of its LDS list caches as 16 bit (all lengths < 65000 on this path, terminator -1): 2.5 KB per
+// workgroup, which is what lets a sixth 2-wave workgroup fit on a CU
+typedef LDS short li16;
+struct LList16 { const li16 *glen; const lf64 *freq; };
 
 __device__ __forceinline__ void team_sync()
 {   // lanes of a team live in one wave: ordering LDS traffic between phases is a compiler matter only
@@ -350,7 +354,7 @@ struct CellSrc { LRec hd, hu, gu, g2u, hl, fl, f2l; };   // records the cell rea
 struct CellDst { LRec h, g, g2, f, f2; };                 // records it writes
 
 template <int KIND, bool NOLL3>
-__device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList> &L_, int m, int n, int lane,
+__device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList16> &L_, int m, int n, int lane,
                         const CellSrc &S_, const CellDst &D_, bool do_vert, bool do_hori, uint8_t *tr,
                         double dab, double pua, double pub
 #ifdef G2G_V2_STAMP
@@ -362,7 +366,7 @@ __device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList
     const int capa = G.capa;
     // private VALUE copies: the per-lane operand selects below pick among these; selecting among members of a struct
     // that lives behind a reference keeps the whole struct in scratch memory (it was: 378 GB of scratch writes per sweep)
-    CellLists<LList> L; L.as = L_.as; L.at = L_.at; L.ar = L_.ar; L.bs = L_.bs; L.bt = L_.bt; L.br = L_.br;
+    CellLists<LList16> L; L.as = L_.as; L.at = L_.at; L.ar = L_.ar; L.bs = L_.bs; L.bt = L_.bt; L.br = L_.br;
     CellSrc S; S.hd = S_.hd; S.hu = S_.hu; S.gu = S_.gu; S.g2u = S_.g2u; S.hl = S_.hl; S.fl = S_.fl; S.f2l = S_.f2l;
     CellDst D; D.h = D_.h; D.g = D_.g; D.g2 = D_.g2; D.f = D_.f; D.f2 = D_.f2;
     // ---- phase A: one independent cost per lane.  Lanes of a wave that take different branches are
@@ -377,8 +381,8 @@ __device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList
     double r = 0;
     if (KIND == 2) {
         const bool aside = (jk == 0 || jk == 2);        // merge a's s-list against b's t/r list, or the mirror
-        const LList cf = aside ? L.as : L.bs;
-        const LList df = (jk == 0) ? L.bt : (jk == 1) ? L.at : (jk == 2) ? L.br : L.ar;
+        const LList16 cf = aside ? L.as : L.bs;
+        const LList16 df = (jk == 0) ? L.bt : (jk == 1) ? L.at : (jk == 2) ? L.br : L.ar;
         const lu32 *dlc = aside ? ldla(rc) : ldlb(rc, capa);
         const lu32 *dld = aside ? ldlb(rc, capa) : ldla(rc);
         if (on) r = p_newgap4(cf, dlc, df, dld) * P.basic_gop;
@@ -459,7 +463,7 @@ __device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList
     const LRec fs = f_from_h ? S.hl : S.fl, fs2 = f2_from_h ? S.hl : S.f2l;
     lu32 *const nul = (lu32 *) 0;
     {   // newdelta jobs (one call, per-lane operands), then incdelta jobs (one call)
-        lu32 *d1 = nul, *d2 = nul; const lu32 *sp = nul; LList df = L.at; bool go = false;
+        lu32 *d1 = nul, *d2 = nul; const lu32 *sp = nul; LList16 df = L.at; bool go = false;
         if (KIND == 2) {
             switch (lane) {
             case 0: go = win == 0; d1 = ldla(D.h); sp = ldla(S.hd); break;
@@ -520,12 +524,12 @@ __device__ void v2_cell(const DevProb &P, const V2Geom &G, const CellLists<LList
 }
 
 // copy one static list (with its terminator) from the HBM pool into an LDS slot, `nl` lanes sharing it
-__device__ __forceinline__ void list_g2l(li32 *gl, lf64 *fr, const DevSide &s, int view, int pos, int lane, int nl)
+__device__ __forceinline__ void list_g2l(li16 *gl, lf64 *fr, const DevSide &s, int view, int pos, int lane, int nl)
 {
     const int o = s.off[view][pos + 1], e = s.off[view][pos + 2];
     const int *sg = s.glen[view] + o;
     const double *sf = s.freq[view] + o;
-    for (int k = lane; k < e - o; k += nl) { gl[k] = sg[k]; fr[k] = sf[k]; }
+    for (int k = lane; k < e - o; k += nl) { gl[k] = (short) sg[k]; fr[k] = sf[k]; }
 }
 
 // ---- a wave-uniform private copy of the DP descriptor -------------------------------------------------
@@ -595,8 +599,8 @@ __device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nst
     lchar *q = lds + R * (G.nslot * G.recsz + 16) + EX_N * G.recsz;
     lf64 *afreq = (lf64 *) q;            q += sizeof(double) * (size_t) R * 3 * mla;
     lf64 *bfreq = (lf64 *) q;            q += sizeof(double) * (size_t) RC * 3 * mlb;
-    li32 *aglen = (li32 *) q;            q += sizeof(int) * (size_t) R * 3 * mla;
-    li32 *bglen = (li32 *) q;
+    li16 *aglen = (li16 *) q;            q += sizeof(short) * (size_t) R * 3 * mla;
+    li16 *bglen = (li16 *) q;
     const size_t rbuf = (size_t) P.v2_rowstride * G.ndw;
     const int bprev = (ti + 2) % 3, bcur = ti % 3;
     const unsigned *rowHp = (const unsigned *) P.v2_rowH + bprev * rbuf, *rowGp = (const unsigned *) P.v2_rowG + bprev * rbuf;
@@ -631,9 +635,9 @@ __device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nst
         }
     }
     // this row's static lists -> LDS (they serve every cell of the row)
-    CellLists<LList> L;
+    CellLists<LList16> L;
     {
-        li32 *ag = aglen + (size_t) team * 3 * mla;
+        li16 *ag = aglen + (size_t) team * 3 * mla;
         lf64 *af = afreq + (size_t) team * 3 * mla;
         if (row_ok) for (int v = 0; v < 3; ++v) list_g2l(ag + v * mla, af + v * mla, a, v, m, lane, TEAM);
         L.as.glen = ag; L.as.freq = af;
@@ -652,7 +656,7 @@ __device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nst
     if (KIND == 2 && pf_tid >= 0 && pf_tid < 3 * TEAM) {   // column ring: column cbase for step 0
         const int v = pf_view;
         const int o = pf_off[cbase + 1], e = pf_off[cbase + 2];
-        for (int k = lane; k < e - o; k += TEAM) { bglen[(size_t) v * mlb + k] = pf_glen[o + k]; bfreq[(size_t) v * mlb + k] = pf_freq[o + k]; }
+        for (int k = lane; k < e - o; k += TEAM) { bglen[(size_t) v * mlb + k] = (short) pf_glen[o + k]; bfreq[(size_t) v * mlb + k] = pf_freq[o + k]; }
     }
     // per-row constants and one-step-ahead register pipelines (column score, b's column thickness,
     // and -- for the strip's first row -- the upper neighbours' records): nothing that comes from HBM is
@@ -700,7 +704,7 @@ __device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nst
             const bool do_vert = m > a.left, do_hori = n > b.left;
             if (KIND == 2) {
                 const int slot = rslot;
-                const li32 *bg = bglen + (size_t) slot * 3 * mlb;
+                const li16 *bg = bglen + (size_t) slot * 3 * mlb;
                 const lf64 *bf = bfreq + (size_t) slot * 3 * mlb;
                 L.bs.glen = bg; L.bs.freq = bf;
                 L.bt.glen = bg + mlb; L.bt.freq = bf + mlb;
@@ -807,11 +811,11 @@ __device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nst
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = lane + j * TEAM;
-                if (k < pf_n) { bglen[pf_base + k] = pf_g[j]; bfreq[pf_base + k] = pf_f[j]; }
+                if (k < pf_n) { bglen[pf_base + k] = (short) pf_g[j]; bfreq[pf_base + k] = pf_f[j]; }
             }
             if (pf_n > 4 * TEAM) {                          // (lists longer than 32 entries: straight copy)
                 const int pos = cbase + s + 1, o = pf_off[pos + 1];
-                for (int k = lane + 4 * TEAM; k < pf_n; k += TEAM) { bglen[pf_base + k] = pf_glen[o + k]; bfreq[pf_base + k] = pf_freq[o + k]; }
+                for (int k = lane + 4 * TEAM; k < pf_n; k += TEAM) { bglen[pf_base + k] = (short) pf_glen[o + k]; bfreq[pf_base + k] = pf_freq[o + k]; }
             }
         }
         if (++rslot == RC) rslot = 0;
