@@ -118,6 +118,7 @@ struct g2g_batch {
     int v4_cols;
     int v2_cols;
     int v2_threads;                 // workgroup size of the v2 kernels: 256 (32-row strips) or 128 (16-row strips)
+    int v3_sweep;                   // v3r (_hf): strips as a pipeline with progress counters (one tile per strip)
     int v3_cols;                    // columns per v3 tile
     int *d_flags;                   // [0..15] queue heads, [16..19] incident report, [20..] tile-completion flags (generation numbers)
     int nflags, gen;
@@ -350,6 +351,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         b->v4_cols = 64;
         if (const char *e = getenv("G2G_V2_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v2_cols = c; }
         if (const char *e = getenv("G2G_V3_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v3_cols = c; }
+        b->v3_sweep = getenv("G2G_V3_SWEEP") ? atoi(getenv("G2G_V3_SWEEP")) : 1;
         if (const char *e = getenv("G2G_V4_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v4_cols = c; }
     }
     // index lists for the two forward kernels (filled below, once eligibility is known)
@@ -470,7 +472,8 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             b->v2_maxrows = std::max(b->v2_maxrows, d.a.right - d.a.left);
             const int al = d.a.left, ar = d.a.right, bl_ = d.b.left, br = d.b.right;
             const int R = d.v2_ok == 5 ? V5_R : d.v2_ok == 4 ? V4_R : d.v2_ok >= 2 ? 64 : b->v2_threads / 8;
-            const int C = d.v2_ok >= 4 ? b->v4_cols : d.v2_ok >= 2 ? b->v3_cols : b->v2_cols;
+            const bool swp3 = d.v2_ok == 3 && d.kind == 1 && b->v3_sweep;          // one tile per strip, pipelined (kind 1 only: no column pool)
+            const int C = swp3 ? (1 << 20) : d.v2_ok >= 4 ? b->v4_cols : d.v2_ok >= 2 ? b->v3_cols : b->v2_cols;
             const int nstrip = (ar - al + R - 1) / R, nblk = (br - bl_ + C - 1) / C;
             const int var = d.v2_ok >= 4 ? 12 + 2 * (d.v2_ok - 4) + (d.noll == 3 ? 1 : 0) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
             if (d.v2_ok >= 4) {
@@ -572,7 +575,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         // one launch per tile wavefront: stream order is the dependency between wavefronts
         typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int, int);
         static const v2k_t v2k[4] = {g2g_v2_hf2, g2g_v2_hf3, g2g_v2_pf2, g2g_v2_pf3};
-        typedef void (*v3k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V3Lds, int);
+        typedef void (*v3k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V3Lds, int, int);
         static const v3k_t v3k[8] = {g2g_v3_hf2, g2g_v3_hf3, g2g_v3_pf2, g2g_v3_pf3, g2g_v3r_hf2, g2g_v3r_hf3, g2g_v3r_pf2, g2g_v3r_pf3};
         // one persistent launch per variant, each on its own stream (they are independent of each other)
         ++b->gen;
@@ -611,7 +614,8 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v3 variant %d: %d tiles, grid %d, lds %d (rows %d, apool@%d, bpool@%d), cols %d, gen %d\n", v, cnt, grid, LO.total, LO.black, LO.aglen, LO.bglen, b->v3_cols, b->gen); fflush(stderr); }
             hipLaunchKernelGGL(v3k[v], dim3(grid), dim3(64), (size_t) LO.total, vs,
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v + 4]), cnt,
-                               b->d_flags + 4 + v, b->d_flags, b->gen, LO, b->v3_cols);
+                               b->d_flags + 4 + v, b->d_flags, b->gen, LO, (v >= 4 && v < 6 && b->v3_sweep) ? (1 << 20) : b->v3_cols,
+                               (v >= 4 && v < 6 && b->v3_sweep) ? 1 : 0);
             HIPCHK(hipGetLastError());
             if (getenv("G2G_DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v3 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[v & 3], vs));

@@ -88,6 +88,9 @@ __device__ __forceinline__ int dhs_nins(const int g, const DHead &h)
     return (int) (e & 0xFFFFu);
 }
 
+#ifndef G2G_V3_PUBLISH
+#define G2G_V3_PUBLISH 32              // sweep mode: steps between two progress publications of a strip (power of 2)
+#endif
 #ifndef G2G_V3_HF_UNROLL
 #define G2G_V3_HF_UNROLL 16               // _hf merge loops fully unrolled (faster than s_set_gpr_idx indexing); _pf loops stay rolled (code size)
 #endif
@@ -596,8 +599,15 @@ __device__ __forceinline__ void v3_rec_store(unsigned *dst, int capa, int capb, 
 }
 
 template <int KIND, bool NOLL3, int NA>
-__device__ void v3_tile(const DevProb &Pmem, lchar *lds, const V3Lds LO, const int ti, const int tj, const int nsteps, const int C)
+__device__ void v3_tile(const DevProb &Pmem, lchar *lds, const V3Lds LO, const int ti, const int tj, const int nsteps, const int C,
+                        const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0)
 {
+    // SWEEP MODE (prog_self != 0): the tile is a whole strip (C covers the row range) and the dependency on the strip
+    // above is a progress counter instead of tile-completion flags: the strip above publishes, every 32 steps, up to
+    // which corner column its last row's records are final ((generation << 20) | column); this strip waits only
+    // before it stages a column beyond what it has seen published.  Strips of one DP then run as a pipeline, each a
+    // few dozen columns behind its predecessor: no fill/drain per column block, no block-boundary records, and a DP's
+    // critical path is strips x (skew + publish interval) instead of (strips + blocks) x tile.
     DevProb P;
     uni_prob(P, Pmem);
     const DevSide &a = P.a, &b = P.b;
@@ -728,8 +738,33 @@ __device__ void v3_tile(const DevProb &Pmem, lchar *lds, const V3Lds LO, const i
             if (wantG) { stage_put(SLOT_G(col), 3 + (col & 1), rg); if (NOLL3) stage_put(SLOT_G2(col), 5 + (col & 1), rg2); }
         }
     };
+    int avail = prog_up ? 0 : 0x7fffffff;                    // corner columns of the strip above known to be final
+    const int penc = (pgen & 0x7FF) << 20;
+    auto need = [&](const int col) {                       // wave-uniform: every lane polls, nobody branches alone
+        const int want = penc | (col < 0xFFFFF ? col : 0xFFFFF);
+        if (prog_up && want > avail) {
+            int it = 0;
+            for (; it < G2G_SPIN_MAX; ++it) {
+                avail = __hip_atomic_load(prog_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (avail >= want) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (it == G2G_SPIN_MAX) { atomicAdd(dbg, 1); dbg[1] = ti; dbg[2] = col; avail = 0x7fffffff; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    auto publish = [&](const int col) {                    // corners <= col of this strip's last row are in HBM
+        if (prog_self) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     if (lane < 28) stsc[lane] = 0;
     team_sync();
+    need(cbase + 1 <= c1 ? cbase + 1 : cbase);
     {
         unsigned rh = 0, rg = 0, rg2 = 0;
         stage_load(cbase, false, rh, rg, rg2);
@@ -789,6 +824,7 @@ __device__ void v3_tile(const DevProb &Pmem, lchar *lds, const V3Lds LO, const i
         if (st_prev) stage_store(n0 + 1, vert0, st_h, st_g, st_g2);
         if (p_act) P.trace[p_tri] = (uint8_t) p_trb;
         if (wr_rows && s > 0) flush_rows(n0 - 1 - llast);
+        if (prog_self && s > 0 && (s & (G2G_V3_PUBLISH - 1)) == 0) publish(n0 - llast);
         // -- hand-over from the row above: what lane t-1 produced one step ago is my upper neighbour, what it
         // produced two steps ago (= my previous upper neighbour) is my diagonal neighbour
         hd = hu;
@@ -817,7 +853,7 @@ __device__ void v3_tile(const DevProb &Pmem, lchar *lds, const V3Lds LO, const i
             if (n + 1 < hi) { sim_nx = simrow[n + 1]; bc_nx = thk_at(b, n + 1)[0]; }
         }
         st_prev = n0 + 1 < hi0 && n0 + 2 <= c1;
-        if (st_prev) stage_load(n0 + 2, vert0, st_h, st_g, st_g2);
+        if (st_prev) { need(n0 + 2); stage_load(n0 + 2, vert0, st_h, st_g, st_g2); }
         RS myH = oH, myG = oG, myG2 = oG2;                 // (the produced records of this step)
         if (active) {
             const bool do_hori = n > b.left;
@@ -877,12 +913,13 @@ __device__ void v3_tile(const DevProb &Pmem, lchar *lds, const V3Lds LO, const i
     }
     if (p_act) P.trace[p_tri] = (uint8_t) p_trb;
     if (wr_rows) flush_rows(cbase + nsteps - 1 - llast);
+    publish(0xFFFFF);
 #undef V3_L
 }
 
 #define V3_KERNEL(NAME, KIND, N3, NA, WPE)                                                           \
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))                                                  \
-NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V3Lds LO, int C) \
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))      \
+NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V3Lds LO, int C, int sweep) \
 {                                                                                                   \
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];                                  \
     li32 *s_vals = (li32 *) ((lchar *) g2g_lds + LO.svals);                                         \
@@ -893,10 +930,16 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         __syncthreads();                                                                            \
         if (t >= ntiles) break;                                                                     \
         const V2Tile T = tiles[t];                                                                  \
-        if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t);                         \
-        if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t);                     \
-        if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t);                     \
-        if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t);                       \
+        if (sweep) {      /* strips as a pipeline: progress counters instead of completion flags */ \
+            v3_tile<KIND, N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, 0, T.nsteps, C,       \
+                                  T.dep_up >= 0 ? done + T.dep_up : (const int *) 0, done + T.self, done + 16, gen); \
+            __syncthreads();                                                                        \
+            continue;                                                                               \
+        }                                                                                           \
+        if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t);                        \
+        if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t);                    \
+        if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t);                    \
+        if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t);                      \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                          \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \

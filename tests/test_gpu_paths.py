@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
 CONFIGS = {
     "default": {},
-    "v3r_cols32": {"G2G_V3_COLS": "32"},
+    "v3r_cols32": {"G2G_V3_COLS": "32", "G2G_V3_SWEEP": "0"},
+    "v3r_tiles": {"G2G_V3_SWEEP": "0"},
     "v3lds_all": {"G2G_NO_AREG": "1", "G2G_V3_PF": "1"},
     "v3lds_all_cols32": {"G2G_NO_AREG": "1", "G2G_V3_PF": "1", "G2G_V3_COLS": "32"},
     "v3_pf": {"G2G_V3_PF": "1", "G2G_V3_COLS": "64"},
@@ -73,7 +74,7 @@ FAMILIES = [
 ]
 
 
-@pytest.mark.parametrize("name", ["v3r_cols32", "v3lds_all", "v3_pf", "v4", "v5", "v2", "v2_t128"])
+@pytest.mark.parametrize("name", ["v3r_cols32", "v3r_tiles", "v3lds_all", "v3_pf", "v4", "v5", "v2", "v2_t128"])
 @pytest.mark.parametrize("fam", FAMILIES, ids=[f[0] for f in FAMILIES])
 def test_large_divisions_every_path(ctx, L, monkeypatch, name, fam):
     """Group-vs-rest divisions of a 650-700 column family (many strips and blocks) per forced path."""
