@@ -118,6 +118,7 @@ struct g2g_batch {
     int v4_cols;
     int v2_cols;
     int v2_threads;                 // workgroup size of the v2 kernels: 256 (32-row strips) or 128 (16-row strips)
+    int v2_sweep;                   // v2 (_pf): the same
     int v3_sweep;                   // v3r (_hf): strips as a pipeline with progress counters (one tile per strip)
     int v3_cols;                    // columns per v3 tile
     int *d_flags;                   // [0..15] queue heads, [16..19] incident report, [20..] tile-completion flags (generation numbers)
@@ -352,6 +353,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         if (const char *e = getenv("G2G_V2_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v2_cols = c; }
         if (const char *e = getenv("G2G_V3_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v3_cols = c; }
         b->v3_sweep = getenv("G2G_V3_SWEEP") ? atoi(getenv("G2G_V3_SWEEP")) : 1;
+        b->v2_sweep = getenv("G2G_V2_SWEEP") ? atoi(getenv("G2G_V2_SWEEP")) : 1;
         if (const char *e = getenv("G2G_V4_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v4_cols = c; }
     }
     // index lists for the two forward kernels (filled below, once eligibility is known)
@@ -473,7 +475,8 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             const int al = d.a.left, ar = d.a.right, bl_ = d.b.left, br = d.b.right;
             const int R = d.v2_ok == 5 ? V5_R : d.v2_ok == 4 ? V4_R : d.v2_ok >= 2 ? 64 : b->v2_threads / 8;
             const bool swp3 = d.v2_ok == 3 && d.kind == 1 && b->v3_sweep;          // one tile per strip, pipelined (kind 1 only: no column pool)
-            const int C = swp3 ? (1 << 20) : d.v2_ok >= 4 ? b->v4_cols : d.v2_ok >= 2 ? b->v3_cols : b->v2_cols;
+            const bool swp2 = d.v2_ok == 1 && b->v2_sweep;
+            const int C = (swp3 || swp2) ? (1 << 20) : d.v2_ok >= 4 ? b->v4_cols : d.v2_ok >= 2 ? b->v3_cols : b->v2_cols;
             const int nstrip = (ar - al + R - 1) / R, nblk = (br - bl_ + C - 1) / C;
             const int var = d.v2_ok >= 4 ? 12 + 2 * (d.v2_ok - 4) + (d.noll == 3 ? 1 : 0) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
             if (d.v2_ok >= 4) {
@@ -573,7 +576,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[3], 0));
         if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[g2g] prologue+sim done: %s\n", hipGetErrorString(e3)); fflush(stderr); }
         // one launch per tile wavefront: stream order is the dependency between wavefronts
-        typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int, int);
+        typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int, int, int);
         static const v2k_t v2k[4] = {g2g_v2_hf2, g2g_v2_hf3, g2g_v2_pf2, g2g_v2_pf3};
         typedef void (*v3k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V3Lds, int, int);
         static const v3k_t v3k[8] = {g2g_v3_hf2, g2g_v3_hf3, g2g_v3_pf2, g2g_v3_pf3, g2g_v3r_hf2, g2g_v3r_hf3, g2g_v3r_pf2, g2g_v3r_pf3};
@@ -593,7 +596,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] variant %d: %d tiles, grid %d x %d threads, lds %zu, cols %d, gen %d\n", v, cnt, grid, T2, b->lds2, b->v2_cols, b->gen); fflush(stderr); }
             hipLaunchKernelGGL(v2k[v], dim3(grid), dim3(T2), b->lds2 + 4 * T2, ctx->vstream[v],
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v]), cnt,
-                               b->d_flags + v, b->d_flags, b->gen, (int) b->lds2, b->v2_cols);
+                               b->d_flags + v, b->d_flags, b->gen, (int) b->lds2, b->v2_sweep ? (1 << 20) : b->v2_cols, b->v2_sweep ? 1 : 0);
             HIPCHK(hipGetLastError());
             if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->vstream[v]); fprintf(stderr, "[g2g] variant %d done: %s\n", v, hipGetErrorString(e3)); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[v], ctx->vstream[v]));

@@ -582,8 +582,12 @@ __device__ __forceinline__ void uni_prob(DevProb &d, const DevProb &s)
 //   cbH/cbF/cbF2[row]        each row's H corner and F records at the block's right edge
 //   colH[row]                the left boundary chain
 template <int KIND, bool NOLL3>
-__device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nsteps, const int C)
+__device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nsteps, const int C,
+                        const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0)
 {
+    // SWEEP MODE (prog_self != 0), as in g2g_kernels_v3.hip: the tile is a whole strip; the strip above publishes every
+    // 32 steps up to which corner column its last row's records are in HBM, this strip waits only before its first
+    // team reads beyond what it has seen published.  Everything is executed uniformly by all threads of the workgroup.
     DevProb P;
     uni_prob(P, Pmem);
     const DevSide &a = P.a, &b = P.b;
@@ -670,6 +674,33 @@ __device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nst
     int rslot = (RC - team % RC) % RC;                     // ring slot of column cbase + s - team
     int wslot = 1 % RC;                                    // ring slot of column cbase + s + 1
     const bool stage_regs = G.ndw <= 4 * TEAM;            // record fits 4 dwords per lane (128 B)
+    int avail = prog_up ? 0 : 0x7fffffff;
+    const int penc = (pgen & 0x7FF) << 20;
+    int hi0 = m0 + P.up + 1; if (hi0 > b.right) hi0 = b.right; if (hi0 > c1) hi0 = c1;    // the first team's hi
+    const int tl = ((m0 + R < a.right) ? m0 + R : a.right) - 1 - m0;                          // team of the strip's last row
+    auto need = [&](int col) {
+        if (col > hi0 + 1) col = hi0 + 1;
+        const int want = penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF);
+        if (prog_up && want > avail) {
+            int it = 0;
+            for (; it < G2G_SPIN_MAX; ++it) {
+                avail = __hip_atomic_load(prog_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (avail >= want) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (it == G2G_SPIN_MAX) { atomicAdd(dbg, 1); dbg[1] = ti; dbg[2] = col; avail = 0x7fffffff; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    auto publish = [&](const int col) {                    // (a barrier inside: call it uniformly)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __hip_atomic_store(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    need(cbase + 2);
 #ifdef G2G_V2_STAMP
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
@@ -679,6 +710,8 @@ __device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nst
         STAMP(7)
         const int n = cbase + s - team;
         const bool active = row_ok && n >= lo && n < hi;
+        if (prog_self && s > 0 && (s & 31) == 0) publish(cbase + s - tl);
+        need(cbase + s + 2);
         double sim_nx = 0, bc_nx = 0;
         if (active) {
             if (!have) { sim_cur = simrow[n]; bc_cur = thk_at(b, n)[0]; }
@@ -823,6 +856,7 @@ __device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nst
         STAMP(6)
         __syncthreads();
     }
+    if (prog_self) publish(0xFFFFF);
 #ifdef G2G_V2_STAMP
     if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g2g_stamp_acc[k + (threadIdx.x == 0 ? 0 : 8)], stamp_acc[k]);
 #endif
@@ -919,7 +953,7 @@ __device__ unsigned long long g2g_wait_acc[4];
 // each thread adds (tid == 0) to the queue head, parks its result in LDS, and slot 0 is the tile.
 #define V2_KERNEL(NAME, KIND, N3)                                                                   \
 extern "C" __global__ void __launch_bounds__(G2G_V2_THREADS, G2G_V2_MINWAVES)                         \
-NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, int lds_tile_off, int C) \
+NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, int lds_tile_off, int C, int sweep) \
 {                                                                                                   \
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];                                  \
     li32 *s_vals = (li32 *) ((lchar *) g2g_lds + lds_tile_off);   /* tail of the dynamic LDS */      \
@@ -930,11 +964,17 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         __syncthreads();                                                                            \
         if (t >= ntiles) break;                                                                     \
         const V2Tile T = tiles[t];                                                                  \
+        if (sweep) {      /* strips as a pipeline: progress counters instead of completion flags */ \
+            v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, 0, T.nsteps, C,               \
+                              T.dep_up >= 0 ? done + T.dep_up : (const int *) 0, done + T.self, done + 16, gen); \
+            __syncthreads();                                                                        \
+            continue;                                                                               \
+        }                                                                                           \
         V2_WAIT_T0                                                                                  \
-        if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t);                         \
-        if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t);                     \
-        if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t);                     \
-        if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t);                       \
+        if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t);                        \
+        if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t);                    \
+        if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t);                    \
+        if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t);                      \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                          \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \

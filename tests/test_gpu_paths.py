@@ -30,7 +30,9 @@ CONFIGS = {
     "v5": {"G2G_V5": "1"},
     "v5_cols16": {"G2G_V5": "1", "G2G_V4_COLS": "16"},
     "v2": {"G2G_FORCE_V2": "1"},
-    "v2_t128": {"G2G_FORCE_V2": "1", "G2G_V2_THREADS": "128", "G2G_V2_COLS": "64"},
+    "v2_t128": {"G2G_FORCE_V2": "1", "G2G_V2_THREADS": "128"},
+    "v2_tiles": {"G2G_FORCE_V2": "1", "G2G_V2_SWEEP": "0"},
+    "v2_tiles_t128": {"G2G_FORCE_V2": "1", "G2G_V2_SWEEP": "0", "G2G_V2_THREADS": "128", "G2G_V2_COLS": "64"},
     "v1": {"G2G_FORCE_V1": "1"},
 }
 ALLVARS = sorted({k for c in CONFIGS.values() for k in c})
@@ -74,7 +76,7 @@ FAMILIES = [
 ]
 
 
-@pytest.mark.parametrize("name", ["v3r_cols32", "v3r_tiles", "v3lds_all", "v3_pf", "v4", "v5", "v2", "v2_t128"])
+@pytest.mark.parametrize("name", ["v3r_cols32", "v3r_tiles", "v3lds_all", "v3_pf", "v4", "v5", "v2", "v2_t128", "v2_tiles", "v2_tiles_t128"])
 @pytest.mark.parametrize("fam", FAMILIES, ids=[f[0] for f in FAMILIES])
 def test_large_divisions_every_path(ctx, L, monkeypatch, name, fam):
     """Group-vs-rest divisions of a 650-700 column family (many strips and blocks) per forced path."""
