@@ -102,6 +102,7 @@ struct g2g_batch {
     std::vector<long long> cells;
     std::vector<size_t> out_off;    // per problem: offset of {score, ntrace, otrace} block
     std::vector<int> tcap;
+    size_t out_lo, out_hi;          // the output blocks occupy arena [out_lo, out_hi)
     std::vector<long long> rr1;     // b.left - a.left + b.right - a.right per problem
     char *d_arena;
     size_t arena_bytes, in_bytes;
@@ -423,11 +424,18 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         b->rr1[i] = (long long) (bl_ - al) + (br - ar);
         d.tcap = (ar - al) + (br - bl_) + 4;
         b->tcap[i] = d.tcap;
+    }
+    // outputs of all problems in ONE contiguous region (a single device-to-host copy fetches a whole sweep)
+    b->out_lo = off;
+    for (int i = 0; i < n; ++i) {
+        DevProb &d = b->dp[i];
+        if (d.kind < 0) continue;
         b->out_off[i] = take(sizeof(double) + sizeof(int) * 2 + sizeof(int2) * (size_t) d.tcap);
         d.score = OFF<double>(b->out_off[i]);
         d.ntrace = OFF<int>(b->out_off[i] + sizeof(double));
         d.otrace = OFF<int2>(b->out_off[i] + sizeof(double) + 2 * sizeof(int));
     }
+    b->out_hi = off;
     b->arena_bytes = off + 256;
     hipError_t e = hipMalloc((void **) &b->d_arena, b->arena_bytes);
     if (e != hipSuccess) { g2g_set_error("hipMalloc(arena): %s", hipGetErrorString(e)); delete b; return G2G_ERR_NOMEM; }
@@ -677,25 +685,24 @@ extern "C" int g2g_batch_fetch(g2g_batch *b, g2g_result *res)
     if (!b || !res) return G2G_ERR_ARG;
     g2g_ctx *ctx = b->ctx;
     HIPCHK(hipSetDevice(ctx->device));
-    // outputs of all problems sit between the first and the last out block: fetch per problem (small)
+    std::vector<char> all(b->out_hi - b->out_lo);
+    if (!all.empty()) HIPCHK(hipMemcpy(all.data(), b->d_arena + b->out_lo, all.size(), hipMemcpyDeviceToHost));
     for (int i = 0; i < b->n; ++i) {
         res[i].status = b->status[i];
         res[i].cells = b->cells[i];
         res[i].trace = 0; res[i].ntrace = 0; res[i].score = 0;
         if (b->status[i]) continue;
-        const size_t bytes = sizeof(double) + 2 * sizeof(int) + sizeof(int2) * (size_t) b->tcap[i];
-        std::vector<char> tmp(bytes);
-        HIPCHK(hipMemcpy(tmp.data(), b->d_arena + b->out_off[i], bytes, hipMemcpyDeviceToHost));
-        memcpy(&res[i].score, tmp.data(), sizeof(double));
+        const char *tmp = all.data() + (b->out_off[i] - b->out_lo);
+        memcpy(&res[i].score, tmp, sizeof(double));
         int nt, rr0;
-        memcpy(&nt, tmp.data() + sizeof(double), sizeof(int));
-        memcpy(&rr0, tmp.data() + sizeof(double) + sizeof(int), sizeof(int));
+        memcpy(&nt, tmp + sizeof(double), sizeof(int));
+        memcpy(&rr0, tmp + sizeof(double) + sizeof(int), sizeof(int));
         res[i].rr[0] = rr0;
         res[i].rr[1] = b->rr1[i];
         if (nt < 2 || nt > b->tcap[i]) { res[i].status = G2G_ERR_DEVICE; continue; }
         res[i].ntrace = nt;
         res[i].trace = (g2g_skl *) malloc(sizeof(g2g_skl) * nt);
-        memcpy(res[i].trace, tmp.data() + sizeof(double) + 2 * sizeof(int), sizeof(g2g_skl) * nt);
+        memcpy(res[i].trace, tmp + sizeof(double) + 2 * sizeof(int), sizeof(g2g_skl) * nt);
     }
     return G2G_OK;
 }
