@@ -583,7 +583,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[3], 0));
         if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[g2g] prologue+sim done: %s\n", hipGetErrorString(e3)); fflush(stderr); }
-        // one launch per tile wavefront: stream order is the dependency between wavefronts
+        // persistent tile / strip kernels: one launch per kernel variant, each on its own stream (they are independent)
         typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int, int, int);
         static const v2k_t v2k[4] = {g2g_v2_hf2, g2g_v2_hf3, g2g_v2_pf2, g2g_v2_pf3};
         typedef void (*v3k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V3Lds, int, int);

@@ -1,4 +1,6 @@
-// g2g_kernels_v2.hip -- the production forward kernel for the gap-profile engines (_hf, _pf; Noll 2/3).
+// g2g_kernels_v2.hip -- 8-lanes-per-cell forward kernels for the gap-profile engines (_hf, _pf; Noll 2/3); the
+// default for _pf (the _hf default is g2g_kernels_v3.hip).  Also: the list primitives every later generation uses,
+// the boundary-chain prologue, the column-score kernel and the tile/strip scheduler conventions.
 //
 // Same recurrence, same arithmetic order as g2g_kernels.hip (Fwd2c::forwardB, reference
 // src/fwd2c.h:359-482 + src/fwd2c.cc:152-251 + src/gfreq.cc:493-605), different machine mapping:
