@@ -584,7 +584,7 @@ __device__ __forceinline__ void uni_prob(DevProb &d, const DevProb &s)
 //   cbH/cbF/cbF2[row]        each row's H corner and F records at the block's right edge
 //   colH[row]                the left boundary chain
 template <int KIND, bool NOLL3>
-__device__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nsteps, const int C,
+__device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nsteps, const int C,
                         const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0)
 {
     // SWEEP MODE (prog_self != 0), as in g2g_kernels_v3.hip: the tile is a whole strip; the strip above publishes every
@@ -966,28 +966,29 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         __syncthreads();                                                                            \
         if (t >= ntiles) break;                                                                     \
         const V2Tile T = tiles[t];                                                                  \
-        if (sweep) {      /* strips as a pipeline: progress counters instead of completion flags */ \
-            v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, 0, T.nsteps, C,               \
-                              T.dep_up >= 0 ? done + T.dep_up : (const int *) 0, done + T.self, done + 16, gen); \
-            __syncthreads();                                                                        \
-            continue;                                                                               \
-        }                                                                                           \
+        /* one call site of the tile function (see g2g_kernels_v3.hip) */                           \
+        const int *pu = (sweep && T.dep_up >= 0) ? done + T.dep_up : (const int *) 0;                \
+        int *ps = sweep ? done + T.self : (int *) 0;                                                \
         V2_WAIT_T0                                                                                  \
-        if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t);                        \
-        if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t);                    \
-        if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t);                    \
-        if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t);                      \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                          \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
+        if (!sweep) {                                                                               \
+            if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t);                    \
+            if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t);                \
+            if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t);                \
+            if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t);                  \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                      \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
+        }                                                                                           \
         __syncthreads();                                                                            \
         V2_WAIT_T1                                                                                  \
-        v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, T.tj, T.nsteps, C);               \
+        v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen); \
         V2_WAIT_T2                                                                                  \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                                          \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
-        __hip_atomic_store(done + T.self, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         \
+        if (!sweep) {                                                                               \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                                      \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
+            __hip_atomic_store(done + T.self, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     \
+        }                                                                                           \
     }                                                                                               \
 }
 V2_KERNEL(g2g_v2_hf2, 1, false)

@@ -599,7 +599,7 @@ __device__ __forceinline__ void v3_rec_store(unsigned *dst, int capa, int capb, 
 }
 
 template <int KIND, bool NOLL3, int NA>
-__device__ void v3_tile(const DevProb &Pmem, lchar *lds, const V3Lds LO, const int ti, const int tj, const int nsteps, const int C,
+__device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V3Lds LO, const int ti, const int tj, const int nsteps, const int C,
                         const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0)
 {
     // SWEEP MODE (prog_self != 0): the tile is a whole strip (C covers the row range) and the dependency on the strip
@@ -930,25 +930,27 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         __syncthreads();                                                                            \
         if (t >= ntiles) break;                                                                     \
         const V2Tile T = tiles[t];                                                                  \
-        if (sweep) {      /* strips as a pipeline: progress counters instead of completion flags */ \
-            v3_tile<KIND, N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, 0, T.nsteps, C,       \
-                                  T.dep_up >= 0 ? done + T.dep_up : (const int *) 0, done + T.self, done + 16, gen); \
-            __syncthreads();                                                                        \
-            continue;                                                                               \
+        /* sweep: strips as a pipeline on progress counters; else tiles on completion flags.  ONE call site of the   \
+           tile function, or it is not inlined and its frame lands in scratch memory */                             \
+        const int *pu = (sweep && T.dep_up >= 0) ? done + T.dep_up : (const int *) 0;                \
+        int *ps = sweep ? done + T.self : (int *) 0;                                                \
+        if (!sweep) {                                                                               \
+            if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t);                    \
+            if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t);                \
+            if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t);                \
+            if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t);                  \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                      \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
         }                                                                                           \
-        if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t);                        \
-        if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t);                    \
-        if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t);                    \
-        if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t);                      \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                          \
+        __syncthreads();                                                                            \
+        v3_tile<KIND, N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen); \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
-        v3_tile<KIND, N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, T.tj, T.nsteps, C);       \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
-        __syncthreads();                                                                            \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                                          \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
-        __hip_atomic_store(done + T.self, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         \
+        if (!sweep) {                                                                               \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                                      \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
+            __hip_atomic_store(done + T.self, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     \
+        }                                                                                           \
     }                                                                                               \
 }
 #ifndef G2G_V3R_WPE
