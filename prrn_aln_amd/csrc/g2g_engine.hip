@@ -112,6 +112,8 @@ struct g2g_batch {
     size_t lds2;                    // dynamic LDS bytes of the v2 launch
     size_t lds2p;                   // ... of the v2 prologue launch
     int v2_maxrows;                 // longest a-range among the v2 problems
+    int v2_maxcols;                 // longest b-range ...
+    size_t simtile_lds;             // LDS of the tiled column-score kernel
     V2Tile *d_tiles;                // tiles: per variant (v2: hf2, hf3, pf2, pf3; v3: the same four) a queue ordered by wavefront i + j
     int var_off[17];                // variant v owns tiles [var_off[v], var_off[v+1])
     V3Lds v3lds[8];                 // LDS plan of the v3 variants
@@ -467,7 +469,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     }
     // v2 tiles: (strip i of R rows) x (block j of C columns, C chosen per batch); per kernel variant one queue
     // ordered by wavefront i + j; one completion flag per tile slot (empty slots count as done for ever)
-    b->d_tiles = 0; b->ntiles = 0; b->lds2p = 0; b->v2_maxrows = 1; b->d_flags = 0; b->nflags = 0; b->gen = 0;
+    b->d_tiles = 0; b->ntiles = 0; b->lds2p = 0; b->v2_maxrows = 1; b->v2_maxcols = 1; b->simtile_lds = 0; b->d_flags = 0; b->nflags = 0; b->gen = 0;
     {
         std::vector<std::vector<std::vector<V2Tile> > > q(16);   // [variant][wavefront] -> tiles
         std::vector<int> flags(20, 0);                    // 0-15 queue heads, 16-19 incident report
@@ -480,6 +482,8 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             const size_t recsz = (16 + 4 * (size_t) (d.capa + (d.kind == 2 ? d.capb : 0)) + 15) & ~(size_t) 15;
             b->lds2p = std::max(b->lds2p, 5 * recsz + 64);
             b->v2_maxrows = std::max(b->v2_maxrows, d.a.right - d.a.left);
+            b->v2_maxcols = std::max(b->v2_maxcols, d.b.right - d.b.left);
+            if (d.a.nelm > 0) b->simtile_lds = std::max(b->simtile_lds, (size_t) 8 * SIM_TR * (d.a.nelm - d.a.felm) + (size_t) 8 * SIM_TC * (d.b.felm > 0 ? d.b.felm : 0) + (size_t) SIM_TC * d.b.many + 64);
             const int al = d.a.left, ar = d.a.right, bl_ = d.b.left, br = d.b.right;
             const int R = d.v2_ok == 5 ? V5_R : d.v2_ok == 4 ? V4_R : d.v2_ok >= 2 ? 64 : b->v2_threads / 8;
             const bool swp3 = d.v2_ok == 3 && d.kind == 1 && b->v3_sweep;          // one tile per strip, pipelined (kind 1 only: no column pool)
@@ -578,8 +582,14 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                            (const DevProb *) b->d_probs, (const int *) b->d_idx2);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->vev[3], ctx->vstream[3]));
+        const int simtiled = (!getenv("G2G_NO_SIMTILE") && b->simtile_lds && b->simtile_lds <= 64 * 1024) ? 1 : 0;
+        if (simtiled) {
+            hipLaunchKernelGGL(g2g_v2_sim_tile_kernel, dim3((b->v2_maxcols + SIM_TC - 1) / SIM_TC, (b->v2_maxrows + SIM_TR - 1) / SIM_TR, b->n2), dim3(256),
+                               b->simtile_lds, ctx->stream, (const DevProb *) b->d_probs, (const int *) b->d_idx2);
+            HIPCHK(hipGetLastError());
+        }
         hipLaunchKernelGGL(g2g_v2_sim_kernel, dim3(b->v2_maxrows, b->n2), dim3(256), 0, ctx->stream,
-                           (const DevProb *) b->d_probs, (const int *) b->d_idx2);
+                           (const DevProb *) b->d_probs, (const int *) b->d_idx2, simtiled);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[3], 0));
         if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[g2g] prologue+sim done: %s\n", hipGetErrorString(e3)); fflush(stderr); }

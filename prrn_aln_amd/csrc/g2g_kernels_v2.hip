@@ -904,18 +904,68 @@ g2g_v2_prologue_kernel(const DevProb *probs, const int *idx)
     if (P.kind == 1) v2_prologue<1>(P, lds); else if (P.kind == 2) v2_prologue<2>(P, lds);
 }
 
+__device__ __forceinline__ bool sim_tiled_kind(int k) { return k == 31 || k == 320 || k == 321 || k == 33 || k == 330; }
 // PwdM::sim2 for every in-band cell of the gap-profile DPs (maln.h:160-172, maln2.cc:534-623,1230-1296):
 // independent of the recurrence, so it is computed ahead of it, fully parallel, row-major per DP
 extern "C" __global__ void __launch_bounds__(256)
-g2g_v2_sim_kernel(const DevProb *probs, const int *idx)
+g2g_v2_sim_kernel(const DevProb *probs, const int *idx, int tiled)
 {
     const DevProb &P = probs[idx[blockIdx.y]];
+    if (tiled && sim_tiled_kind(P.sim2_kind)) return;        // done by g2g_v2_sim_tile_kernel
     const int m = P.a.left + blockIdx.x;
     if (m >= P.a.right) return;
     int nlo = m + P.lw; if (nlo < P.b.left) nlo = P.b.left;
     int nhi = m + P.up + 1; if (nhi > P.b.right) nhi = P.b.right;
     double *out = P.v2_sim + P.v2_rowoff[m - P.a.left] - nlo;
     for (int n = nlo + threadIdx.x; n < nhi; n += blockDim.x) out[n] = sim2(P, m, n);
+}
+
+// The same for the scorers of the gap-profile engines -- sim31, sim32i/w (profile of a x residues of b) and sim33/33_n
+// (profile of a . frequency vector of b) -- TILED: a block owns 32 rows x 128 columns, stages the 32 profile rows of a
+// and the 128 columns of b (residues or frequency vectors) in LDS once and computes 4096 scores from there.  The
+// row-by-row kernel above re-reads b's column data for every row: 1.6e9 cells x 184 B through L2 for sim33, which is
+// what made it take 34 ms per sweep.  Expressions and summation order are those of sim2() (g2g_kernels.hip).
+#define SIM_TR 32
+#define SIM_TC 128
+extern "C" __global__ void __launch_bounds__(256)
+g2g_v2_sim_tile_kernel(const DevProb *probs, const int *idx)
+{
+    extern __shared__ __attribute__((aligned(16))) char g2g_lds[];
+    const DevProb &P = probs[idx[blockIdx.z]];
+    const int kind = P.sim2_kind;
+    if (!sim_tiled_kind(kind)) return;                      // (those run in g2g_v2_sim_kernel)
+    const DevSide &a = P.a, &b = P.b;
+    const int m0 = a.left + blockIdx.y * SIM_TR, c0 = b.left + blockIdx.x * SIM_TC;
+    if (m0 >= a.right || c0 >= b.right) return;
+    const int m1 = m0 + SIM_TR < a.right ? m0 + SIM_TR : a.right, c1 = c0 + SIM_TC < b.right ? c0 + SIM_TC : b.right;
+    if (c0 > (m1 - 1) + P.up || c1 - 1 < m0 + P.lw) return;  // tile outside the band
+    const int tid = threadIdx.x;
+    const int na = a.nelm - a.felm;                         // profile part of a's column vectors
+    const bool vecb = kind == 33 || kind == 330;
+    const int nb = vecb ? b.felm : 0;
+    lf64 *Ap = (lf64 *) (lchar *) g2g_lds;                  // [SIM_TR][na]
+    lf64 *Bf = Ap + SIM_TR * na;                            // [SIM_TC][nb]
+    LDS uint8_t *Br = (LDS uint8_t *) (Bf + SIM_TC * nb);   // [SIM_TC][b.many]
+    for (int k = tid; k < (m1 - m0) * na; k += 256) { const int r = k / na, j = k - r * na; Ap[k] = vss_at(a, m0 + r)[a.felm + j]; }
+    if (vecb) for (int k = tid; k < (c1 - c0) * nb; k += 256) { const int c = k / nb, j = k - c * nb; Bf[k] = vss_at(b, c0 + c)[j]; }
+    else for (int k = tid; k < (c1 - c0) * b.many; k += 256) Br[k] = res_at(b, c0)[k];
+    __syncthreads();
+    const int c = tid & (SIM_TC - 1), n = c0 + c;
+    if (n >= c1) return;
+    for (int r = tid >> 7; r < m1 - m0; r += 2) {
+        const int m = m0 + r;
+        int nlo = m + P.lw; if (nlo < b.left) nlo = b.left;
+        int nhi = m + P.up + 1; if (nhi > b.right) nhi = b.right;
+        if (n < nlo || n >= nhi) continue;
+        const lf64 *va = Ap + r * na;
+        double sc = 0;
+        if (kind == 31) sc = va[Br[(size_t) c * b.many]];
+        else if (kind == 320) { const LDS uint8_t *br = Br + (size_t) c * b.many; for (int j = 0; j < b.many; ++j) sc += va[br[j]]; }
+        else if (kind == 321) { const LDS uint8_t *br = Br + (size_t) c * b.many; for (int j = 0; j < b.many; ++j) sc += va[br[j]] * b.weight[j]; }
+        else if (kind == 33) { const lf64 *vb = Bf + (size_t) c * nb; for (int j = 0; j < b.felm; ++j) sc += va[j] * vb[j]; }
+        else { const lf64 *vb = Bf + (size_t) c * nb; const int dc[6] = {0, 1, 2, 3, 5, 9}; for (int j = 0; j < b.felm; ++j) sc += va[dc[j]] * vb[j]; }
+        P.v2_sim[P.v2_rowoff[m - a.left] + (n - nlo)] = sc;
+    }
 }
 
 // self / dep_*: indices into the batch's tile-completion flags (-1: no such neighbour)
