@@ -126,6 +126,7 @@ struct g2g_batch {
     int v3_cols;                    // columns per v3 tile
     int *d_flags;                   // [0..15] queue heads, [16..19] incident report, [20..] tile-completion flags (generation numbers)
     int nflags, gen;
+    std::vector<int> flags0;        // initial contents of d_flags (re-uploaded when the 11-bit generation of the progress counters wraps)
     long long ntiles;
     float fwd_ms, tb_ms;
 };
@@ -538,6 +539,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         for (int v = 0; v < 8; ++v) b->v3lds[v] = v3_layout(need[v].rows_bytes, need[v].ca4, need[v].apool, need[v].bpool, b->v3_cols);
         b->ntiles = (long long) all.size();
         b->nflags = (int) flags.size();
+        b->flags0 = flags;
         if (!all.empty()) {
             hipError_t e2 = hipMalloc((void **) &b->d_tiles, sizeof(V2Tile) * all.size());
             if (e2 == hipSuccess) e2 = hipMemcpy(b->d_tiles, all.data(), sizeof(V2Tile) * all.size(), hipMemcpyHostToDevice);
@@ -600,6 +602,10 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         static const v3k_t v3k[8] = {g2g_v3_hf2, g2g_v3_hf3, g2g_v3_pf2, g2g_v3_pf3, g2g_v3r_hf2, g2g_v3r_hf3, g2g_v3r_pf2, g2g_v3r_pf3};
         // one persistent launch per variant, each on its own stream (they are independent of each other)
         ++b->gen;
+        if ((b->gen & 0x7FF) == 0 && b->d_flags) {             // sweep-mode progress counters carry gen & 0x7FF: start over
+            HIPCHK(hipMemcpyAsync(b->d_flags, b->flags0.data(), sizeof(int) * b->flags0.size(), hipMemcpyHostToDevice, ctx->stream));
+            ++b->gen;
+        }
         HIPCHK(hipMemsetAsync(b->d_flags, 0, 20 * sizeof(int), ctx->stream));           // queue heads, incident report
         HIPCHK(hipEventRecord(ctx->vev[4], ctx->stream));
         int ncu = 256;

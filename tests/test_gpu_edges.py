@@ -84,3 +84,18 @@ def test_batches_are_cut_to_the_memory_budget(ctx, monkeypatch):
     res = ctx.forward_batch(hs)
     for d, (scr, cells, tr, st) in zip(ds, res):
         assert st == 0 and scr == d["scr"][0] and np.array_equal(tr, d["vmf_trace"])
+
+
+def test_many_runs_of_one_batch(ctx):
+    """A resident batch can be run any number of times: the sweep-mode progress counters carry an 11-bit generation,
+    so run across the wrap (2048) and check that the results never change."""
+    names = ["syn24x120_k3", "syn24x120_k1", "prot16x100_ls3_k2", "syn64x96_balanced"]
+    ds = [dict(np.load(os.path.join(os.path.dirname(__file__), "golden", n + ".npz"))) for n in names]
+    hs = [_abi.problem_from_arrays(d) for d in ds]
+    batch = ctx.prepare(hs)
+    for it in range(2100):
+        batch.run()
+        if it in (0, 1, 2046, 2047, 2048, 2049, 2099):
+            for d, (scr, cells, tr, st) in zip(ds, batch.fetch()):
+                assert st == 0 and scr == d["scr"][0] and np.array_equal(tr, d["vmf_trace"]), it
+    batch.free()
