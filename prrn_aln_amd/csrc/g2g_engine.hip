@@ -617,10 +617,15 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             int wpc2 = 2048 / T2;              // workgroups per CU the grid provides (LDS decides how many are resident)
             if (const char *e = getenv("G2G_V2_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc2 = w; }
             const int grid = std::min(cnt, ncu * wpc2);
+            // sweep mode: the kernel argument is the publish interval.  A DP's critical path is columns + strips x
+            // interval: 32 steps when the strips outnumber the resident workgroups several times over (throughput
+            // bound, fewer fences), 16 when they do not (a shard of a sweep: -8 % at 1/8 of the bench sweep).
+            const int res2 = ncu * std::max(1, std::min(wpc2, (int) (V2_LDS_MAX / (b->lds2 + 4 * (size_t) T2))));
+            const int pint2 = !b->v2_sweep ? 0 : b->v2_sweep >= 8 ? b->v2_sweep : cnt < 4 * res2 ? 16 : 32;
             if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] variant %d: %d tiles, grid %d x %d threads, lds %zu, cols %d, gen %d\n", v, cnt, grid, T2, b->lds2, b->v2_cols, b->gen); fflush(stderr); }
             hipLaunchKernelGGL(v2k[v], dim3(grid), dim3(T2), b->lds2 + 4 * T2, ctx->vstream[v],
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v]), cnt,
-                               b->d_flags + v, b->d_flags, b->gen, (int) b->lds2, b->v2_sweep ? (1 << 20) : b->v2_cols, b->v2_sweep ? 1 : 0);
+                               b->d_flags + v, b->d_flags, b->gen, (int) b->lds2, b->v2_sweep ? (1 << 20) : b->v2_cols, pint2);
             HIPCHK(hipGetLastError());
             if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->vstream[v]); fprintf(stderr, "[g2g] variant %d done: %s\n", v, hipGetErrorString(e3)); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[v], ctx->vstream[v]));
@@ -642,7 +647,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             hipLaunchKernelGGL(v3k[v], dim3(grid), dim3(64), (size_t) LO.total, vs,
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v + 4]), cnt,
                                b->d_flags + 4 + v, b->d_flags, b->gen, LO, (v >= 4 && v < 6 && b->v3_sweep) ? (1 << 20) : b->v3_cols,
-                               (v >= 4 && v < 6 && b->v3_sweep) ? 1 : 0);
+                               !(v >= 4 && v < 6 && b->v3_sweep) ? 0 : b->v3_sweep >= 8 ? b->v3_sweep : cnt < 4 * ncu * std::min(wpc, 8) ? 16 : 32);
             HIPCHK(hipGetLastError());
             if (getenv("G2G_DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v3 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[v & 3], vs));

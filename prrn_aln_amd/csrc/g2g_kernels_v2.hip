@@ -585,7 +585,7 @@ __device__ __forceinline__ void uni_prob(DevProb &d, const DevProb &s)
 //   colH[row]                the left boundary chain
 template <int KIND, bool NOLL3>
 __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nsteps, const int C,
-                        const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0)
+                        const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0, const int pint = 32)
 {
     // SWEEP MODE (prog_self != 0), as in g2g_kernels_v3.hip: the tile is a whole strip; the strip above publishes every
     // 32 steps up to which corner column its last row's records are in HBM, this strip waits only before its first
@@ -712,7 +712,7 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         STAMP(7)
         const int n = cbase + s - team;
         const bool active = row_ok && n >= lo && n < hi;
-        if (prog_self && s > 0 && (s & 31) == 0) publish(cbase + s - tl);
+        if (prog_self && s > 0 && (s & (pint - 1)) == 0) publish(cbase + s - tl);
         need(cbase + s + 2);
         double sim_nx = 0, bc_nx = 0;
         if (active) {
@@ -1030,7 +1030,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         }                                                                                           \
         __syncthreads();                                                                            \
         V2_WAIT_T1                                                                                  \
-        v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen); \
+        v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen, sweep); \
         V2_WAIT_T2                                                                                  \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \

@@ -88,9 +88,6 @@ __device__ __forceinline__ int dhs_nins(const int g, const DHead &h)
     return (int) (e & 0xFFFFu);
 }
 
-#ifndef G2G_V3_PUBLISH
-#define G2G_V3_PUBLISH 32              // sweep mode: steps between two progress publications of a strip (power of 2)
-#endif
 #ifndef G2G_V3_HF_UNROLL
 #define G2G_V3_HF_UNROLL 16               // _hf merge loops fully unrolled (faster than s_set_gpr_idx indexing); _pf loops stay rolled (code size)
 #endif
@@ -600,10 +597,10 @@ __device__ __forceinline__ void v3_rec_store(unsigned *dst, int capa, int capb, 
 
 template <int KIND, bool NOLL3, int NA>
 __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V3Lds LO, const int ti, const int tj, const int nsteps, const int C,
-                        const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0)
+                        const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0, const int pint = 32)
 {
     // SWEEP MODE (prog_self != 0): the tile is a whole strip (C covers the row range) and the dependency on the strip
-    // above is a progress counter instead of tile-completion flags: the strip above publishes, every 32 steps, up to
+    // above is a progress counter instead of tile-completion flags: the strip above publishes, every pint (16/32) steps, up to
     // which corner column its last row's records are final ((generation << 20) | column); this strip waits only
     // before it stages a column beyond what it has seen published.  Strips of one DP then run as a pipeline, each a
     // few dozen columns behind its predecessor: no fill/drain per column block, no block-boundary records, and a DP's
@@ -824,7 +821,7 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
         if (st_prev) stage_store(n0 + 1, vert0, st_h, st_g, st_g2);
         if (p_act) P.trace[p_tri] = (uint8_t) p_trb;
         if (wr_rows && s > 0) flush_rows(n0 - 1 - llast);
-        if (prog_self && s > 0 && (s & (G2G_V3_PUBLISH - 1)) == 0) publish(n0 - llast);
+        if (prog_self && s > 0 && (s & (pint - 1)) == 0) publish(n0 - llast);
         // -- hand-over from the row above: what lane t-1 produced one step ago is my upper neighbour, what it
         // produced two steps ago (= my previous upper neighbour) is my diagonal neighbour
         hd = hu;
@@ -943,7 +940,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
         }                                                                                           \
         __syncthreads();                                                                            \
-        v3_tile<KIND, N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen); \
+        v3_tile<KIND, N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen, sweep); \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
         if (!sweep) {                                                                               \
