@@ -108,6 +108,7 @@ struct g2g_batch {
     size_t arena_bytes, in_bytes;
     DevProb *d_probs;
     int *d_idx1, *d_idx2;           // problems run by the v1 / v2 forward kernel
+    int *d_idxp; int np;            // problems whose boundary chains run in the prologue kernel (the others: as queue entries)
     int n1, n2;
     size_t lds2;                    // dynamic LDS bytes of the v2 launch
     size_t lds2p;                   // ... of the v2 prologue launch
@@ -470,10 +471,13 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     }
     // v2 tiles: (strip i of R rows) x (block j of C columns, C chosen per batch); per kernel variant one queue
     // ordered by wavefront i + j; one completion flag per tile slot (empty slots count as done for ever)
-    b->d_tiles = 0; b->ntiles = 0; b->lds2p = 0; b->v2_maxrows = 1; b->v2_maxcols = 1; b->simtile_lds = 0; b->d_flags = 0; b->nflags = 0; b->gen = 0;
+    b->d_tiles = 0; b->d_idxp = 0; b->np = 0; b->ntiles = 0; b->lds2p = 0; b->v2_maxrows = 1; b->v2_maxcols = 1; b->simtile_lds = 0; b->d_flags = 0; b->nflags = 0; b->gen = 0;
     {
         std::vector<std::vector<std::vector<V2Tile> > > q(16);   // [variant][wavefront] -> tiles
         std::vector<int> flags(20, 0);                    // 0-15 queue heads, 16-19 incident report
+        std::vector<V2Tile> pre[16];                      // boundary chains of sweep-mode DPs: they head their variant's queue
+        std::vector<int> ip;                              // the other DPs: chains in the prologue kernel
+        const bool chainq = !getenv("G2G_NO_CHAINQ");
         int v4rows[4] = {0, 0, 0, 0}, v4ca4[4] = {0, 0, 0, 0};
         V3Need need[8];
         memset(need, 0, sizeof need);
@@ -501,6 +505,16 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
                 x.rows_bytes = std::max(x.rows_bytes, nd.rows_bytes); x.ca4 = std::max(x.ca4, nd.ca4);
                 x.apool = std::max(x.apool, nd.apool); x.bpool = std::max(x.bpool, nd.bpool);
             }
+            const bool cq = chainq && (swp2 || swp3);
+            int ftop = -1, fleft = -1;
+            if (cq) {
+                ftop = (int) flags.size(); fleft = ftop + 1;
+                flags.push_back(0); flags.push_back(0);
+                V2Tile T;
+                T.prob = i; T.tj = 0; T.nsteps = 0; T.dep_up = T.dep_left = T.dep_diag = T.dep_war = -1;
+                T.ti = -1; T.self = ftop; pre[var].push_back(T);
+                T.ti = -2; T.self = fleft; pre[var].push_back(T);
+            } else ip.push_back(i);
             const int fbase = (int) flags.size();
             flags.resize(flags.size() + (size_t) nstrip * nblk, 0x7fffffff);
             for (int ti = 0; ti < nstrip; ++ti) {
@@ -518,8 +532,8 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
                     V2Tile T;
                     T.prob = i; T.ti = ti; T.tj = tj; T.nsteps = nsteps;
                     T.self = fbase + ti * nblk + tj;
-                    T.dep_up = ti > 0 ? T.self - nblk : -1;
-                    T.dep_left = tj > 0 ? T.self - 1 : -1;
+                    T.dep_up = ti > 0 ? T.self - nblk : ftop;             // sweep mode: the top chain is strip 0's "strip above"
+                    T.dep_left = tj > 0 ? T.self - 1 : fleft;
                     T.dep_diag = (ti > 0 && tj > 0) ? T.self - nblk - 1 : -1;
                     T.dep_war = (ti > 1 && tj + 1 < nblk) ? T.self - 2 * nblk + 1 : -1;
                     flags[T.self] = 0;
@@ -532,6 +546,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         std::vector<V2Tile> all;
         for (int v = 0; v < 16; ++v) {
             b->var_off[v] = (int) all.size();
+            all.insert(all.end(), pre[v].begin(), pre[v].end());
             for (size_t k = 0; k < q[v].size(); ++k) all.insert(all.end(), q[v][k].begin(), q[v][k].end());
         }
         b->var_off[16] = (int) all.size();
@@ -541,8 +556,10 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         b->nflags = (int) flags.size();
         b->flags0 = flags;
         if (!all.empty()) {
-            hipError_t e2 = hipMalloc((void **) &b->d_tiles, sizeof(V2Tile) * all.size());
+            hipError_t e2 = hipMalloc((void **) &b->d_tiles, sizeof(V2Tile) * all.size() + sizeof(int) * (ip.size() + 1));
             if (e2 == hipSuccess) e2 = hipMemcpy(b->d_tiles, all.data(), sizeof(V2Tile) * all.size(), hipMemcpyHostToDevice);
+            b->d_idxp = (int *) (b->d_tiles + all.size()); b->np = (int) ip.size();
+            if (e2 == hipSuccess && b->np) e2 = hipMemcpy(b->d_idxp, ip.data(), sizeof(int) * ip.size(), hipMemcpyHostToDevice);
             if (e2 == hipSuccess) e2 = hipMalloc((void **) &b->d_flags, sizeof(int) * flags.size());
             if (e2 == hipSuccess) e2 = hipMemcpy(b->d_flags, flags.data(), sizeof(int) * flags.size(), hipMemcpyHostToDevice);
             if (e2 != hipSuccess) { g2g_set_error("tiles: %s", hipGetErrorString(e2)); hipFree(b->d_arena); delete b; return G2G_ERR_NOMEM; }
@@ -580,9 +597,12 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->vev[4], ctx->stream));
         HIPCHK(hipStreamWaitEvent(ctx->vstream[3], ctx->vev[4], 0));
-        hipLaunchKernelGGL(g2g_v2_prologue_kernel, dim3(b->n2), dim3(128), b->lds2p, ctx->vstream[3],
-                           (const DevProb *) b->d_probs, (const int *) b->d_idx2);
-        HIPCHK(hipGetLastError());
+        const int pro_off = getenv("G2G_NO_PROSTAGE") ? 0 : (int) ((b->lds2p + 15) & ~(size_t) 15);
+        if (b->np) {
+            hipLaunchKernelGGL(g2g_v2_prologue_kernel, dim3(b->np), dim3(128), pro_off ? pro_off + 2 * PRO_LDS_BYTES : b->lds2p, ctx->vstream[3],
+                               (const DevProb *) b->d_probs, (const int *) b->d_idxp, pro_off);
+            HIPCHK(hipGetLastError());
+        }
         HIPCHK(hipEventRecord(ctx->vev[3], ctx->vstream[3]));
         const int simtiled = (!getenv("G2G_NO_SIMTILE") && b->simtile_lds && b->simtile_lds <= 64 * 1024) ? 1 : 0;
         if (simtiled) {
@@ -596,9 +616,9 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[3], 0));
         if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[g2g] prologue+sim done: %s\n", hipGetErrorString(e3)); fflush(stderr); }
         // persistent tile / strip kernels: one launch per kernel variant, each on its own stream (they are independent)
-        typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int, int, int);
+        typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int, int, int, int);
         static const v2k_t v2k[4] = {g2g_v2_hf2, g2g_v2_hf3, g2g_v2_pf2, g2g_v2_pf3};
-        typedef void (*v3k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V3Lds, int, int);
+        typedef void (*v3k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V3Lds, int, int, int);
         static const v3k_t v3k[8] = {g2g_v3_hf2, g2g_v3_hf3, g2g_v3_pf2, g2g_v3_pf3, g2g_v3r_hf2, g2g_v3r_hf3, g2g_v3r_pf2, g2g_v3r_pf3};
         // one persistent launch per variant, each on its own stream (they are independent of each other)
         ++b->gen;
@@ -625,7 +645,8 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] variant %d: %d tiles, grid %d x %d threads, lds %zu, cols %d, gen %d\n", v, cnt, grid, T2, b->lds2, b->v2_cols, b->gen); fflush(stderr); }
             hipLaunchKernelGGL(v2k[v], dim3(grid), dim3(T2), b->lds2 + 4 * T2, ctx->vstream[v],
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v]), cnt,
-                               b->d_flags + v, b->d_flags, b->gen, (int) b->lds2, b->v2_sweep ? (1 << 20) : b->v2_cols, pint2);
+                               b->d_flags + v, b->d_flags, b->gen, (int) b->lds2, b->v2_sweep ? (1 << 20) : b->v2_cols, pint2,
+                               (pro_off && pro_off + PRO_LDS_BYTES <= b->lds2) ? pro_off : 0);
             HIPCHK(hipGetLastError());
             if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->vstream[v]); fprintf(stderr, "[g2g] variant %d done: %s\n", v, hipGetErrorString(e3)); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[v], ctx->vstream[v]));
@@ -647,7 +668,8 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             hipLaunchKernelGGL(v3k[v], dim3(grid), dim3(64), (size_t) LO.total, vs,
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v + 4]), cnt,
                                b->d_flags + 4 + v, b->d_flags, b->gen, LO, (v >= 4 && v < 6 && b->v3_sweep) ? (1 << 20) : b->v3_cols,
-                               !(v >= 4 && v < 6 && b->v3_sweep) ? 0 : b->v3_sweep >= 8 ? b->v3_sweep : cnt < 4 * ncu * std::min(wpc, 8) ? 16 : 32);
+                               !(v >= 4 && v < 6 && b->v3_sweep) ? 0 : b->v3_sweep >= 8 ? b->v3_sweep : cnt < 4 * ncu * std::min(wpc, 8) ? 16 : 32,
+                               (pro_off && pro_off + (int) PRO_LDS_BYTES <= LO.svals) ? pro_off : 0);
             HIPCHK(hipGetLastError());
             if (getenv("G2G_DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v3 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[v & 3], vs));

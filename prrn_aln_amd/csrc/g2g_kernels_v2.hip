@@ -293,9 +293,18 @@ __device__ __forceinline__ void rec_store_all(unsigned *dst, LRec src, int ndw)
     for (int k = 0; k < ndw; ++k) dst[k] = sp[k];
 }
 
+// progress of a boundary chain that runs as a queue entry of a persistent kernel (sweep mode): same counter format as a
+// strip's (g2g_kernels_v3.hip); called by the walking lane after its stores
+__device__ __forceinline__ void chain_publish(int *prog, int penc, int v)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(prog, penc | (v < 0xFFFFF ? v : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // ---- prologue: the boundary chains of initB (fwd2c.h:138-176), one lane each, lists straight from HBM
 template <int KIND>
-__device__ void v2_chain_top(const DevProb &P, const V2Geom &G, LRec s0, LRec s1, unsigned *rowH)
+__device__ void v2_chain_top(const DevProb &P, const V2Geom &G, LRec s0, LRec s1, unsigned *rowH, int *prog = 0, int penc = 0)
 {
     const DevSide &a = P.a, &b = P.b;
     int rrt = b.right - a.left; if (P.up < rrt) rrt = P.up;
@@ -319,11 +328,12 @@ __device__ void v2_chain_top(const DevProb &P, const V2Geom &G, LRec s0, LRec s1
         lglb(cur) = 0;
         lval(cur) = lval(prv) + gnp;
         rec_store_all(rowH + (size_t) n * G.ndw, cur, G.ndw);
+        if (prog && ((n - b.left) & 31) == 0) chain_publish(prog, penc, n);
         LRec t = prv; prv = cur; cur = t;
     }
 }
 template <int KIND>
-__device__ void v2_chain_left(const DevProb &P, const V2Geom &G, LRec s0, LRec s1, unsigned *colH)
+__device__ void v2_chain_left(const DevProb &P, const V2Geom &G, LRec s0, LRec s1, unsigned *colH, int *prog = 0, int penc = 0)
 {
     const DevSide &a = P.a, &b = P.b;
     int rrl = b.left - a.right; if (P.lw > rrl) rrl = P.lw;
@@ -347,7 +357,144 @@ __device__ void v2_chain_left(const DevProb &P, const V2Geom &G, LRec s0, LRec s
         else { p_incdelta(ldlb(cur, G.capa), (lu32 *) 0, ldlb(prv, G.capa)); lglb(cur) = 0; }
         lval(cur) = lval(prv) + gnp;
         rec_store_all(colH + (size_t) (m - a.left) * G.ndw, cur, G.ndw);
+        if (prog && ((m - a.left) & 31) == 0) chain_publish(prog, penc, m - a.left);
         LRec t = prv; prv = cur; cur = t;
+    }
+}
+
+// ---- the same chains with their static lists staged through LDS ---------------------------------------
+// One lane walks a chain, and with the lists in HBM every step of it is a string of dependent global loads
+// (offset -> gap lengths -> frequencies, three times): ~8.6 us per step, 18 ms for 2049 columns -- 10 % of a DP
+// sweep once the sweep is sharded over 8 GPUs.  The lists of consecutive positions are contiguous in the profile,
+// so the whole wave copies them a block of PRO_B positions at a time (one latency per block instead of several per
+// step) and the walking lane reads LDS only.  Arithmetic and order are those of v2_chain_top/left above.
+#define PRO_B 32                       // positions per staged block
+#define PRO_POOL 1024                  // entries of the two staged views of a block (shrinks the block if short)
+#define PRO_CONST 128                  // entries of the three views of the chain's fixed position
+struct ProLds {
+    lf64 *pf, *cf, *pu; li32 *pg, *cg, *po;
+    __device__ __forceinline__ void carve(lchar *base) {
+        pf = (lf64 *) base; cf = pf + PRO_POOL; pu = cf + PRO_CONST;
+        pg = (li32 *) (pu + PRO_B); cg = pg + PRO_POOL; po = cg + PRO_CONST;
+    }
+};
+static const size_t PRO_LDS_BYTES = (8 * (PRO_POOL + PRO_CONST + PRO_B) + 4 * (PRO_POOL + PRO_CONST + 2 * (PRO_B + 1)) + 15) & ~(size_t) 15;
+
+__device__ __forceinline__ void pro_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+// the three views of `side` at position pos -> cg/cf; offsets of the views in co[3]
+__device__ __forceinline__ void pro_stage_const(const DevSide &side, int pos, const ProLds &S, int lane, int (&co)[3])
+{
+    int o = 0;
+    for (int v = 0; v < 3; ++v) {
+        const int g0 = side.off[v][pos + 1], len = side.off[v][pos + 2] - g0;
+        co[v] = o;
+        for (int k = lane; k < len; k += 64) { S.cg[o + k] = side.glen[v][g0 + k]; S.cf[o + k] = side.freq[v][g0 + k]; }
+        o += len;
+    }
+}
+// views 0 (s) and 1 (t) of positions [p0, p0 + count) -> pg/pf, per-position offsets -> po[v * (PRO_B + 1) + j];
+// returns the count that fits the pool
+__device__ __forceinline__ int pro_stage_block(const DevSide &side, int p0, int count, const ProLds &S, int lane)
+{
+    int g0[2], len[2];
+    for (;;) {
+        for (int v = 0; v < 2; ++v) { g0[v] = side.off[v][p0 + 1]; len[v] = side.off[v][p0 + count + 1] - g0[v]; }
+        if (len[0] + len[1] <= PRO_POOL || count == 1) break;
+        count >>= 1;
+    }
+    for (int v = 0; v < 2; ++v) {
+        const int base = v ? len[0] : 0;
+        for (int k = lane; k < len[v]; k += 64) { S.pg[base + k] = side.glen[v][g0[v] + k]; S.pf[base + k] = side.freq[v][g0[v] + k]; }
+        if (lane < count) S.po[v * (PRO_B + 1) + lane] = base + side.off[v][p0 + lane + 1] - g0[v];
+    }
+    return count;
+}
+__device__ __forceinline__ LList pro_list(const li32 *g, const lf64 *f, int o) { LList l; l.glen = g + o; l.freq = f + o; return l; }
+
+template <int KIND>
+__device__ void v2_chain_top_staged(const DevProb &P, const V2Geom &G, LRec s0, LRec s1, unsigned *rowH, const ProLds &S, const int lane, int *prog = 0, int penc = 0)
+{
+    const DevSide &a = P.a, &b = P.b;
+    int rrt = b.right - a.left; if (P.up < rrt) rrt = P.up;
+    const int nlast = a.left + rrt, ai = a.left - 1;
+    int co[3];
+    pro_stage_const(a, ai, S, lane, co);
+    if (lane == 0) {
+        lrec_black<KIND>(s0, G.capa); lval(s0) = 0; ldir(s0) = D_DIAG;          // origin
+        rec_store_all(rowH + (size_t) b.left * G.ndw, s0, G.ndw);
+    }
+    LRec prv = s0, cur = s1;
+    CellLists<LList> L;
+    L.as = pro_list(S.cg, S.cf, co[0]); L.at = pro_list(S.cg, S.cf, co[1]); L.ar = pro_list(S.cg, S.cf, co[2]);
+    L.bs = L.bt = L.br = L.as;
+    for (int n0 = b.left + 1; n0 <= nlast; ) {
+        int count = nlast - n0 + 1; if (count > PRO_B) count = PRO_B;
+        pro_wave_sync();                                  // the walking lane is done with the previous block
+        if (KIND == 2) count = pro_stage_block(b, n0 - 1, count, S, lane);
+        if (lane < count) S.pu[lane] = unpb(P, n0 - 1 + lane, ai);
+        pro_wave_sync();
+        if (lane == 0) {
+            for (int j = 0; j < count; ++j) {
+                const int n = n0 + j;
+                if (KIND == 2) { L.bs = pro_list(S.pg, S.pf, S.po[j]); L.bt = pro_list(S.pg, S.pf, S.po[PRO_B + 1 + j]); }
+                const double pub = S.pu[j];
+                double gnp = gap_hori<KIND>(P, L, prv, G.capa);
+                gnp = (n - b.left < P.codonk1) ? gnp + pub : (P.v2divv1 * gnp + P.u2divu1 * pub);
+                ldir(cur) = isvert(ldir(prv)) ? D_NEWH : D_HORI;
+                if (KIND == 2) p_newdelta(ldlb(cur, G.capa), (lu32 *) 0, L.bt, ldlb(prv, G.capa));
+                p_incdelta(ldla(cur), (lu32 *) 0, ldla(prv));
+                lglb(cur) = 0;
+                lval(cur) = lval(prv) + gnp;
+                rec_store_all(rowH + (size_t) n * G.ndw, cur, G.ndw);
+                LRec t = prv; prv = cur; cur = t;
+            }
+            if (prog) chain_publish(prog, penc, n0 + count - 1);
+        }
+        n0 += count;
+    }
+}
+template <int KIND>
+__device__ void v2_chain_left_staged(const DevProb &P, const V2Geom &G, LRec s0, LRec s1, unsigned *colH, const ProLds &S, const int lane, int *prog = 0, int penc = 0)
+{
+    const DevSide &a = P.a, &b = P.b;
+    int rrl = b.left - a.right; if (P.lw > rrl) rrl = P.lw;
+    const int mlast = b.left - rrl, bi = b.left - 1;
+    int co[3] = {0, 0, 0};
+    if (KIND == 2) pro_stage_const(b, bi, S, lane, co);
+    if (lane == 0) { lrec_black<KIND>(s0, G.capa); lval(s0) = 0; ldir(s0) = D_DIAG; }
+    LRec prv = s0, cur = s1;
+    CellLists<LList> L;
+    L.as = pro_list(S.cg, S.cf, 0); L.at = L.ar = L.bs = L.bt = L.br = L.as;
+    if (KIND == 2) { L.bs = pro_list(S.cg, S.cf, co[0]); L.bt = pro_list(S.cg, S.cf, co[1]); L.br = pro_list(S.cg, S.cf, co[2]); }
+    for (int m0 = a.left + 1; m0 <= mlast; ) {
+        int count = mlast - m0 + 1; if (count > PRO_B) count = PRO_B;
+        pro_wave_sync();
+        count = pro_stage_block(a, m0 - 1, count, S, lane);
+        if (lane < count) S.pu[lane] = unpa(P, m0 - 1 + lane, bi);
+        pro_wave_sync();
+        if (lane == 0) {
+            for (int j = 0; j < count; ++j) {
+                const int m = m0 + j;
+                L.as = pro_list(S.pg, S.pf, S.po[j]); L.at = pro_list(S.pg, S.pf, S.po[PRO_B + 1 + j]);
+                const double pua = S.pu[j];
+                double gnp = gap_vert<KIND>(P, L, prv, G.capa);
+                gnp = (m - a.left < P.codonk1) ? gnp + pua : (P.v2divv1 * gnp + P.u2divu1 * pua);
+                ldir(cur) = ishori(ldir(prv)) ? D_NEWV : D_VERT;
+                const int g1 = lglb(prv) + 1;
+                p_newdelta(ldla(cur), (lu32 *) 0, L.at, ldla(prv));
+                if (KIND == 1) lglb(cur) = g1;
+                else { p_incdelta(ldlb(cur, G.capa), (lu32 *) 0, ldlb(prv, G.capa)); lglb(cur) = 0; }
+                lval(cur) = lval(prv) + gnp;
+                rec_store_all(colH + (size_t) (m - a.left) * G.ndw, cur, G.ndw);
+                LRec t = prv; prv = cur; cur = t;
+            }
+            if (prog) chain_publish(prog, penc, m0 + count - 1 - a.left);
+        }
+        m0 += count;
     }
 }
 
@@ -585,7 +732,8 @@ __device__ __forceinline__ void uni_prob(DevProb &d, const DevProb &s)
 //   colH[row]                the left boundary chain
 template <int KIND, bool NOLL3>
 __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nsteps, const int C,
-                        const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0, const int pint = 32)
+                        const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0, const int pint = 32,
+                        const int *prog_left = 0)
 {
     // SWEEP MODE (prog_self != 0), as in g2g_kernels_v3.hip: the tile is a whole strip; the strip above publishes every
     // 32 steps up to which corner column its last row's records are in HBM, this strip waits only before its first
@@ -620,6 +768,18 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
     const int m_left_last = b.left - rrl;                  // last row whose corner (m, b.left) exists
     const LRec black = G.extra(EX_BLACK);
     const int m0 = a.left + ti * R, m = m0 + team;
+    if (prog_left) {                                       // sweep mode: the left boundary chain runs beside the strips (v2_chain_tile)
+        const int rows_ = m0 + R - a.left;
+        const int wantl = ((pgen & 0x7FF) << 20) | (rows_ < 0xFFFFF ? rows_ : 0xFFFFF);
+        int it = 0;
+        for (; it < G2G_SPIN_MAX; ++it) {
+            if (__hip_atomic_load(prog_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wantl) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (it == G2G_SPIN_MAX) { atomicAdd(dbg, 1); dbg[1] = ti; dbg[2] = -2; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const int c0 = b.left + tj * C;
     int c1 = c0 + C; if (c1 > b.right) c1 = b.right;
     const bool row_ok = m < a.right;
@@ -867,15 +1027,54 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
 // boundary chains of every DP: one small workgroup each (wave 0: top row, wave 1: left column); they are
 // latency-bound single-lane chains and run on their own stream beside the (fully parallel) score kernel
 template <int KIND>
-__device__ void v2_prologue(const DevProb &P, lchar *lds)
+__device__ void v2_prologue(const DevProb &Pmem, lchar *lds, const int pro_off)
 {
+    DevProb P;
+    uni_prob(P, Pmem);                                   // descriptor in scalar registers (see uni_prob)
     V2Geom G;
     G.capa = P.capa; G.capb = (KIND == 2) ? P.capb : 0;
     G.recsz = (16 + 4 * (G.capa + G.capb) + 15) & ~15; G.ndw = G.recsz / 4;
     G.nslot = 1; G.R = 4; G.lds = lds;
     unsigned *rowH2 = (unsigned *) P.v2_rowH + 2 * (size_t) P.v2_rowstride * G.ndw;
+    const int mlx = P.a.maxlist > P.b.maxlist ? P.a.maxlist : P.b.maxlist;
+    if (pro_off && 3 * mlx <= PRO_CONST && 2 * mlx <= PRO_POOL) {         // lists staged through LDS, a wave per chain
+        ProLds S; S.carve(lds + pro_off + (threadIdx.x >> 6) * PRO_LDS_BYTES);
+        if (threadIdx.x < 64) v2_chain_top_staged<KIND>(P, G, G.row(0, 0), G.row(1, 0), rowH2, S, threadIdx.x);
+        else v2_chain_left_staged<KIND>(P, G, G.row(2, 0), G.row(3, 0), (unsigned *) P.v2_colH, S, threadIdx.x - 64);
+        return;
+    }
     if (threadIdx.x == 0) v2_chain_top<KIND>(P, G, G.row(0, 0), G.row(1, 0), rowH2);
     if (threadIdx.x == 64) v2_chain_left<KIND>(P, G, G.row(2, 0), G.row(3, 0), (unsigned *) P.v2_colH);
+}
+
+
+// A boundary chain as an entry of a persistent kernel's queue (sweep mode): which = -1 top row, -2 left column, walked by
+// the first wave of the workgroup.  Chain entries head the queue and wait for nothing, so the strips that poll their
+// progress counters (strip 0: the top chain as its "strip above"; every strip: the left chain, before it starts) cannot
+// deadlock -- and the chains run beside the strips instead of in a kernel of their own before them (16 ms of a 166 ms
+// sweep at 1/8 of the bench batch).
+template <int KIND>
+__device__ __forceinline__ void v2_chain_tile(const DevProb &Pmem, lchar *lds, const int which, int *prog, const int pgen, const int pro_off)
+{
+    if (threadIdx.x >= 64) return;
+    DevProb P;
+    uni_prob(P, Pmem);
+    V2Geom G;
+    G.capa = P.capa; G.capb = (KIND == 2) ? P.capb : 0;
+    G.recsz = (16 + 4 * (G.capa + G.capb) + 15) & ~15; G.ndw = G.recsz / 4;
+    G.nslot = 1; G.R = 4; G.lds = lds;
+    unsigned *rowH2 = (unsigned *) P.v2_rowH + 2 * (size_t) P.v2_rowstride * G.ndw;
+    const int penc = (pgen & 0x7FF) << 20;
+    const int mlx = P.a.maxlist > P.b.maxlist ? P.a.maxlist : P.b.maxlist;
+    if (pro_off && 3 * mlx <= PRO_CONST && 2 * mlx <= PRO_POOL) {
+        ProLds S; S.carve(lds + pro_off);
+        if (which == -1) v2_chain_top_staged<KIND>(P, G, G.row(0, 0), G.row(1, 0), rowH2, S, threadIdx.x, prog, penc);
+        else v2_chain_left_staged<KIND>(P, G, G.row(0, 0), G.row(1, 0), (unsigned *) P.v2_colH, S, threadIdx.x, prog, penc);
+    } else if (threadIdx.x == 0) {
+        if (which == -1) v2_chain_top<KIND>(P, G, G.row(0, 0), G.row(1, 0), rowH2, prog, penc);
+        else v2_chain_left<KIND>(P, G, G.row(0, 0), G.row(1, 0), (unsigned *) P.v2_colH, prog, penc);
+    }
+    if (threadIdx.x == 0) chain_publish(prog, penc, 0xFFFFF);
 }
 
 // row offsets of the column-score matrix (needed by the score kernel, which then runs beside the chains)
@@ -896,12 +1095,12 @@ g2g_v2_rowoff_kernel(const DevProb *probs, const int *idx, int n)
 }
 
 extern "C" __global__ void __launch_bounds__(128)
-g2g_v2_prologue_kernel(const DevProb *probs, const int *idx)
-{
+g2g_v2_prologue_kernel(const DevProb *probs, const int *idx, int pro_off)
+{   // pro_off: byte offset of the two list-staging areas in dynamic LDS (0: lists straight from HBM)
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];
     lchar *lds = (lchar *) g2g_lds;
     const DevProb &P = probs[idx[blockIdx.x]];
-    if (P.kind == 1) v2_prologue<1>(P, lds); else if (P.kind == 2) v2_prologue<2>(P, lds);
+    if (P.kind == 1) v2_prologue<1>(P, lds, pro_off); else if (P.kind == 2) v2_prologue<2>(P, lds, pro_off);
 }
 
 __device__ __forceinline__ bool sim_tiled_kind(int k) { return k == 31 || k == 320 || k == 321 || k == 33 || k == 330; }
@@ -1005,7 +1204,7 @@ __device__ unsigned long long g2g_wait_acc[4];
 // each thread adds (tid == 0) to the queue head, parks its result in LDS, and slot 0 is the tile.
 #define V2_KERNEL(NAME, KIND, N3)                                                                   \
 extern "C" __global__ void __launch_bounds__(G2G_V2_THREADS, G2G_V2_MINWAVES)                         \
-NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, int lds_tile_off, int C, int sweep) \
+NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, int lds_tile_off, int C, int sweep, int pro_off) \
 {                                                                                                   \
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];                                  \
     li32 *s_vals = (li32 *) ((lchar *) g2g_lds + lds_tile_off);   /* tail of the dynamic LDS */      \
@@ -1016,8 +1215,14 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         __syncthreads();                                                                            \
         if (t >= ntiles) break;                                                                     \
         const V2Tile T = tiles[t];                                                                  \
+        if (T.ti < 0) {           /* a boundary chain (see v2_chain_tile) */                        \
+            v2_chain_tile<KIND>(probs[T.prob], (lchar *) g2g_lds, T.ti, done + T.self, gen, pro_off); \
+            __syncthreads();                                                                        \
+            continue;                                                                               \
+        }                                                                                           \
         /* one call site of the tile function (see g2g_kernels_v3.hip) */                           \
         const int *pu = (sweep && T.dep_up >= 0) ? done + T.dep_up : (const int *) 0;                \
+        const int *pl = (sweep && T.dep_left >= 0) ? done + T.dep_left : (const int *) 0;            \
         int *ps = sweep ? done + T.self : (int *) 0;                                                \
         V2_WAIT_T0                                                                                  \
         if (!sweep) {                                                                               \
@@ -1030,7 +1235,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         }                                                                                           \
         __syncthreads();                                                                            \
         V2_WAIT_T1                                                                                  \
-        v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen, sweep); \
+        v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen, sweep, pl); \
         V2_WAIT_T2                                                                                  \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \

@@ -597,7 +597,8 @@ __device__ __forceinline__ void v3_rec_store(unsigned *dst, int capa, int capb, 
 
 template <int KIND, bool NOLL3, int NA>
 __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V3Lds LO, const int ti, const int tj, const int nsteps, const int C,
-                        const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0, const int pint = 32)
+                        const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0, const int pint = 32,
+                        const int *prog_left = 0)
 {
     // SWEEP MODE (prog_self != 0): the tile is a whole strip (C covers the row range) and the dependency on the strip
     // above is a progress counter instead of tile-completion flags: the strip above publishes, every pint (16/32) steps, up to
@@ -629,6 +630,18 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
     int rrl = b.left - a.right; if (P.lw > rrl) rrl = P.lw;
     const int m_left_last = b.left - rrl;                  // last row whose corner (m, b.left) exists
     const int m0 = a.left + ti * 64, m = m0 + lane;
+    if (prog_left) {                                       // sweep mode: the left boundary chain runs beside the strips (v2_chain_tile)
+        const int rows_ = m0 + 64 - a.left;
+        const int wantl = ((pgen & 0x7FF) << 20) | (rows_ < 0xFFFFF ? rows_ : 0xFFFFF);
+        int it = 0;
+        for (; it < G2G_SPIN_MAX; ++it) {
+            if (__hip_atomic_load(prog_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wantl) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (it == G2G_SPIN_MAX) { atomicAdd(dbg, 1); dbg[1] = ti; dbg[2] = -2; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const int mend = (m0 + 64 < a.right) ? m0 + 64 : a.right;
     const int llast = mend - 1 - m0;                       // lane of the strip's last row
     const int c0 = b.left + tj * C;
@@ -916,7 +929,7 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
 
 #define V3_KERNEL(NAME, KIND, N3, NA, WPE)                                                           \
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))      \
-NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V3Lds LO, int C, int sweep) \
+NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V3Lds LO, int C, int sweep, int pro_off) \
 {                                                                                                   \
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];                                  \
     li32 *s_vals = (li32 *) ((lchar *) g2g_lds + LO.svals);                                         \
@@ -927,6 +940,12 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         __syncthreads();                                                                            \
         if (t >= ntiles) break;                                                                     \
         const V2Tile T = tiles[t];                                                                  \
+        if (T.ti < 0) {           /* a boundary chain (v2_chain_tile, g2g_kernels_v2.hip) */         \
+            v2_chain_tile<KIND>(probs[T.prob], (lchar *) g2g_lds, T.ti, done + T.self, gen, pro_off); \
+            __syncthreads();                                                                        \
+            continue;                                                                               \
+        }                                                                                           \
+        const int *pl = (sweep && T.dep_left >= 0) ? done + T.dep_left : (const int *) 0;            \
         /* sweep: strips as a pipeline on progress counters; else tiles on completion flags.  ONE call site of the   \
            tile function, or it is not inlined and its frame lands in scratch memory */                             \
         const int *pu = (sweep && T.dep_up >= 0) ? done + T.dep_up : (const int *) 0;                \
@@ -940,7 +959,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
         }                                                                                           \
         __syncthreads();                                                                            \
-        v3_tile<KIND, N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen, sweep); \
+        v3_tile<KIND, N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen, sweep, pl); \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
         if (!sweep) {                                                                               \

@@ -20,6 +20,10 @@ pytestmark = pytest.mark.gpu
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
 CONFIGS = {
     "default": {},
+    "prologue_kernel": {"G2G_NO_CHAINQ": "1"},                       # boundary chains in their own kernel, lists staged in LDS
+    "prologue_kernel_hbm": {"G2G_NO_CHAINQ": "1", "G2G_NO_PROSTAGE": "1"},   # ... lists straight from HBM
+    "chainq_hbm": {"G2G_NO_PROSTAGE": "1"},                          # chains as queue entries, lists from HBM
+    "v2_chainq_hbm": {"G2G_FORCE_V2": "1", "G2G_NO_PROSTAGE": "1"},
     "v3r_cols32": {"G2G_V3_COLS": "32", "G2G_V3_SWEEP": "0"},
     "v3r_tiles": {"G2G_V3_SWEEP": "0"},
     "v3lds_all": {"G2G_NO_AREG": "1", "G2G_V3_PF": "1"},
