@@ -488,7 +488,10 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             b->lds2p = std::max(b->lds2p, 5 * recsz + 64);
             b->v2_maxrows = std::max(b->v2_maxrows, d.a.right - d.a.left);
             b->v2_maxcols = std::max(b->v2_maxcols, d.b.right - d.b.left);
-            if (d.a.nelm > 0) b->simtile_lds = std::max(b->simtile_lds, (size_t) 8 * SIM_TR * (d.a.nelm - d.a.felm) + (size_t) 8 * SIM_TC * (d.b.felm > 0 ? d.b.felm : 0) + (size_t) SIM_TC * d.b.many + 64);
+            if (d.a.nelm > 0 && sim_tiled_kind(d.sim2_kind)) {        // a's profile rows + b's frequency vectors or residues
+                const bool vecb = d.sim2_kind == 33 || d.sim2_kind == 330;
+                b->simtile_lds = std::max(b->simtile_lds, (size_t) 8 * SIM_TR * ((d.a.nelm - d.a.felm + 1) & ~1) + (vecb ? (size_t) 8 * SIM_TC * (d.b.felm > 0 ? d.b.felm : 0) : (size_t) SIM_TC * d.b.many) + 64);
+            }
             const int al = d.a.left, ar = d.a.right, bl_ = d.b.left, br = d.b.right;
             const int R = d.v2_ok == 5 ? V5_R : d.v2_ok == 4 ? V4_R : d.v2_ok >= 2 ? 64 : b->v2_threads / 8;
             const bool swp3 = d.v2_ok == 3 && d.kind == 1 && b->v3_sweep;          // one tile per strip, pipelined (kind 1 only: no column pool)

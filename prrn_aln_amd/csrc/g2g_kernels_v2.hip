@@ -1103,7 +1103,7 @@ g2g_v2_prologue_kernel(const DevProb *probs, const int *idx, int pro_off)
     if (P.kind == 1) v2_prologue<1>(P, lds, pro_off); else if (P.kind == 2) v2_prologue<2>(P, lds, pro_off);
 }
 
-__device__ __forceinline__ bool sim_tiled_kind(int k) { return k == 31 || k == 320 || k == 321 || k == 33 || k == 330; }
+__host__ __device__ __forceinline__ bool sim_tiled_kind(int k) { return k == 31 || k == 320 || k == 321 || k == 33 || k == 330; }
 // PwdM::sim2 for every in-band cell of the gap-profile DPs (maln.h:160-172, maln2.cc:534-623,1230-1296):
 // independent of the recurrence, so it is computed ahead of it, fully parallel, row-major per DP
 extern "C" __global__ void __launch_bounds__(256)
@@ -1124,8 +1124,32 @@ g2g_v2_sim_kernel(const DevProb *probs, const int *idx, int tiled)
 // and the 128 columns of b (residues or frequency vectors) in LDS once and computes 4096 scores from there.  The
 // row-by-row kernel above re-reads b's column data for every row: 1.6e9 cells x 184 B through L2 for sim33, which is
 // what made it take 34 ms per sweep.  Expressions and summation order are those of sim2() (g2g_kernels.hip).
-#define SIM_TR 32
+#define SIM_TR 64
 #define SIM_TC 128
+// sim33 / sim33_n rows of one thread's column: b's frequency vector sits in registers (NB: compile-time bound of felm),
+// a's profile row is a wave-uniform LDS read.  Same products, same summation order as sim2().
+template <int NB, bool DC>
+__device__ __forceinline__ void sim_tile_vec(const DevProb &P, const lf64 *Ap, const int nap, const lf64 *vbl, const int felm,
+                                             const int m0, const int m1, const int n, const int r0)
+{
+    const DevSide &a = P.a, &b = P.b;
+    double vb[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) vb[j] = j < felm ? vbl[j] : 0;
+    for (int r = r0; r < m1 - m0; r += 2) {
+        const int m = m0 + r;
+        int nlo = m + P.lw; if (nlo < b.left) nlo = b.left;
+        int nhi = m + P.up + 1; if (nhi > b.right) nhi = b.right;
+        const lf64 *va = Ap + r * nap;
+        double sc = 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            constexpr int dc[6] = {0, 1, 2, 3, 5, 9};
+            if (j < felm) sc += va[DC ? dc[j < 6 ? j : 0] : j] * vb[j];
+        }
+        if (n >= nlo && n < nhi) P.v2_sim[P.v2_rowoff[m - a.left] + (n - nlo)] = sc;
+    }
+}
 extern "C" __global__ void __launch_bounds__(256)
 g2g_v2_sim_tile_kernel(const DevProb *probs, const int *idx)
 {
@@ -1142,21 +1166,25 @@ g2g_v2_sim_tile_kernel(const DevProb *probs, const int *idx)
     const int na = a.nelm - a.felm;                         // profile part of a's column vectors
     const bool vecb = kind == 33 || kind == 330;
     const int nb = vecb ? b.felm : 0;
-    lf64 *Ap = (lf64 *) (lchar *) g2g_lds;                  // [SIM_TR][na]
-    lf64 *Bf = Ap + SIM_TR * na;                            // [SIM_TC][nb]
-    LDS uint8_t *Br = (LDS uint8_t *) (Bf + SIM_TC * nb);   // [SIM_TC][b.many]
-    for (int k = tid; k < (m1 - m0) * na; k += 256) { const int r = k / na, j = k - r * na; Ap[k] = vss_at(a, m0 + r)[a.felm + j]; }
+    const int nap = (na + 1) & ~1;                          // row pitch of Ap (even: 16-byte aligned rows)
+    lf64 *Ap = (lf64 *) (lchar *) g2g_lds;                  // [SIM_TR][nap]
+    lf64 *Bf = Ap + SIM_TR * nap;                           // [SIM_TC][nb]
+    LDS uint8_t *Br = (LDS uint8_t *) Bf;                   // [SIM_TC][b.many] (the kinds that read residues have no Bf)
+    for (int k = tid; k < (m1 - m0) * na; k += 256) { const int r = k / na, j = k - r * na; Ap[r * nap + j] = vss_at(a, m0 + r)[a.felm + j]; }
     if (vecb) for (int k = tid; k < (c1 - c0) * nb; k += 256) { const int c = k / nb, j = k - c * nb; Bf[k] = vss_at(b, c0 + c)[j]; }
     else for (int k = tid; k < (c1 - c0) * b.many; k += 256) Br[k] = res_at(b, c0)[k];
     __syncthreads();
     const int c = tid & (SIM_TC - 1), n = c0 + c;
     if (n >= c1) return;
+    if (kind == 330 && b.felm <= 6) { sim_tile_vec<6, true>(P, Ap, nap, Bf + (size_t) c * nb, b.felm, m0, m1, n, tid >> 7); return; }
+    if (kind == 33 && b.felm <= 6) { sim_tile_vec<6, false>(P, Ap, nap, Bf + (size_t) c * nb, b.felm, m0, m1, n, tid >> 7); return; }
+    if (kind == 33 && b.felm <= 24) { sim_tile_vec<24, false>(P, Ap, nap, Bf + (size_t) c * nb, b.felm, m0, m1, n, tid >> 7); return; }
     for (int r = tid >> 7; r < m1 - m0; r += 2) {
         const int m = m0 + r;
         int nlo = m + P.lw; if (nlo < b.left) nlo = b.left;
         int nhi = m + P.up + 1; if (nhi > b.right) nhi = b.right;
         if (n < nlo || n >= nhi) continue;
-        const lf64 *va = Ap + r * na;
+        const lf64 *va = Ap + r * nap;
         double sc = 0;
         if (kind == 31) sc = va[Br[(size_t) c * b.many]];
         else if (kind == 320) { const LDS uint8_t *br = Br + (size_t) c * b.many; for (int j = 0; j < b.many; ++j) sc += va[br[j]]; }
