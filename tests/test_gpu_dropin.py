@@ -1,0 +1,92 @@
+"""The drop-in claim, end to end: the reference's own programs (`aln`, `prrn5`) linked with integration/g2g_bind.cc
+-- align2() (reference src/maln2.cc:1875) routed to libg2g.so by `ld --wrap`, nothing of the reference edited --
+must print exactly what the unmodified programs print, with the DPs actually running on the GPU.
+
+The binaries are built by `make -f oracle/Makefile.ref` (into oracle/_ref/, which travels to the GPU box but is
+not in git); the tests skip when they are absent.  Inputs are synthetic families written in the reference's
+sequential multi-sequence format."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import refdump
+from prrn_aln_amd.synth import DNA, drop_common_gaps, make_family, tree_branches
+
+REF = refdump.REF_DIR
+BIN = {k: os.path.join(REF, k) for k in ("aln", "aln_g2g", "prrn5", "prrn5_g2g")}
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not all(os.path.exists(p) for p in BIN.values()) or not refdump.available(),
+                                 reason="oracle/_ref drop-in binaries not built (make -f oracle/Makefile.ref)")]
+
+
+def _run(exe, args, cwd, mode=None):
+    env = dict(os.environ, ALN_TAB=os.path.join(REF, "table"), G2G_BIND_STATS="1")
+    if mode:
+        env["G2G_BIND"] = mode
+    p = subprocess.run([BIN[exe]] + args, cwd=cwd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return p.stdout, p.stderr
+
+
+def _stats(err):
+    m = re.search(r"g2g_bind: (\d+) align2 calls, (\d+) on the GPU, (\d+) by the reference, (\d+) mismatches", err)
+    assert m, err[-2000:]
+    return tuple(int(x) for x in m.groups())
+
+
+def _family(tmp, seed, n_seq, length, dna=False, **kw):
+    a = dict(n_seq=n_seq, length=length, seed=seed, indel=0.03, max_indel=8)
+    a.update(kw)
+    if dna:
+        a["alphabet"] = DNA
+    fam = make_family(**a)
+    names = ["s%03d" % i for i in range(len(fam.msa))]
+    refdump.write_multi(os.path.join(tmp, "fam.msa"), names, list(fam.msa), "fam")
+    return fam, names
+
+
+@pytest.mark.parametrize("seed,n_seq,length", [(5, 24, 150), (6, 40, 90), (7, 12, 200)])
+def test_aln_group_pair_identical_output(tmp_path, seed, n_seq, length):
+    tmp = str(tmp_path)
+    fam, names = _family(tmp, seed, n_seq, length)
+    n = len(fam.msa)
+    done = 0
+    for side in sorted(tree_branches(fam.tree), key=lambda s: -min(len(s), n - len(s)))[:4]:
+        sa = set(side)
+        A = [i for i in range(n) if i in sa]
+        B = [i for i in range(n) if i not in sa]
+        refdump.write_multi(os.path.join(tmp, "GA"), [names[i] for i in A], drop_common_gaps([fam.msa[i] for i in A]), "GA")
+        refdump.write_multi(os.path.join(tmp, "GB"), [names[i] for i in B], drop_common_gaps([fam.msa[i] for i in B]), "GB")
+        ref_out, _ = _run("aln", ["-s", tmp, "GA", "GB"], tmp)
+        out, err = _run("aln_g2g", ["-s", tmp, "GA", "GB"], tmp)
+        calls, gpu, cpu, bad = _stats(err)
+        assert gpu >= 1 and cpu == 0 and bad == 0, err[-500:]
+        assert out == ref_out
+        done += 1
+    assert done
+
+
+@pytest.mark.parametrize("seed,n_seq,length,dna", [(5, 24, 150, False), (8, 16, 120, True)])
+def test_prrn5_refinement_identical_output(tmp_path, seed, n_seq, length, dna):
+    """Refinement of a pre-aligned family: every align2() of Prrn::onecycle runs on the GPU; the refined MSA and
+    the sum-of-pairs line are those of the unmodified prrn5."""
+    tmp = str(tmp_path)
+    _family(tmp, seed, n_seq, length, dna=dna)
+    for opts in (["-YH0", "-R1"], ["-YH0", "-R1", "-O4"]):
+        ref_out, _ = _run("prrn5", opts + ["fam.msa"], tmp)
+        out, err = _run("prrn5_g2g", opts + ["fam.msa"], tmp)
+        calls, gpu, cpu, bad = _stats(err)
+        assert calls > 50 and gpu > 0 and bad == 0, err[-500:]
+        assert gpu >= 0.9 * calls, (calls, gpu, cpu)       # (what stays on the CPU: empty ranges, modes off the path)
+        assert out == ref_out
+
+
+def test_prrn5_verify_mode_counts_no_mismatch(tmp_path):
+    """G2G_BIND=verify: both implementations run on every call; scores, skeletons and fstat.val must agree."""
+    tmp = str(tmp_path)
+    _family(tmp, 11, 20, 100)
+    out, err = _run("prrn5_g2g", ["-YH0", "-R1", "-O4", "fam.msa"], tmp, mode="verify")
+    calls, gpu, cpu, bad = _stats(err)
+    assert gpu > 0 and bad == 0, err[-800:]
