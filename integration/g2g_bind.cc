@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <mutex>
 #include "aln.h"
 #include "mseq.h"
 #include "maln.h"
@@ -48,12 +49,11 @@ struct Stats {
 g2g_ctx* context()
 {
 	static g2g_ctx*	ctx = 0;
-	static bool	tried = false;
-	if (!tried) {
-	    tried = true;
+	static std::once_flag	once;
+	std::call_once(once, []() {
 	    ctx = g2g_create(-1);
 	    if (!ctx) fprintf(stderr, "g2g_bind: no GPU context (%s); align2 stays on the CPU\n", g2g_last_error());
-	}
+	});
 	return ctx;
 }
 
@@ -161,6 +161,8 @@ SKL* alignC_g2g(mSeq* seqs[], PwdM* pwd, VTYPE* scr)
 	const g2g_problem*	pp = &p;
 	g2g_result	r;
 	memset(&r, 0, sizeof(r));
+	static std::mutex	gpu;			// prrn5 -t<n>: thread_onecycle calls align2 from several pthreads, one g2g_ctx
+	std::lock_guard<std::mutex>	lock(gpu);
 	if (g2g_forward_batch(ctx, 1, &pp, &r) != G2G_OK || r.status != G2G_OK) {
 	    if (r.trace) g2g_free(r.trace);
 	    return 0;
