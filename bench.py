@@ -215,7 +215,7 @@ def main():
                        "failed_items": bad},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "g2g_v3r_hf2 + g2g_v2_pf2 (persistent tile kernels, concurrent) incl. g2g_v2_rowoff/prologue/sim kernels", "kernel_ms": fwd_avg_ms, "traceback_ms": tb_ms / args.steps,
+                         "kernel": "g2g_v3r_hf2 + g2g_v2_pf2 (persistent strip kernels incl. their boundary chains, concurrent) after g2g_v2_rowoff + g2g_v2_sim_tile", "kernel_ms": fwd_avg_ms, "traceback_ms": tb_ms / args.steps,
                          "bytes_per_cell": BYTES_PER_CELL[noll], "cells_per_launch": my_cells},
         }
         if sp_ms is not None:
