@@ -112,11 +112,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # G2G_BENCH_REHEARSE=1: all ranks on GPU 0 with the gloo backend -- a rehearsal of the N>1 code path on a one-GPU box
+    # (RCCL refuses two ranks on one device); the number it prints is not a scaling result and says so.
+    rehearse = world > 1 and os.environ.get("G2G_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -148,7 +156,9 @@ def main():
         res = batch.fetch()
         out = [(scr, engine.stdskl(tr), st) for (scr, cells, tr, st) in res]
         if world > 1:
-            slots = torch.from_numpy(sweep.pack_slots(mine, out, cap, nslots)).cuda()
+            slots = torch.from_numpy(sweep.pack_slots(mine, out, cap, nslots))
+            if not rehearse:
+                slots = slots.cuda()
             gathered = [torch.empty_like(slots) for _ in range(world)]
             dist.all_gather(gathered, slots)
             return out, gathered
@@ -169,7 +179,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -193,12 +203,19 @@ def main():
         fwd_avg_ms = fwd_ms / args.steps
         noll = holders[0].problem.noll if holders else 2
         line_tag = "NON-DEFAULT workload (DNA, ls=3): not the BASELINE metric" if args.dna else None
+        if rehearse:
+            line_tag = "REHEARSAL: %d ranks share GPU 0 over gloo; exercises the N>1 code path, not a scaling result" % world
         ach = my_cells * BYTES_PER_CELL[noll] / (fwd_avg_ms * 1e-3) / 1e9 if fwd_avg_ms else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                # measured on the whole default sweep; a rank / a non-default workload launches a different number of
+                # cells: scaled by cells (the PMC traffic is proportional to cells to within a few per cent), null for
+                # the workload the counters were not taken on
+                if traffic is not None:
+                    traffic = None if (args.dna or args.nseq != 256 or args.length != 1024 or args.limit) else traffic * my_cells / total_cells
             except Exception:
                 traffic = None
         line = {
@@ -223,7 +240,8 @@ def main():
             line["config"]["calcSpScore_failed"] = sp_bad
         if line_tag:
             line["config"]["note"] = line_tag
-            line["config"]["workload"] = line["config"]["workload"].replace("proteins", "DNA sequences").replace(" aa ", " nt ")
+            if args.dna:
+                line["config"]["workload"] = line["config"]["workload"].replace("proteins", "DNA sequences").replace(" aa ", " nt ")
         if args.shard_of > 1 and world == 1:
             line["rehearsal"] = "rank 0's share of a %d-rank job on one GPU: %d divisions, %.4g cells, %.1f ms per step" % (
                 args.shard_of, len(mine), my_cells, ms_per_step)
