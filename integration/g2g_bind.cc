@@ -21,7 +21,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <set>
 #include <mutex>
+#include <thread>
+#include <chrono>
+#include <condition_variable>
 #include "aln.h"
 #include "mseq.h"
 #include "maln.h"
@@ -38,13 +42,69 @@ extern "C" SKL* __real__Z6align2PP4mSeqP4PwdMPdP6Gsinfo(mSeq* seqs[], PwdM* pwdm
 namespace {
 
 struct Stats {
-	long	calls, gpu, cpu, mismatch;
+	long	calls, gpu, cpu, mismatch, batches, maxbatch;
 	~Stats() {
 	    if (getenv("G2G_BIND_STATS"))
-		fprintf(stderr, "g2g_bind: %ld align2 calls, %ld on the GPU, %ld by the reference, %ld mismatches\n",
-		    calls, gpu, cpu, mismatch);
+		fprintf(stderr, "g2g_bind: %ld align2 calls, %ld on the GPU, %ld by the reference, %ld mismatches"
+		    "; %ld GPU batches, largest %ld\n", calls, gpu, cpu, mismatch, batches, maxbatch);
 	}
-} stats = {0, 0, 0, 0};
+} stats = {0, 0, 0, 0, 0, 0};
+std::mutex	stats_mu;		// (prrn5 -t<n> calls align2 from several pthreads)
+#define COUNT(field) do {std::lock_guard<std::mutex> l_(stats_mu); ++stats.field;} while (0)
+
+// prrn5 -t<n>: thread_onecycle (src/prrn5.cc:565-592) aligns n candidate divisions in n pthreads at once.  One g2g_ctx
+// serves them all, and instead of running their DPs one after the other the calls that arrive together are run as
+// ONE g2g_forward_batch: the first caller leads, collects whatever arrives within a short quiet window, launches, and
+// hands every waiting caller its own result.  A lone caller (serial prrn5, aln) goes straight through.
+struct Req {const g2g_problem* p; g2g_result r; bool done;};
+struct Batcher {
+	std::mutex	mu;
+	std::condition_variable	cv;
+	std::vector<Req*>	pending;
+	std::set<std::thread::id>	callers;
+	bool	busy;
+	Batcher() : busy(false) {}
+	void submit(g2g_ctx* ctx, Req* q) {
+	    std::unique_lock<std::mutex>	lk(mu);
+	    callers.insert(std::this_thread::get_id());
+	    pending.push_back(q);
+	    cv.notify_all();
+	    while (!q->done) {
+		if (busy) {cv.wait(lk); continue;}
+		busy = true;					// this caller leads the next batch
+		if (callers.size() > 1) {			// let the other threads' calls arrive: quiet for 200 us, 3 ms at most
+		    const auto	t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(3);
+		    for (;;) {
+			const size_t	before = pending.size();
+			cv.wait_for(lk, std::chrono::microseconds(200));
+			if (pending.size() == before || pending.size() >= callers.size() ||
+			    std::chrono::steady_clock::now() >= t_end) break;
+		    }
+		}
+		std::vector<Req*>	mine;
+		mine.swap(pending);
+		lk.unlock();
+		const int	n = (int) mine.size();
+		std::vector<const g2g_problem*>	probs(n);
+		std::vector<g2g_result>	res(n);
+		for (int i = 0; i < n; ++i) {probs[i] = mine[i]->p; memset(&res[i], 0, sizeof(g2g_result));}
+		const int	rc = g2g_forward_batch(ctx, n, probs.data(), res.data());
+		for (int i = 0; i < n; ++i) {
+		    mine[i]->r = res[i];
+		    if (rc != G2G_OK && mine[i]->r.status == G2G_OK) mine[i]->r.status = rc;
+		}
+		{
+		    std::lock_guard<std::mutex>	l2(stats_mu);
+		    ++stats.batches;
+		    if (n > stats.maxbatch) stats.maxbatch = n;
+		}
+		lk.lock();
+		for (int i = 0; i < n; ++i) mine[i]->done = true;
+		busy = false;
+		cv.notify_all();
+	    }
+	}
+} batcher;
 
 g2g_ctx* context()
 {
@@ -158,12 +218,12 @@ SKL* alignC_g2g(mSeq* seqs[], PwdM* pwd, VTYPE* scr)
 	SideBuf	A, B;
 	side(p.a, seqs[0], pwd->wta, naive, A);
 	side(p.b, seqs[1], pwd->wtb, naive, B);
-	const g2g_problem*	pp = &p;
-	g2g_result	r;
-	memset(&r, 0, sizeof(r));
-	static std::mutex	gpu;			// prrn5 -t<n>: thread_onecycle calls align2 from several pthreads, one g2g_ctx
-	std::lock_guard<std::mutex>	lock(gpu);
-	if (g2g_forward_batch(ctx, 1, &pp, &r) != G2G_OK || r.status != G2G_OK) {
+	Req	q;
+	q.p = &p; q.done = false;
+	memset(&q.r, 0, sizeof(q.r));
+	batcher.submit(ctx, &q);
+	const g2g_result&	r = q.r;
+	if (r.status != G2G_OK) {
 	    if (r.trace) g2g_free(r.trace);
 	    return 0;
 	}
@@ -225,11 +285,11 @@ bool same_skl(const SKL* x, const SKL* y)
 extern "C" SKL* __wrap__Z6align2PP4mSeqP4PwdMPdP6Gsinfo(mSeq* seqs[], PwdM* pwdm, VTYPE* scr, Gsinfo* GsI)
 {
 	static const char*	mode = getenv("G2G_BIND");
-	++stats.calls;
+	COUNT(calls);
 	const bool	off = mode && !strcmp(mode, "off");
 	const bool	verify = mode && !strcmp(mode, "verify");
 	if (off || !on_gpu_path(seqs, pwdm, GsI)) {
-	    ++stats.cpu;
+	    COUNT(cpu);
 	    return __real__Z6align2PP4mSeqP4PwdMPdP6Gsinfo(seqs, pwdm, scr, GsI);
 	}
 	if (verify) {
@@ -241,18 +301,18 @@ extern "C" SKL* __wrap__Z6align2PP4mSeqP4PwdMPdP6Gsinfo(mSeq* seqs[], PwdM* pwdm
 	    pwdm->alnprm.sh = sh0;
 	    SKL*	ref = __real__Z6align2PP4mSeqP4PwdMPdP6Gsinfo(seqs, pwdm, scr, GsI);
 	    if (handled) {
-		++stats.gpu;
+		COUNT(gpu);
 		if (!same_skl(mine, ref) || (ref && (s2 != *scr || g2.fstat.val != GsI->fstat.val))) {
-		    ++stats.mismatch;
+		    COUNT(mismatch);
 		    fprintf(stderr, "g2g_bind: MISMATCH mode %d score %.17g vs %.17g\n", pwdm->alnmode, s2, *scr);
 		}
-	    } else ++stats.cpu;
+	    } else COUNT(cpu);
 	    delete[] mine;
 	    return ref;
 	}
 	bool	handled = false;
 	SKL*	skl = align2_gpu(seqs, pwdm, scr, GsI, handled);
-	if (handled) {++stats.gpu; return skl;}
-	++stats.cpu;
+	if (handled) {COUNT(gpu); return skl;}
+	COUNT(cpu);
 	return __real__Z6align2PP4mSeqP4PwdMPdP6Gsinfo(seqs, pwdm, scr, GsI);
 }

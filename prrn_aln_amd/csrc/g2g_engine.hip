@@ -494,7 +494,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             }
             const int al = d.a.left, ar = d.a.right, bl_ = d.b.left, br = d.b.right;
             const int R = d.v2_ok == 5 ? V5_R : d.v2_ok == 4 ? V4_R : d.v2_ok >= 2 ? 64 : b->v2_threads / 8;
-            const bool swp3 = d.v2_ok == 3 && d.kind == 1 && b->v3_sweep;          // one tile per strip, pipelined (kind 1 only: no column pool)
+            const bool swp3 = (d.v2_ok == 3 || d.v2_ok == 2) && d.kind == 1 && b->v3_sweep;   // one tile per strip, pipelined (kind 1 only: no column pool)
             const bool swp2 = d.v2_ok == 1 && b->v2_sweep;
             const int C = (swp3 || swp2) ? (1 << 20) : d.v2_ok >= 4 ? b->v4_cols : d.v2_ok >= 2 ? b->v3_cols : b->v2_cols;
             const int nstrip = (ar - al + R - 1) / R, nblk = (br - bl_ + C - 1) / C;
@@ -642,9 +642,10 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             const int grid = std::min(cnt, ncu * wpc2);
             // sweep mode: the kernel argument is the publish interval.  A DP's critical path is columns + strips x
             // interval: 32 steps when the strips outnumber the resident workgroups several times over (throughput
-            // bound, fewer fences), 16 when they do not (a shard of a sweep: -8 % at 1/8 of the bench sweep).
+            // bound, fewer fences), 16 when they do not (a shard of a sweep: -8 % at 1/8 of the bench sweep), 4 when the
+            // strips fill less than a quarter of the chip (a handful of DPs: latency is all that counts, -10 %).
             const int res2 = ncu * std::max(1, std::min(wpc2, (int) (V2_LDS_MAX / (b->lds2 + 4 * (size_t) T2))));
-            const int pint2 = !b->v2_sweep ? 0 : b->v2_sweep >= 8 ? b->v2_sweep : cnt < 4 * res2 ? 16 : 32;
+            const int pint2 = !b->v2_sweep ? 0 : b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= res2 ? 4 : cnt < 4 * res2 ? 16 : 32;
             if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] variant %d: %d tiles, grid %d x %d threads, lds %zu, cols %d, gen %d\n", v, cnt, grid, T2, b->lds2, b->v2_cols, b->gen); fflush(stderr); }
             hipLaunchKernelGGL(v2k[v], dim3(grid), dim3(T2), b->lds2 + 4 * T2, ctx->vstream[v],
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v]), cnt,
@@ -661,6 +662,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             if (const char *e = getenv("G2G_ONLY_VAR")) if (atoi(e) != v) continue;       // profiling aid
             hipStream_t vs = ctx->vstream[v & 3];
             const V3Lds &LO = b->v3lds[v];
+            const bool swpv = (v & 3) < 2;                   // the _hf variants (LDS lists 0,1; register lists 4,5) run in sweep mode
             if (LO.total > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *) v3k[v], hipFuncAttributeMaxDynamicSharedMemorySize, LO.total));
             HIPCHK(hipStreamWaitEvent(vs, ctx->vev[4], 0));
             int wpc = (int) (V2_LDS_MAX / (size_t) LO.total);              // resident tiles per CU (LDS-bound)
@@ -670,8 +672,8 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v3 variant %d: %d tiles, grid %d, lds %d (rows %d, apool@%d, bpool@%d), cols %d, gen %d\n", v, cnt, grid, LO.total, LO.black, LO.aglen, LO.bglen, b->v3_cols, b->gen); fflush(stderr); }
             hipLaunchKernelGGL(v3k[v], dim3(grid), dim3(64), (size_t) LO.total, vs,
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v + 4]), cnt,
-                               b->d_flags + 4 + v, b->d_flags, b->gen, LO, (v >= 4 && v < 6 && b->v3_sweep) ? (1 << 20) : b->v3_cols,
-                               !(v >= 4 && v < 6 && b->v3_sweep) ? 0 : b->v3_sweep >= 8 ? b->v3_sweep : cnt < 4 * ncu * std::min(wpc, 8) ? 16 : 32,
+                               b->d_flags + 4 + v, b->d_flags, b->gen, LO, (swpv && b->v3_sweep) ? (1 << 20) : b->v3_cols,
+                               !(swpv && b->v3_sweep) ? 0 : b->v3_sweep >= 2 ? b->v3_sweep : 4 * cnt <= ncu * std::min(wpc, 8) ? 4 : cnt < 4 * ncu * std::min(wpc, 8) ? 16 : 32,
                                (pro_off && pro_off + (int) PRO_LDS_BYTES <= LO.svals) ? pro_off : 0);
             HIPCHK(hipGetLastError());
             if (getenv("G2G_DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v3 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }

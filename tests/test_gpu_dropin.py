@@ -90,3 +90,20 @@ def test_prrn5_verify_mode_counts_no_mismatch(tmp_path):
     out, err = _run("prrn5_g2g", ["-YH0", "-R1", "-O4", "fam.msa"], tmp, mode="verify")
     calls, gpu, cpu, bad = _stats(err)
     assert gpu > 0 and bad == 0, err[-800:]
+
+
+def test_prrn5_threaded_calls_are_batched(tmp_path):
+    """prrn5 -t8: thread_onecycle (reference src/prrn5.cc:565-592) calls align2 from 8 pthreads; the binding runs the calls
+    that arrive together as one g2g_forward_batch.  Output must equal that of the unmodified threaded program."""
+    tmp = str(tmp_path)
+    _family(tmp, 9, 48, 200)
+    opts = ["-YH0", "-R1", "-O4", "-t8", "fam.msa"]
+    ref_out, _ = _run("prrn5", opts, tmp)
+    out, err = _run("prrn5_g2g", opts, tmp)
+    calls, gpu, cpu, bad = _stats(err)
+    m = re.search(r"(\d+) GPU batches, largest (\d+)", err)
+    assert m, err[-500:]
+    batches, largest = int(m.group(1)), int(m.group(2))
+    assert gpu >= 0.9 * calls and bad == 0
+    assert largest > 1 and batches < gpu, (batches, largest, gpu)
+    assert out == ref_out

@@ -27,7 +27,7 @@ CONFIGS = {
     "v3r_cols32": {"G2G_V3_COLS": "32", "G2G_V3_SWEEP": "0"},
     "v3r_tiles": {"G2G_V3_SWEEP": "0"},
     "v3lds_all": {"G2G_NO_AREG": "1", "G2G_V3_PF": "1"},
-    "v3lds_all_cols32": {"G2G_NO_AREG": "1", "G2G_V3_PF": "1", "G2G_V3_COLS": "32"},
+    "v3lds_all_cols32": {"G2G_NO_AREG": "1", "G2G_V3_PF": "1", "G2G_V3_COLS": "32", "G2G_V3_SWEEP": "0"},   # tile mode
     "v3_pf": {"G2G_V3_PF": "1", "G2G_V3_COLS": "64"},
     "v4": {"G2G_V4": "1"},
     "v4_cols16": {"G2G_V4": "1", "G2G_V4_COLS": "16"},
