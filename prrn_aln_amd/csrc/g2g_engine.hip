@@ -84,14 +84,34 @@ extern "C" void g2g_free(void *p) { free(p); }
 // ---- batch -----------------------------------------------------------------------------------
 
 struct Blob {                       // host image of the input part of the arena
-    std::vector<char> h;
+    // (a raw realloc'ed buffer: a std::vector zero-fills and copies 1.2 GB of profiles again and again while it
+    // grows -- that was 1.1 s of a 1.3 s prepare for the bench sweep)
+    char *p; size_t sz, cap;
+    Blob() : p(0), sz(0), cap(0) {}
+    ~Blob() { free(p); }
+    Blob(const Blob &) = delete;
+    Blob &operator=(const Blob &) = delete;
+    void grow(size_t need)
+    {
+        if (need <= cap) return;
+        size_t c = cap ? cap : ((size_t) 1 << 20);
+        while (c < need) c *= 2;
+        char *q = (char *) realloc(p, c);
+        if (!q) throw std::bad_alloc();
+        p = q; cap = c;
+    }
+    void extend(size_t newsize) { if (newsize <= sz) return; grow(newsize); memset(p + sz, 0, newsize - sz); sz = newsize; }
     size_t put(const void *src, size_t bytes)
     {
-        size_t off = (h.size() + 15) & ~(size_t) 15;
-        h.resize(off + bytes);
-        if (bytes) memcpy(h.data() + off, src, bytes);
+        const size_t off = (sz + 15) & ~(size_t) 15;
+        grow(off + bytes);
+        if (off > sz) memset(p + sz, 0, off - sz);
+        if (bytes) memcpy(p + off, src, bytes);
+        sz = off + bytes;
         return off;
     }
+    char *data() { return p; }
+    size_t size() const { return sz; }
 };
 
 struct g2g_batch {
@@ -301,6 +321,14 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     if (!ctx || n < 0 || !out) return G2G_ERR_ARG;
     if (!ctx->ok) return G2G_ERR_NODEVICE;
     HIPCHK(hipSetDevice(ctx->device));
+    const bool prep_dbg = getenv("G2G_DEBUG_PREP") != 0;
+    auto prep_t0 = std::chrono::steady_clock::now();
+    auto prep_lap = [&](const char *what) {
+        if (!prep_dbg) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[g2g prepare] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - prep_t0).count());
+        prep_t0 = t;
+    };
     g2g_batch *b = new g2g_batch();
     b->ctx = ctx; b->n = n; b->d_arena = 0; b->d_probs = 0; b->fwd_ms = b->tb_ms = 0;
     b->v3_cols = 128; b->v4_cols = 64; b->v2_cols = G2G_V2_TILE_COLS;
@@ -308,7 +336,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     b->dp.resize(n); b->status.assign(n, G2G_OK); b->cells.assign(n, 0); b->out_off.assign(n, 0); b->tcap.assign(n, 0); b->rr1.assign(n, 0);
     Blob bl;
     size_t probs_off = bl.put(0, 0);
-    bl.h.resize(probs_off + sizeof(DevProb) * (size_t) (n > 0 ? n : 1));
+    bl.extend(probs_off + sizeof(DevProb) * (size_t) (n > 0 ? n : 1));
     // 1. inputs
     for (int i = 0; i < n; ++i) {
         DevProb &d = b->dp[i];
@@ -363,8 +391,8 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     }
     // index lists for the two forward kernels (filled below, once eligibility is known)
     const size_t idx_off = bl.put(0, 0);
-    bl.h.resize(idx_off + sizeof(int) * 2 * (size_t) (n > 0 ? n : 1));
-    b->in_bytes = (bl.h.size() + 255) & ~(size_t) 255;
+    bl.extend(idx_off + sizeof(int) * 2 * (size_t) (n > 0 ? n : 1));
+    b->in_bytes = (bl.size() + 255) & ~(size_t) 255;
     // 2. state / trace / outputs (device only)
     size_t off = b->in_bytes;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t) 15; return o; };
@@ -441,7 +469,9 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     }
     b->out_hi = off;
     b->arena_bytes = off + 256;
+    prep_lap("host image of the inputs");
     hipError_t e = hipMalloc((void **) &b->d_arena, b->arena_bytes);
+    prep_lap("hipMalloc(arena)");
     if (e != hipSuccess) { g2g_set_error("hipMalloc(arena): %s", hipGetErrorString(e)); delete b; return G2G_ERR_NOMEM; }
     for (int i = 0; i < n; ++i) {
         DevProb &d = b->dp[i];
@@ -458,7 +488,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         rebase(d.trace, b->d_arena); rebase(d.score, b->d_arena); rebase(d.ntrace, b->d_arena); rebase(d.otrace, b->d_arena);
     }
     {
-        int *i1 = (int *) (bl.h.data() + idx_off), *i2 = i1 + (n > 0 ? n : 1);
+        int *i1 = (int *) (bl.data() + idx_off), *i2 = i1 + (n > 0 ? n : 1);
         b->n1 = b->n2 = 0; b->lds2 = 0;
         for (int i = 0; i < n; ++i) {
             const DevProb &d = b->dp[i];
@@ -568,11 +598,13 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             if (e2 != hipSuccess) { g2g_set_error("tiles: %s", hipGetErrorString(e2)); hipFree(b->d_arena); delete b; return G2G_ERR_NOMEM; }
         }
     }
-    if (n) memcpy(bl.h.data() + probs_off, b->dp.data(), sizeof(DevProb) * (size_t) n);
+    prep_lap("descriptors, tiles, flags");
+    if (n) memcpy(bl.data() + probs_off, b->dp.data(), sizeof(DevProb) * (size_t) n);
     b->d_probs = (DevProb *) (b->d_arena + probs_off);
-    e = hipMemcpyAsync(b->d_arena, bl.h.data(), bl.h.size(), hipMemcpyHostToDevice, ctx->stream);
+    e = hipMemcpyAsync(b->d_arena, bl.data(), bl.size(), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { g2g_set_error("upload: %s", hipGetErrorString(e)); hipFree(b->d_arena); delete b; return G2G_ERR_DEVICE; }
+    prep_lap("upload");
     *out = b;
     return G2G_OK;
 }
