@@ -68,13 +68,14 @@ def test_aln_group_pair_identical_output(tmp_path, seed, n_seq, length):
     assert done
 
 
-@pytest.mark.parametrize("seed,n_seq,length,dna", [(5, 24, 150, False), (8, 16, 120, True)])
-def test_prrn5_refinement_identical_output(tmp_path, seed, n_seq, length, dna):
+@pytest.mark.parametrize("seed,n_seq,length,dna,extra", [(5, 24, 150, False, []), (8, 16, 120, True, []),
+                                                         (8, 16, 120, True, ["-yl3"]), (12, 20, 140, False, ["-yl3"])])
+def test_prrn5_refinement_identical_output(tmp_path, seed, n_seq, length, dna, extra):
     """Refinement of a pre-aligned family: every align2() of Prrn::onecycle runs on the GPU; the refined MSA and
-    the sum-of-pairs line are those of the unmodified prrn5."""
+    the sum-of-pairs line are those of the unmodified prrn5.  `-yl3`: double-affine gap penalty (Noll 3 kernels)."""
     tmp = str(tmp_path)
     _family(tmp, seed, n_seq, length, dna=dna)
-    for opts in (["-YH0", "-R1"], ["-YH0", "-R1", "-O4"]):
+    for opts in (["-YH0", "-R1"] + extra, ["-YH0", "-R1", "-O4"] + extra):
         ref_out, _ = _run("prrn5", opts + ["fam.msa"], tmp)
         out, err = _run("prrn5_g2g", opts + ["fam.msa"], tmp)
         calls, gpu, cpu, bad = _stats(err)
