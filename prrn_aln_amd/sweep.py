@@ -7,6 +7,8 @@ GPU and shards across GPUs.  This module builds the divisions (
 ranks and packs results into fixed-size slots for the all-gather between sweeps."""
 from __future__ import annotations
 
+import os
+from concurrent.futures import ThreadPoolExecutor
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -34,7 +36,8 @@ class Sweep:
     """All divisions of one sweep over a family's current MSA, as PwdM objects (host-side builders run in
     libg2g.so).  `order` lists division ids by decreasing DP size (longest-processing-time first)."""
 
-    def __init__(self, fam: Family, alp: op.AlnParam, weighted: bool = True, limit: Optional[int] = None):
+    def __init__(self, fam: Family, alp: op.AlnParam, weighted: bool = True, limit: Optional[int] = None,
+                 workers: Optional[int] = None):
         self.fam, self.alp = fam, alp
         self.codes = op.encode(fam.msa, alp.molc)
         n = len(fam.msa)
@@ -42,15 +45,24 @@ class Sweep:
         self.branches = tree_branches(fam.tree)
         if limit:
             self.branches = self.branches[:limit]
-        self.pwds: List[op.PwdM] = []
-        self.groups = []
-        for side in self.branches:
+        # The builders of a division (aggregate, thickness, profiles, gap profiles: g2g_host.cpp) touch only their own
+        # objects and run outside the GIL (ctypes): divisions are built by a pool of host threads (5.9 s -> <1 s for the
+        # 509 divisions of the bench sweep on 16 cores).
+        def build(side):
             a, b, ia, ib = division_groups(self.codes, side)
             wa = None if self.weights is None else self.weights[ia]
             wb = None if self.weights is None else self.weights[ib]
             ga, gb = op.mSeq(a, alp, wa), op.mSeq(b, alp, wb)
-            self.groups.append((ga, gb))
-            self.pwds.append(op.PwdM([ga, gb], alp))
+            return (ga, gb), op.PwdM([ga, gb], alp)
+
+        nthr = workers if workers is not None else min(16, os.cpu_count() or 1)
+        if nthr > 1 and len(self.branches) > 1:
+            with ThreadPoolExecutor(max_workers=nthr) as pool:
+                built = list(pool.map(build, self.branches))
+        else:
+            built = [build(side) for side in self.branches]
+        self.groups = [g for g, _ in built]
+        self.pwds: List[op.PwdM] = [p for _, p in built]
         self.cells = np.array([band_cells(p.problem) for p in self.pwds], np.int64)
         self.order = np.argsort(-self.cells, kind="stable")
 
