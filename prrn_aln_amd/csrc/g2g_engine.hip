@@ -7,6 +7,8 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <thread>
+#include <atomic>
 #include <algorithm>
 #include <chrono>
 #include "../../include/g2g.h"
@@ -38,6 +40,7 @@ struct g2g_ctx {
     hipStream_t vstream[4];         // one per v2 kernel variant: their tile wavefronts are independent
     hipEvent_t ev[4];
     hipEvent_t vev[5];
+    char *stage; size_t stage_cap;  // pinned host staging buffer of g2g_batch_prepare, kept between calls
 };
 
 extern "C" g2g_ctx *g2g_create(int device)
@@ -53,6 +56,7 @@ extern "C" g2g_ctx *g2g_create(int device)
     g2g_ctx *c = new g2g_ctx();
     c->device = device;
     c->ok = 0;
+    c->stage = 0; c->stage_cap = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; g2g_set_error("%s", "stream"); return NULL; }
     for (int i = 0; i < 4; ++i) hipEventCreate(&c->ev[i]);
     for (int i = 0; i < 4; ++i) hipStreamCreateWithFlags(&c->vstream[i], hipStreamNonBlocking);
@@ -75,6 +79,7 @@ extern "C" void g2g_destroy(g2g_ctx *c)
     for (int i = 0; i < 5; ++i) hipEventDestroy(c->vev[i]);
     for (int i = 0; i < 4; ++i) hipStreamDestroy(c->vstream[i]);
     hipStreamDestroy(c->stream);
+    if (c->stage) hipHostFree(c->stage);
     delete c;
 }
 
@@ -87,28 +92,52 @@ struct Blob {                       // host image of the input part of the arena
     // (a raw realloc'ed buffer: a std::vector zero-fills and copies 1.2 GB of profiles again and again while it
     // grows -- that was 1.1 s of a 1.3 s prepare for the bench sweep)
     char *p; size_t sz, cap;
-    Blob() : p(0), sz(0), cap(0) {}
-    ~Blob() { free(p); }
+    struct Copy { size_t off; const void *src; size_t bytes; };
+    std::vector<Copy> later;        // big copies are deferred and done by a few host threads at once (flush)
+    g2g_ctx *owner;                 // the buffer is the context's pinned staging area: it outlives the Blob (no page
+                                    // faults and a DMA-able source on every call after the first)
+    explicit Blob(g2g_ctx *c) : p(c->stage), sz(0), cap(c->stage_cap), owner(c), oom(false) {}
+    ~Blob() { owner->stage = p; owner->stage_cap = cap; }
     Blob(const Blob &) = delete;
     Blob &operator=(const Blob &) = delete;
+    bool oom;
     void grow(size_t need)
     {
-        if (need <= cap) return;
-        size_t c = cap ? cap : ((size_t) 1 << 20);
-        while (c < need) c *= 2;
-        char *q = (char *) realloc(p, c);
-        if (!q) throw std::bad_alloc();
+        if (need <= cap || oom) return;
+        const size_t c = need + need / 8 + ((size_t) 1 << 20);
+        char *q = 0;
+        if (hipHostMalloc((void **) &q, c, hipHostMallocDefault) != hipSuccess || !q) { (void) hipGetLastError(); oom = true; return; }
+        if (sz) memcpy(q, p, sz);
+        if (p) hipHostFree(p);
         p = q; cap = c;
     }
-    void extend(size_t newsize) { if (newsize <= sz) return; grow(newsize); memset(p + sz, 0, newsize - sz); sz = newsize; }
+    void extend(size_t newsize) { if (newsize <= sz) return; grow(newsize); if (oom) return; memset(p + sz, 0, newsize - sz); sz = newsize; }
     size_t put(const void *src, size_t bytes)
     {
         const size_t off = (sz + 15) & ~(size_t) 15;
         grow(off + bytes);
+        if (oom) return 0;
         if (off > sz) memset(p + sz, 0, off - sz);
-        if (bytes) memcpy(p + off, src, bytes);
+        if (bytes >= ((size_t) 64 << 10)) { Copy c = {off, src, bytes}; later.push_back(c); }
+        else if (bytes) memcpy(p + off, src, bytes);
         sz = off + bytes;
         return off;
+    }
+    void flush()
+    {
+        if (later.empty() || oom) return;
+        unsigned nthr = std::thread::hardware_concurrency();
+        if (nthr > 16) nthr = 16;
+        if (nthr < 1) nthr = 1;
+        if (const char *e = getenv("G2G_PACK_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) nthr = (unsigned) v; }
+        if (nthr > later.size()) nthr = (unsigned) later.size();
+        std::atomic<size_t> next(0);
+        auto work = [&]() { for (size_t k; (k = next.fetch_add(1)) < later.size(); ) memcpy(p + later[k].off, later[k].src, later[k].bytes); };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nthr; ++t) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        later.clear();
     }
     char *data() { return p; }
     size_t size() const { return sz; }
@@ -334,7 +363,24 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     b->v3_cols = 128; b->v4_cols = 64; b->v2_cols = G2G_V2_TILE_COLS;
 
     b->dp.resize(n); b->status.assign(n, G2G_OK); b->cells.assign(n, 0); b->out_off.assign(n, 0); b->tcap.assign(n, 0); b->rr1.assign(n, 0);
-    Blob bl;
+    Blob bl(ctx);
+    {   // size the staging buffer once (growing a pinned buffer means allocating and copying it again)
+        auto side_bytes = [](const g2g_side &s) {
+            const size_t cols = (size_t) s.len + 2;
+            size_t t = cols * s.many + 8 * (size_t) s.many + 24 * cols + 256;
+            if (s.pseq && s.nelm > 0) t += 8 * cols * s.nelm;
+            if (s.has_gfq) for (int v = 0; v < 3; ++v) if (s.gfq.off[v]) t += 4 * cols + 12 * (size_t) s.gfq.off[v][s.len + 1] + 64;
+            if (s.gapdens) t += 16 * cols * s.many;
+            return t;
+        };
+        size_t est = (sizeof(DevProb) + 8) * (size_t) (n > 0 ? n : 1) + 4096;
+        for (int i = 0; i < n; ++i) {
+            const g2g_problem *p = prob[i];
+            if (check_problem(p) != G2G_OK) continue;
+            est += side_bytes(p->a) + side_bytes(p->b) + 8 * (size_t) (p->simmtx ? p->simdim * p->simrows : 0) + 64;
+        }
+        bl.grow(est);
+    }
     size_t probs_off = bl.put(0, 0);
     bl.extend(probs_off + sizeof(DevProb) * (size_t) (n > 0 ? n : 1));
     // 1. inputs
@@ -469,6 +515,8 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     }
     b->out_hi = off;
     b->arena_bytes = off + 256;
+    bl.flush();
+    if (bl.oom) { g2g_set_error("%s", "host staging buffer: out of (pinned) memory"); delete b; return G2G_ERR_NOMEM; }
     prep_lap("host image of the inputs");
     hipError_t e = hipMalloc((void **) &b->d_arena, b->arena_bytes);
     prep_lap("hipMalloc(arena)");
