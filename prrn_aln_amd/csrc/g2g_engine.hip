@@ -41,6 +41,8 @@ struct g2g_ctx {
     hipEvent_t ev[4];
     hipEvent_t vev[5];
     char *stage; size_t stage_cap;  // pinned host staging buffer of g2g_batch_prepare, kept between calls
+    char *spare; size_t spare_bytes; // one device arena kept from the last freed batch (hipMalloc/hipFree of tens of GB per
+                                    // call cost up to a second); contents are as undefined as a fresh allocation's
 };
 
 extern "C" g2g_ctx *g2g_create(int device)
@@ -57,6 +59,7 @@ extern "C" g2g_ctx *g2g_create(int device)
     c->device = device;
     c->ok = 0;
     c->stage = 0; c->stage_cap = 0;
+    c->spare = 0; c->spare_bytes = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; g2g_set_error("%s", "stream"); return NULL; }
     for (int i = 0; i < 4; ++i) hipEventCreate(&c->ev[i]);
     for (int i = 0; i < 4; ++i) hipStreamCreateWithFlags(&c->vstream[i], hipStreamNonBlocking);
@@ -80,6 +83,7 @@ extern "C" void g2g_destroy(g2g_ctx *c)
     for (int i = 0; i < 4; ++i) hipStreamDestroy(c->vstream[i]);
     hipStreamDestroy(c->stream);
     if (c->stage) hipHostFree(c->stage);
+    if (c->spare) hipFree(c->spare);
     delete c;
 }
 
@@ -155,6 +159,7 @@ struct g2g_batch {
     std::vector<long long> rr1;     // b.left - a.left + b.right - a.right per problem
     char *d_arena;
     size_t arena_bytes, in_bytes;
+    size_t arena_cap;               // bytes actually allocated behind d_arena (>= arena_bytes when the arena was reused)
     DevProb *d_probs;
     int *d_idx1, *d_idx2;           // problems run by the v1 / v2 forward kernel
     int *d_idxp; int np;            // problems whose boundary chains run in the prologue kernel (the others: as queue entries)
@@ -345,6 +350,18 @@ static void rebase_side(DevSide &d, char *base)
     rebase(d.gapdens, base); rebase(d.postgapdens, base);
 }
 
+// a batch gives its arena back: the context keeps ONE (the larger) for the next prepare
+static void release_arena(g2g_batch *b)
+{
+    if (!b->d_arena) return;
+    g2g_ctx *c = b->ctx;
+    if (getenv("G2G_NO_ARENA_CACHE")) hipFree(b->d_arena);
+    else if (!c->spare) { c->spare = b->d_arena; c->spare_bytes = b->arena_cap; }
+    else if (c->spare_bytes < b->arena_cap) { hipFree(c->spare); c->spare = b->d_arena; c->spare_bytes = b->arena_cap; }
+    else hipFree(b->d_arena);
+    b->d_arena = 0;
+}
+
 extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *prob, g2g_batch **out)
 {
     if (!ctx || n < 0 || !out) return G2G_ERR_ARG;
@@ -518,7 +535,15 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     bl.flush();
     if (bl.oom) { g2g_set_error("%s", "host staging buffer: out of (pinned) memory"); delete b; return G2G_ERR_NOMEM; }
     prep_lap("host image of the inputs");
-    hipError_t e = hipMalloc((void **) &b->d_arena, b->arena_bytes);
+    hipError_t e = hipSuccess;
+    if (ctx->spare && !getenv("G2G_NO_ARENA_CACHE") && ctx->spare_bytes >= b->arena_bytes && ctx->spare_bytes / 2 <= b->arena_bytes + ((size_t) 256 << 20)) {
+        b->d_arena = ctx->spare; b->arena_cap = ctx->spare_bytes;
+        ctx->spare = 0; ctx->spare_bytes = 0;
+    } else {
+        if (ctx->spare) { hipFree(ctx->spare); ctx->spare = 0; ctx->spare_bytes = 0; }     // (too small or far too big)
+        e = hipMalloc((void **) &b->d_arena, b->arena_bytes);
+        b->arena_cap = b->arena_bytes;
+    }
     prep_lap("hipMalloc(arena)");
     if (e != hipSuccess) { g2g_set_error("hipMalloc(arena): %s", hipGetErrorString(e)); delete b; return G2G_ERR_NOMEM; }
     for (int i = 0; i < n; ++i) {
@@ -643,7 +668,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             if (e2 == hipSuccess && b->np) e2 = hipMemcpy(b->d_idxp, ip.data(), sizeof(int) * ip.size(), hipMemcpyHostToDevice);
             if (e2 == hipSuccess) e2 = hipMalloc((void **) &b->d_flags, sizeof(int) * flags.size());
             if (e2 == hipSuccess) e2 = hipMemcpy(b->d_flags, flags.data(), sizeof(int) * flags.size(), hipMemcpyHostToDevice);
-            if (e2 != hipSuccess) { g2g_set_error("tiles: %s", hipGetErrorString(e2)); hipFree(b->d_arena); delete b; return G2G_ERR_NOMEM; }
+            if (e2 != hipSuccess) { g2g_set_error("tiles: %s", hipGetErrorString(e2)); release_arena(b); delete b; return G2G_ERR_NOMEM; }
         }
     }
     prep_lap("descriptors, tiles, flags");
@@ -651,7 +676,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     b->d_probs = (DevProb *) (b->d_arena + probs_off);
     e = hipMemcpyAsync(b->d_arena, bl.data(), bl.size(), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { g2g_set_error("upload: %s", hipGetErrorString(e)); hipFree(b->d_arena); delete b; return G2G_ERR_DEVICE; }
+    if (e != hipSuccess) { g2g_set_error("upload: %s", hipGetErrorString(e)); release_arena(b); delete b; return G2G_ERR_DEVICE; }
     prep_lap("upload");
     *out = b;
     return G2G_OK;
@@ -854,7 +879,7 @@ extern "C" void g2g_batch_free(g2g_batch *b)
 {
     if (!b) return;
     hipSetDevice(b->ctx->device);
-    if (b->d_arena) hipFree(b->d_arena);
+    release_arena(b);
     if (b->d_tiles) hipFree(b->d_tiles);
     if (b->d_flags) hipFree(b->d_flags);
     delete b;
