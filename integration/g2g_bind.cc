@@ -54,7 +54,7 @@ std::mutex	stats_mu;		// (prrn5 -t<n> calls align2 from several pthreads)
 
 // prrn5 -t<n>: thread_onecycle (src/prrn5.cc:565-592) aligns n candidate divisions in n pthreads at once.  One g2g_ctx
 // serves them all, and instead of running their DPs one after the other the calls that arrive together are run as
-// ONE g2g_forward_batch: the first caller leads, collects whatever arrives within a short quiet window, launches, and
+// ONE g2g_forward_batch: the first caller leads, collects whatever arrives until the callers have been quiet for 0.5 ms, launches, and
 // hands every waiting caller its own result.  A lone caller (serial prrn5, aln) goes straight through.
 struct Req {const g2g_problem* p; g2g_result r; bool done;};
 struct Batcher {
@@ -72,11 +72,14 @@ struct Batcher {
 	    while (!q->done) {
 		if (busy) {cv.wait(lk); continue;}
 		busy = true;					// this caller leads the next batch
-		if (callers.size() > 1) {			// let the other threads' calls arrive: quiet for 200 us, 3 ms at most
-		    const auto	t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(3);
+		if (callers.size() > 1) {			// let the other threads' calls arrive: until none has come for
+		    // `quiet` us (default 500), `quiet` x 15 at most.  A batch costs about the same 50-100 ms whether it holds
+		    // one DP or sixty (a DP is a latency-bound chain), so a few ms of waiting for company are well spent.
+		    static const long	quiet = getenv("G2G_BIND_QUIET_US")? atol(getenv("G2G_BIND_QUIET_US")): 500;
+		    const auto	t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(15 * quiet);
 		    for (;;) {
 			const size_t	before = pending.size();
-			cv.wait_for(lk, std::chrono::microseconds(200));
+			cv.wait_for(lk, std::chrono::microseconds(quiet));
 			if (pending.size() == before || pending.size() >= callers.size() ||
 			    std::chrono::steady_clock::now() >= t_end) break;
 		    }
