@@ -212,9 +212,11 @@ def main():
     e2e_ms = None
     if world == 1 and not args.shard_of:
         try:
-            t1 = time.perf_counter()
-            full = op.align2_batch(ctx, holders)
-            e2e_ms = 1e3 * (time.perf_counter() - t1)
+            e2e_ms = float("inf")
+            for _ in range(2):                             # (the first call also allocates its device arena: steady state = min)
+                t1 = time.perf_counter()
+                full = op.align2_batch(ctx, holders)
+                e2e_ms = min(e2e_ms, 1e3 * (time.perf_counter() - t1))
             if any(st != 0 for (_, _, st) in full) or any(a[0] != b_[0] for a, b_ in zip(full, out)):
                 e2e_ms = -e2e_ms                           # scores differ from the resident-batch run: flag it
         except Exception:
