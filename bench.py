@@ -28,7 +28,7 @@ BYTES_PER_CELL = {2: 33, 3: 49}          # 2*Noll*sizeof(double) + 1 direction b
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(sw, budget_s, gpu_scores=None):
+def cpu_baseline(sw, budget_s, gpu_scores=None, gpu_sp=None):
     """Reference (or port) CPU path on a bounded sample, 1 core.  Returns dict for the JSON line.  When the GPU scores
     of this rank's divisions are given, the sampled divisions are also compared score by score (the second half of
     the metric: score delta vs the reference)."""
@@ -41,6 +41,7 @@ def cpu_baseline(sw, budget_s, gpu_scores=None):
     secs = 0.0
     used = []
     ref_scr = {}
+    ref_sp = {}
     try:
         import refdump
         if not refdump.available():
@@ -58,6 +59,11 @@ def cpu_baseline(sw, budget_s, gpu_scores=None):
             ga = R.group(["a%d" % i for i in ia], rows(a), wa)
             gb = R.group(["b%d" % i for i in ib], rows(b), wb)
             sec, c, mode, scr = R.forward_timed(ga, gb)
+            if gpu_sp is not None and int(k) in gpu_sp and len(ref_sp) < 12:
+                try:                                   # untimed: the reference's own align2 + calcSpScore for the SP delta
+                    ref_sp[int(k)] = R.align_fstat(ga, gb)[1]
+                except Exception:
+                    pass
             R.free(ga); R.free(gb)
             cells += c; secs += sec; used.append(int(k)); ref_scr[int(k)] = scr
             if secs > budget_s:
@@ -86,6 +92,10 @@ def cpu_baseline(sw, budget_s, gpu_scores=None):
         both = [k for k in used if k in gpu_scores]
         out["score_delta_vs_ref"] = {"divisions_compared": len(both),
                                      "max_abs_delta": max([abs(gpu_scores[k] - ref_scr[k]) for k in both] or [0.0])}
+    if gpu_sp is not None and ref_sp:
+        # sum-of-pairs score of the NEW alignment (Gsinfo.fstat.val): GPU calcSpScore vs the reference's align2 + calcSpScore
+        out["sp_score_delta_vs_ref"] = {"divisions_compared": len(ref_sp),
+                                        "max_abs_delta": max(abs(gpu_sp[k] - v) for k, v in ref_sp.items())}
     return out
 
 
@@ -205,8 +215,10 @@ def main():
         fst = batch.spscore(sps, [skl for (_, skl, _) in out])
         sp_ms = 1e3 * (time.perf_counter() - t1)
         sp_bad = sum(1 for (_, _, st) in fst if st != 0)
+        gpu_sp = {int(k): float(v) for k, (v, _, st) in zip(mine, fst) if st == 0}
     except Exception as e:                                   # never let the extra row break the benchmark line
         sp_ms, sp_bad = None, str(e)
+        gpu_sp = None
     # (not part of the metric either) the whole operator from host memory: g2g_align2_batch = pack + upload + kernels +
     # fetch + stdskl + end check, i.e. what a caller pays per sweep when nothing is resident
     e2e_ms = None
@@ -275,7 +287,7 @@ def main():
             line["rehearsal"] = "rank 0's share of a %d-rank job on one GPU: %d divisions, %.4g cells, %.1f ms per step" % (
                 args.shard_of, len(mine), my_cells, ms_per_step)
         if not args.no_cpu and world == 1:                # (rank 0 at N = 1 only)
-            line["cpu_baseline"] = cpu_baseline(sw, args.cpu_seconds, {int(k): float(o[0]) for k, o in zip(mine, out)})
+            line["cpu_baseline"] = cpu_baseline(sw, args.cpu_seconds, {int(k): float(o[0]) for k, o in zip(mine, out)}, gpu_sp)
             if line["cpu_baseline"]["value"]:
                 line["config"]["gpu_over_cpu_1core"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line))

@@ -403,4 +403,22 @@ double ref_align_timed(void* ga, void* gb, int64_t* cells, int* alnmode)
 	return scr;
 }
 
+// The whole operator for one pair: PwdM + align2 with a Gsinfo; returns the DP score, *val / *gap receive
+// GsI->fstat.val / .gap (PreSpScore::calcSpScore, fspscore.cc:584-622) -- the sum-of-pairs score prrn's acceptance
+// test reads.  Used by bench.py for the "SP-score delta vs ref" half of the metric.
+double ref_align_fstat(void* ga, void* gb, double* val, double* gap)
+{
+	mSeq*	sqs[3] = {(mSeq*) ga, (mSeq*) gb, 0};
+	sqs[0]->exg_seq(sqs[0]->inex.exgl, sqs[0]->inex.exgr);
+	sqs[1]->exg_seq(sqs[1]->inex.exgl, sqs[1]->inex.exgr);
+	PwdM	pwd(sqs);
+	Gsinfo	gsi;
+	VTYPE	scr = 0;
+	SKL*	skl = align2(sqs, &pwd, &scr, &gsi);
+	delete[] skl;
+	if (val) *val = gsi.fstat.val;
+	if (gap) *gap = gsi.fstat.gap;
+	return scr;
+}
+
 }	// extern "C"

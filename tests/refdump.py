@@ -142,6 +142,17 @@ class RefLib:
         sec = self.lib.ref_forward_timed(ga, gb, ctypes.byref(cells), ctypes.byref(mode), ctypes.byref(scr))
         return sec, cells.value, mode.value, scr.value
 
+    def align_fstat(self, ga, gb):
+        """(DP score, fstat.val, fstat.gap) of the reference's align2 with a Gsinfo."""
+        if not hasattr(self.lib, "ref_align_fstat"):
+            raise RuntimeError("oracle/_ref predates ref_align_fstat: rebuild it")
+        self.lib.ref_align_fstat.restype = ctypes.c_double
+        self.lib.ref_align_fstat.argtypes = [ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        val, gap = ctypes.c_double(0), ctypes.c_double(0)
+        scr = self.lib.ref_align_fstat(ga, gb, ctypes.byref(val), ctypes.byref(gap))
+        return scr, val.value, gap.value
+
     def align_timed(self, ga, gb):
         cells = ctypes.c_int64(0)
         mode = ctypes.c_int(0)
