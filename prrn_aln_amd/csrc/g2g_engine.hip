@@ -500,8 +500,15 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
                 v4_layout(v4_rows_bytes(d), (d.capa + 3) & ~3, b->v4_cols).total <= (int) V2_LDS_MAX) d.v2_ok = 4;
             else if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_AREG") && (d.kind == 1 || getenv("G2G_V3_PF")) && d.a.maxlist <= G2G_V3_NA &&
                 v3_need(d, p, b->v3_cols, true).total <= (int) V2_LDS_MAX) d.v2_ok = 3;
-            else if (!getenv("G2G_FORCE_V2") && (d.kind == 1 || getenv("G2G_V3_PF")) && v3_need(d, p, b->v3_cols).total <= (int) V2_LDS_MAX) d.v2_ok = 2;
-            else if (v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist, b->v2_threads) + 4 * b->v2_threads <= V2_LDS_MAX) d.v2_ok = 1;
+            else {
+                // lists too long for registers: the LDS-list one-lane-per-cell kernel, unless its LDS footprint leaves fewer than
+                // three waves per CU and the 8-lanes-per-cell kernel fits (a 512 x 2048 nt DNA sweep with 17-32 entry lists and
+                // Noll 3: 87 KB per strip; 28.3 s with it, 22.4 s on v2)
+                const bool v2fit = v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist, b->v2_threads) + 4 * b->v2_threads <= V2_LDS_MAX;
+                const int v3tot = (!getenv("G2G_FORCE_V2") && (d.kind == 1 || getenv("G2G_V3_PF"))) ? v3_need(d, p, b->v3_cols).total : (int) V2_LDS_MAX + 1;
+                if (v3tot <= (int) V2_LDS_MAX && (v3tot <= (int) V2_LDS_MAX / 3 || !v2fit || getenv("G2G_NO_AREG"))) d.v2_ok = 2;
+                else if (v2fit) d.v2_ok = 1;
+            }
         }
         if (d.v2_ok) {
             const size_t recsz = (16 + 4 * (size_t) (d.capa + (d.kind == 2 ? d.capb : 0)) + 15) & ~(size_t) 15;
@@ -813,6 +820,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         }
     }
     if (b->n1) {
+        if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v1 (state in HBM): %d of %d problems\n", b->n1, b->n); fflush(stderr); }
         hipLaunchKernelGGL(g2g_forward_kernel, dim3(b->n1), dim3(G2G_FWD_THREADS), 0, ctx->stream,
                            (const DevProb *) b->d_probs, (const int *) b->d_idx1);
         HIPCHK(hipGetLastError());
