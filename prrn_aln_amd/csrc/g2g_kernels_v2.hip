@@ -30,8 +30,12 @@ __device__ unsigned long long g2g_stamp_acc[16];
 #endif
 #define DL_END 0xFFFFu                       // packed terminator glen (INT_MAX in the reference)
 #ifndef G2G_SPIN_MAX
-#define G2G_SPIN_MAX (1 << 22)
+#define G2G_SPIN_MAX (1 << 24)       // ~20-30 s of polling: a producer wave may be parked for seconds when several processes
+                                    // share the GPU (4 ranks rehearsed on one device timed out with 1 << 22)
 #endif
+// once ANY wait of the launch has given up the batch is lost: the others stop waiting at their next check instead of
+// each running out its own bound (a dead dependency chain would otherwise drain one time-out after the other)
+#define G2G_SPIN_BAIL(it, dbg) if (((it) & 4095) == 4095 && __hip_atomic_load((dbg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { (it) = G2G_SPIN_MAX - 1; }
 #define DL_GUARD 128                         // no list is this long: a corrupted one must not hang the wave
 
 // Everything below lives in LDS and says so in its pointer types (address space 3): generic pointers
@@ -775,6 +779,7 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         for (; it < G2G_SPIN_MAX; ++it) {
             if (__hip_atomic_load(prog_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wantl) break;
             __builtin_amdgcn_s_sleep(8);
+            G2G_SPIN_BAIL(it, dbg)
         }
         if (it == G2G_SPIN_MAX) { atomicAdd(dbg, 1); dbg[1] = ti; dbg[2] = -2; }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -849,6 +854,7 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
                 avail = __hip_atomic_load(prog_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (avail >= want) break;
                 __builtin_amdgcn_s_sleep(8);
+                G2G_SPIN_BAIL(it, dbg)
             }
             if (it == G2G_SPIN_MAX) { atomicAdd(dbg, 1); dbg[1] = ti; dbg[2] = col; avail = 0x7fffffff; }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1211,6 +1217,7 @@ __device__ __forceinline__ void v2_wait_flag(const int *flag, int gen, int *dbg,
     for (int it = 0; it < G2G_SPIN_MAX; ++it) {
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gen) return;
         __builtin_amdgcn_s_sleep(8);
+        G2G_SPIN_BAIL(it, dbg)
     }
     atomicAdd(dbg, 1);
     dbg[1] = tile; dbg[2] = (int) (flag - dbg);

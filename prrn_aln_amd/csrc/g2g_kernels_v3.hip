@@ -637,6 +637,7 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
         for (; it < G2G_SPIN_MAX; ++it) {
             if (__hip_atomic_load(prog_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wantl) break;
             __builtin_amdgcn_s_sleep(8);
+            G2G_SPIN_BAIL(it, dbg)
         }
         if (it == G2G_SPIN_MAX) { atomicAdd(dbg, 1); dbg[1] = ti; dbg[2] = -2; }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -758,6 +759,7 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
                 avail = __hip_atomic_load(prog_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (avail >= want) break;
                 __builtin_amdgcn_s_sleep(8);
+                G2G_SPIN_BAIL(it, dbg)
             }
             if (it == G2G_SPIN_MAX) { atomicAdd(dbg, 1); dbg[1] = ti; dbg[2] = col; avail = 0x7fffffff; }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
