@@ -543,11 +543,11 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     if (bl.oom) { g2g_set_error("%s", "host staging buffer: out of (pinned) memory"); delete b; return G2G_ERR_NOMEM; }
     prep_lap("host image of the inputs");
     hipError_t e = hipSuccess;
-    if (ctx->spare && !getenv("G2G_NO_ARENA_CACHE") && ctx->spare_bytes >= b->arena_bytes && ctx->spare_bytes / 2 <= b->arena_bytes + ((size_t) 256 << 20)) {
+    if (ctx->spare && !getenv("G2G_NO_ARENA_CACHE") && ctx->spare_bytes >= b->arena_bytes) {   // (any size that fits: batch sizes of a refinement loop vary call by call)
         b->d_arena = ctx->spare; b->arena_cap = ctx->spare_bytes;
         ctx->spare = 0; ctx->spare_bytes = 0;
     } else {
-        if (ctx->spare) { hipFree(ctx->spare); ctx->spare = 0; ctx->spare_bytes = 0; }     // (too small or far too big)
+        if (ctx->spare) { hipFree(ctx->spare); ctx->spare = 0; ctx->spare_bytes = 0; }     // (too small: replaced by this batch's arena on release)
         e = hipMalloc((void **) &b->d_arena, b->arena_bytes);
         b->arena_cap = b->arena_bytes;
     }
