@@ -15,6 +15,7 @@
 //
 // G2G_BIND=off     every call goes to the reference (A/B switch)
 // G2G_BIND=verify  both run; score and skeleton are compared, mismatches counted, the reference's result returned
+// G2G_BIND_MIN_CELLS=<n>  DPs whose rectangle has fewer than n cells stay on the CPU (default 0: none)
 // A summary line is written to stderr at exit when G2G_BIND_STATS is set.
 
 #include <stdint.h>
@@ -242,6 +243,10 @@ bool on_gpu_path(mSeq* seqs[], PwdM* pwdm, Gsinfo* GsI)
 {
 	if (!GsI || (algmode.qck & 1)) return false;
 	if (seqs[0]->left == seqs[0]->right || seqs[1]->left == seqs[1]->right) return false;
+	// G2G_BIND_MIN_CELLS=<n>: rectangles smaller than n cells stay on the CPU (one GPU round trip costs ~2 ms of launches
+	// and synchronisation, about 3e4 cells of a host core); default 0 = everything on the path goes to the GPU
+	static const double	min_cells = getenv("G2G_BIND_MIN_CELLS")? atof(getenv("G2G_BIND_MIN_CELLS")): 0;
+	if (min_cells > 0 && (double) (seqs[0]->right - seqs[0]->left) * (seqs[1]->right - seqs[1]->left) < min_cells) return false;
 	switch (pwdm->alnmode) {
 	    case NGP_ALB: case HLF_ALB: case RHF_ALB: case GPF_ALB: case NTV_ALB: return true;
 	    default: return false;
