@@ -222,7 +222,7 @@ def main():
     # (not part of the metric either) the whole operator from host memory: g2g_align2_batch = pack + upload + kernels +
     # fetch + stdskl + end check, i.e. what a caller pays per sweep when nothing is resident
     e2e_ms = None
-    if world == 1 and not args.shard_of:
+    if world == 1 and not args.shard_of and not args.no_cpu:     # (--no-cpu = the timed region only: profiling runs)
         try:
             e2e_ms = float("inf")
             for _ in range(2):                             # (the first call also allocates its device arena: steady state = min)
