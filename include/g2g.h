@@ -128,7 +128,13 @@ typedef struct g2g_result {
 
 typedef struct g2g_ctx g2g_ctx;
 
-/* Create a context bound to one HIP device (device < 0: current device).  Returns NULL on failure. */
+/* Create a context bound to one HIP device (device < 0: current device).  Returns NULL on failure.
+   Threading: a context (its streams, its pinned staging buffer and its spare device arena) serves ONE host thread at a
+   time -- callers with several threads serialise their calls or batch them (integration/g2g_bind.cc does the latter);
+   the group / PwdM builders (g2g_group_create, g2g_pwdm_create) touch only their own objects and may run on any
+   number of threads.  g2g_last_error() is per thread.  One process per GPU: the persistent kernels poll flags
+   written by other resident workgroups of the same launch and must not compete with another process for the device
+   (every wait is bounded; an oversubscribed device shows up as a failed batch, not a hang).                       */
 g2g_ctx *g2g_create(int device);
 void     g2g_destroy(g2g_ctx *ctx);
 const char *g2g_last_error(void);
