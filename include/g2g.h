@@ -201,12 +201,15 @@ const g2g_problem *g2g_pwdm_problem(const g2g_pwdm *p);
  * (src/fspscore.h:202-254, calscr src/fspscore.cc:346-541) followed by PwdM::rescale (src/maln2.cc:245-252): the score is
  * re-evaluated ALONG the path (column scores, unpaired-column penalties and the gap-open counts of the gap-profile
  * algebra) and returned per unit pair weight; Prrn::onecycle takes fstat.val of the old and the new alignment as the
- * acceptance delta.  On this path: NGP / HLF / RHF / GPF modes with Noll 2 (the naive NTV units and the long-gap
- * bookkeeping `Gep1st` of -yl3 are not: G2G_ERR_MODE).  mch/mmc/unp of FSTAT (PwdM::stt2) are not computed.        */
+ * acceptance delta.  On this path: NGP / HLF / RHF / GPF modes with Noll 2 and 3 (-yl3: the long-gap bookkeeping
+ * `Gep1st`, src/mseq.cc:658-758, included); the naive NTV units are not: G2G_ERR_MODE.  mch/mmc/unp of FSTAT
+ * (PwdM::stt2) are not computed.                                                                                  */
 typedef struct {
     double vab;          /* PwdM::Vab = scale * wa * wb (src/maln2.cc:234)                         */
     double basic_gep;    /* PwdB::BasicGEP = -u * axbscale (src/aln2.cc:103)                       */
     double diffu;        /* PwdB::diffu = LongGEP - BasicGEP (src/aln2.cc:105)                      */
+    double diff_u;       /* PwdM::diff_u = scale * (u - u1) (src/maln2.cc:233): weight of the long-gap count `lunp` in
+                            PwdM::wgop (maln.h:321-325); only read when Noll = 3                                */
 } g2g_spparams;
 typedef struct { double val, gap; int32_t status; int32_t reserved; } g2g_fstat;
 /* level 0: on a prepared batch (inputs resident in HBM); skl[i] = the standardised skeleton of problem i

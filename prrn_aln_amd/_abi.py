@@ -122,7 +122,7 @@ def problem_from_arrays(d: Dict[str, np.ndarray]) -> ProblemHolder:
 
 
 class SpParams(C.Structure):
-    _fields_ = [("vab", C.c_double), ("basic_gep", C.c_double), ("diffu", C.c_double)]
+    _fields_ = [("vab", C.c_double), ("basic_gep", C.c_double), ("diffu", C.c_double), ("diff_u", C.c_double)]
 
 
 class Fstat(C.Structure):

@@ -919,16 +919,31 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
     char *d = 0;
     const size_t o_skl = 0, o_off = (b_skl + 15) & ~(size_t) 15, o_cnt = o_off + ((b_int + 15) & ~(size_t) 15),
                  o_sp = o_cnt + ((b_int + 15) & ~(size_t) 15), o_out = o_sp + ((b_sp + 15) & ~(size_t) 15),
-                 o_st = o_out + ((b_out + 15) & ~(size_t) 15), total = o_st + b_int;
+                 o_st = o_out + ((b_out + 15) & ~(size_t) 15);
+    // Gep1st rings (Noll 3, gap-profile units): (a.many + b.many) x (codonk1 + 1) ints per problem, zeroed
+    std::vector<long long> goff(n, -1);
+    size_t gints = 0;
+    for (int i = 0; i < n; ++i) {
+        const DevProb &dp = b->dp[i];
+        if (dp.kind >= 1 && dp.kind <= 2 && dp.noll == 3 && dp.codonk1 > 0 && dp.codonk1 < (1 << 20)) {
+            goff[i] = (long long) gints;
+            gints += (size_t) (dp.a.many + dp.b.many) * ((size_t) dp.codonk1 + 1);
+        }
+    }
+    const size_t b_goff = sizeof(long long) * n, o_goff = (o_st + b_int + 15) & ~(size_t) 15,
+                 o_gws = (o_goff + b_goff + 15) & ~(size_t) 15, total = o_gws + sizeof(int) * (gints ? gints : 1);
     HIPCHK(hipMalloc((void **) &d, total));
     hipError_t e = hipMemcpyAsync(d + o_skl, all.data(), b_skl, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_off, off.data(), b_int, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_cnt, cnt.data(), b_int, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_sp, sp, b_sp, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_goff, goff.data(), b_goff, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && gints) e = hipMemsetAsync(d + o_gws, 0, sizeof(int) * gints, ctx->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(g2g_spscore_kernel, dim3(n), dim3(64), 0, ctx->stream, (const DevProb *) b->d_probs, n,
                            (const SpParamsDev *) (d + o_sp), (const int2 *) (d + o_skl), (const int *) (d + o_off),
-                           (const int *) (d + o_cnt), (double *) (d + o_out), (int *) (d + o_st));
+                           (const int *) (d + o_cnt), (double *) (d + o_out), (int *) (d + o_st),
+                           gints ? (int *) (d + o_gws) : (int *) 0, (const long long *) (d + o_goff));
         e = hipGetLastError();
     }
     std::vector<double> ho(2 * (size_t) n);

@@ -645,6 +645,7 @@ extern "C" g2g_pwdm *g2g_pwdm_create(g2g_ctx *, const g2g_params *prm, g2g_group
         const double wa = a_mode ? a.sumwt : 1, wb = b_mode ? b.sumwt : 1;
         P->sp.vab = (double) (prm->scale * wa * wb);
         P->sp.basic_gep = BasicGEP; P->sp.diffu = diffu;
+        P->sp.diff_u = (double) (f_scale * (f_u - f_u1));      // resetuab, src/maln2.cc:233 (float arithmetic)
     }
     if (swapped) *swapped = swp;
     return P;

@@ -683,10 +683,62 @@ extern "C" __global__ void __launch_bounds__(64) g2g_traceback_kernel(const DevP
 // PwdM::wgop + PwdM::rescale (maln.h:321-325, maln2.cc:245-252).  A dependent chain per alignment (every column
 // updates the dynamic gap lists the next one reads): one wave per alignment, lane 0 walks; alignments run in parallel.
 // The lists live in the first slot of the v1 state arrays of the problem (free once the forward sweep is over).
-struct SpParamsDev { double vab, basic_gep, diffu; };
+struct SpParamsDev { double vab, basic_gep, diffu, diff_u; };      // = g2g_spparams
+// Gep1st (reference src/mseq.h:355-373, src/mseq.cc:658-758): per member a ring of the last k1 positions that held a
+// residue; counts the "long" part of unpaired runs (`lunp`) when Noll = 3.  Rings live in a zeroed workspace in HBM
+// ((many) x (k1 + 1) ints per side); one lane walks the members IN ORDER (the weights are summed in member order).
+struct GepDev { int many, k1; int *q, *qp; const double *w; };
+__device__ __forceinline__ int gep_shift1(const GepDev &g, int i, int n)
+{   // Queue::shift, clib.h:322-326
+    int *slot = g.q + (size_t) i * g.k1 + g.qp[i];
+    const int old = *slot;
+    *slot = n;
+    if (++g.qp[i] == g.k1) g.qp[i] = 0;
+    return old;
+}
+__device__ __forceinline__ int gep_oldest(const GepDev &g, int i) { return g.q[(size_t) i * g.k1 + g.qp[i]]; }
+__device__ void gep_shift(const GepDev &g, const uint8_t *res, int n)
+{   // mseq.cc:675-679
+    for (int i = 0; i < g.many; ++i) if (res[i] > 1) gep_shift1(g, i, n);
+}
+__device__ double gep_longup_res(const GepDev &g, const uint8_t *res, int n, int tgl, bool sft)
+{   // mseq.cc:681-696
+    double lu = 0;
+    for (int i = 0; i < g.many; ++i)
+        if (res[i] > 1) {
+            const int cp = n - (sft ? gep_shift1(g, i, n) : gep_oldest(g, i));
+            if (tgl > cp) { if (g.w) lu += g.w[i]; else lu += 1; }
+        }
+    return lu;
+}
+__device__ __forceinline__ int sl_len(const SList df) { int k = 0; while (df.glen[k] >= 0) ++k; return k; }
+__device__ double gep_longup_half(const GepDev &g, const SList df, const DList dld, int pos)
+{   // mseq.cc:729-742
+    double lunp = 0;
+    for (int k = sl_len(df) - 1; k > 0; --k) {
+        const int gi = gaplen_sd(df.glen[k], dld);
+        if (gi > pos - gep_oldest(g, 0)) lunp += df.freq[k];
+        else break;
+    }
+    gep_shift1(g, 0, pos);
+    return lunp;
+}
+__device__ double gep_longup_both(const GepDev &g, const SList df, const DList dld, const uint8_t *res, int pos)
+{   // mseq.cc:744-758
+    double lunp = 0;
+    for (int k = sl_len(df) - 1; k > 0; --k) {
+        const int gi = gaplen_sd(df.glen[k], dld);
+        const double lu = gep_longup_res(g, res, pos, gi, false) * df.freq[k];
+        if (lu == 0) break;
+        lunp += lu;
+    }
+    gep_shift(g, res, pos);
+    return lunp;
+}
 template <int KIND>
 __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int ni, int &apos, int &bpos, int &glb,
-                          const DList dla, const DList dlb, double &scr, double &tgap)
+                          const DList dla, const DList dlb, double &scr, double &tgap,
+                          const bool gep, const GepDev &agep, const GepDev &bgep, double &lunp)
 {
     const DevSide &a = P.a, &b = P.b;
     if (KIND == 0) {
@@ -714,6 +766,7 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
                 scr += sim2(P, apos, bpos);
                 tgap += newgap_di(gfq_at(a, 1, apos), glb, dla);
                 newdelta(dla, gfq_at(a, 1, apos), dla);
+                if (gep) { lunp += gep_longup_half(bgep, gfq_at(a, 1, apos), dla, bpos); gep_shift(agep, res_at(a, apos), apos); }
                 glb = 0;
             }
         } else if (mi) {
@@ -723,6 +776,7 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
                 tgap += newgap_cj(gfq_at(a, 0, apos), dla, glb);
                 newdelta(dla, gfq_at(a, 1, apos), dla);
                 ++glb;
+                if (gep) lunp += gep_longup_res(agep, res_at(a, apos), apos, glb, true);
             }
         } else if (ni) {
             while (ni--) {
@@ -730,6 +784,7 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
                 scr += unpb(P, bpos, apos);
                 tgap += newgap_di(gfq_at(a, 2, apos), glb, dla);
                 incdelta2(dla, dla);
+                if (gep) lunp += gep_longup_half(bgep, gfq_at(a, 2, apos), dla, bpos);
             }
         }
     } else {
@@ -741,6 +796,10 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
                       + newgap4(gfq_at(b, 0, bpos), dlb, gfq_at(a, 1, apos), dla);
                 newdelta(dla, gfq_at(a, 1, apos), dla);
                 newdelta(dlb, gfq_at(b, 1, bpos), dlb);
+                if (gep) {
+                    lunp += gep_longup_both(agep, gfq_at(b, 1, bpos), dlb, res_at(a, apos), apos);
+                    lunp += gep_longup_both(bgep, gfq_at(a, 1, apos), dla, res_at(b, bpos), bpos);
+                }
             }
         } else if (mi) {
             while (mi--) {
@@ -749,6 +808,7 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
                 tgap += newgap4(gfq_at(a, 0, apos), dla, gfq_at(b, 2, bpos), dlb);
                 newdelta(dla, gfq_at(a, 1, apos), dla);
                 incdelta2(dlb, dlb);
+                if (gep) lunp += gep_longup_both(agep, gfq_at(b, 2, bpos), dlb, res_at(a, apos), apos);
             }
         } else if (ni) {
             while (ni--) {
@@ -757,13 +817,22 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
                 tgap += newgap4(gfq_at(b, 0, bpos), dlb, gfq_at(a, 2, apos), dla);
                 newdelta(dlb, gfq_at(b, 1, bpos), dlb);
                 incdelta2(dla, dla);
+                if (gep) lunp += gep_longup_both(bgep, gfq_at(a, 2, apos), dla, res_at(b, bpos), bpos);
             }
         }
     }
 }
 template <int KIND>
-__device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *skl, int nskl, double *out)
+__device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *skl, int nskl, double *out, int *gepws)
 {
+    // Gep1st of both sides (fspscore.h:146-147: alprm.ls > 2); the workspace arrives zeroed
+    const bool gep = KIND >= 1 && P.noll == 3 && gepws != 0;
+    GepDev agep, bgep;
+    agep.many = P.a.many; bgep.many = P.b.many; agep.k1 = bgep.k1 = P.codonk1;
+    agep.w = P.a.weight; bgep.w = P.b.weight;
+    agep.q = gepws; agep.qp = gepws + (size_t) P.a.many * P.codonk1;
+    bgep.q = agep.qp + P.a.many; bgep.qp = bgep.q + (size_t) P.b.many * P.codonk1;
+    double lunp = 0;
     DList dla, dlb;
     dla.p = P.dla[XH]; dla.s = P.width; dlb.p = P.dlb[XH]; dlb.s = P.width;
     if (KIND >= 1) cleardelta(dla);
@@ -773,29 +842,31 @@ __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *
     double scr = 0, tgap = 0;
     for (int k = 1; k < nskl; ++k) {
         const int mi = skl[k].x - m, ni = skl[k].y - n, i = mi - ni;
-        if (!i || !mi || !ni) sp_calscr<KIND>(P, sp, mi, ni, apos, bpos, glb, dla, dlb, scr, tgap);
-        else if (i > 0) { sp_calscr<KIND>(P, sp, ni, ni, apos, bpos, glb, dla, dlb, scr, tgap); sp_calscr<KIND>(P, sp, i, 0, apos, bpos, glb, dla, dlb, scr, tgap); }
-        else { sp_calscr<KIND>(P, sp, mi, mi, apos, bpos, glb, dla, dlb, scr, tgap); sp_calscr<KIND>(P, sp, 0, -i, apos, bpos, glb, dla, dlb, scr, tgap); }
+        if (!i || !mi || !ni) sp_calscr<KIND>(P, sp, mi, ni, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp);
+        else if (i > 0) { sp_calscr<KIND>(P, sp, ni, ni, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp); sp_calscr<KIND>(P, sp, i, 0, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp); }
+        else { sp_calscr<KIND>(P, sp, mi, mi, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp); sp_calscr<KIND>(P, sp, 0, -i, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp); }
         m = skl[k].x; n = skl[k].y;
     }
-    scr += tgap * (KIND == 1 ? P.weighted_gop : P.basic_gop);                   // wgop(tgap, 0)
+    scr += tgap * (KIND == 1 ? P.weighted_gop : P.basic_gop) + sp.diff_u * lunp;    // wgop(tgap, lunp), maln.h:321-325
     out[0] = scr / sp.vab;                                                       // rescale
     out[1] = tgap / sp.vab;
 }
 extern "C" __global__ void __launch_bounds__(64)
 g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const int2 *skl, const int *skl_off, const int *nskl,
-                   double *out, int *status)
+                   double *out, int *status, int *gepws, const long long *gep_off)
 {
     const int ip = blockIdx.x;
     if (ip >= nprob || threadIdx.x != 0) return;
     const DevProb &P = probs[ip];
     out[2 * ip] = 0; out[2 * ip + 1] = 0;
     if (P.kind < 0) { status[ip] = -1; return; }
-    if (P.kind == 3 || P.noll != 2) { status[ip] = -2; return; }                // naive units / Gep1st: not on this path
+    if (P.kind == 3) { status[ip] = -2; return; }                               // naive units: not on this path
+    int *ws = (gepws && gep_off[ip] >= 0) ? gepws + gep_off[ip] : (int *) 0;
+    if (P.noll == 3 && P.kind >= 1 && !ws) { status[ip] = -2; return; }
     if (nskl[ip] < 2) { status[ip] = -1; return; }
     const int2 *s = skl + skl_off[ip];
-    if (P.kind == 0) sp_calcskl<0>(P, sp[ip], s, nskl[ip], out + 2 * ip);
-    else if (P.kind == 1) sp_calcskl<1>(P, sp[ip], s, nskl[ip], out + 2 * ip);
-    else sp_calcskl<2>(P, sp[ip], s, nskl[ip], out + 2 * ip);
+    if (P.kind == 0) sp_calcskl<0>(P, sp[ip], s, nskl[ip], out + 2 * ip, ws);
+    else if (P.kind == 1) sp_calcskl<1>(P, sp[ip], s, nskl[ip], out + 2 * ip, ws);
+    else sp_calcskl<2>(P, sp[ip], s, nskl[ip], out + 2 * ip, ws);
     status[ip] = 0;
 }

@@ -59,6 +59,7 @@ def test_builders_match_reference(path):
     sp = op.spparams(pw)                               # scalars of PreSpScore::calcSpScore (f1)
     assert sp.vab == d["Vab"][0] and sp.basic_gep == d["BasicGEP"][0]
     assert sp.diffu == d["LongGEP"][0] - d["BasicGEP"][0]
+    assert sp.diff_u == d["diff_u"][0]
     ref = _abi.problem_from_arrays(d).c
     assert q.u2divu1 == ref.u2divu1 and q.v2divv1 == ref.v2divv1 and q.u == ref.u
     for pfx, s in (("a_", q.a), ("b_", q.b)):

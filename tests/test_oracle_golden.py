@@ -48,11 +48,12 @@ def test_oracle_homscore(L, path):
     assert [rr[0], rr[1]] == d["homscore_rr"].tolist()
 
 
-SP_GOLD = [f for f in GOLD if int(np.load(f)["alnmode"][0]) in (6, 8, 9) and int(np.load(f)["Noll"][0]) == 2]
+SP_GOLD = [f for f in GOLD if int(np.load(f)["alnmode"][0]) in (6, 8, 9)]            # Noll 2 and 3 (Gep1st)
 
 
 def sp_from_golden(d):
-    return _abi.SpParams(float(d["Vab"][0]), float(d["BasicGEP"][0]), float(d["LongGEP"][0]) - float(d["BasicGEP"][0]))
+    return _abi.SpParams(float(d["Vab"][0]), float(d["BasicGEP"][0]), float(d["LongGEP"][0]) - float(d["BasicGEP"][0]),
+                         float(d["diff_u"][0]))
 
 
 @pytest.mark.parametrize("path", SP_GOLD, ids=[os.path.basename(p)[:-4] for p in SP_GOLD])
@@ -70,4 +71,4 @@ def test_oracle_spscore_scope(L):
     other = [f for f in GOLD if f not in SP_GOLD]
     d = dict(np.load(other[0]))
     rc, _, _ = oraclelib.spscore(L, _abi.problem_from_arrays(d), sp_from_golden(d), d["align2_skl"])
-    assert rc == -2                                  # naive units / long-gap bookkeeping: G2G_ERR_MODE
+    assert rc == -2                                  # naive units: G2G_ERR_MODE
