@@ -686,7 +686,10 @@ extern "C" __global__ void __launch_bounds__(64) g2g_traceback_kernel(const DevP
 struct SpParamsDev { double vab, basic_gep, diffu, diff_u; };      // = g2g_spparams
 // Gep1st (reference src/mseq.h:355-373, src/mseq.cc:658-758): per member a ring of the last k1 positions that held a
 // residue; counts the "long" part of unpaired runs (`lunp`) when Noll = 3.  Rings live in a zeroed workspace in HBM
-// ((many) x (k1 + 1) ints per side); one lane walks the members IN ORDER (the weights are summed in member order).
+// ((many) x (k1 + 1) ints per side).  The whole wave executes the chain in lockstep (every lane replays the scalar part:
+// same loads, same values, same stores); the member loops are spread over the lanes (member i on lane i mod 64) and the
+// weights of the members that count are added IN MEMBER ORDER by a ballot walk every lane performs identically.
+__device__ __forceinline__ void gep_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 struct GepDev { int many, k1; int *q, *qp; const double *w; };
 __device__ __forceinline__ int gep_shift1(const GepDev &g, int i, int n)
 {   // Queue::shift, clib.h:322-326
@@ -699,16 +702,27 @@ __device__ __forceinline__ int gep_shift1(const GepDev &g, int i, int n)
 __device__ __forceinline__ int gep_oldest(const GepDev &g, int i) { return g.q[(size_t) i * g.k1 + g.qp[i]]; }
 __device__ void gep_shift(const GepDev &g, const uint8_t *res, int n)
 {   // mseq.cc:675-679
-    for (int i = 0; i < g.many; ++i) if (res[i] > 1) gep_shift1(g, i, n);
+    for (int i = threadIdx.x; i < g.many; i += 64) if (res[i] > 1) gep_shift1(g, i, n);
+    gep_wave_sync();
 }
 __device__ double gep_longup_res(const GepDev &g, const uint8_t *res, int n, int tgl, bool sft)
 {   // mseq.cc:681-696
     double lu = 0;
-    for (int i = 0; i < g.many; ++i)
-        if (res[i] > 1) {
+    for (int base = 0; base < g.many; base += 64) {
+        const int i = base + (int) threadIdx.x;
+        bool hit = false;
+        if (i < g.many && res[i] > 1) {
             const int cp = n - (sft ? gep_shift1(g, i, n) : gep_oldest(g, i));
-            if (tgl > cp) { if (g.w) lu += g.w[i]; else lu += 1; }
+            hit = tgl > cp;
         }
+        unsigned long long m = __ballot(hit);
+        while (m) {                                            // members that count, ascending: the reference's order of the sum
+            const int j = __ffsll((long long) m) - 1;
+            m &= m - 1;
+            if (g.w) lu += g.w[base + j]; else lu += 1;
+        }
+    }
+    if (sft) gep_wave_sync();
     return lu;
 }
 __device__ __forceinline__ int sl_len(const SList df) { int k = 0; while (df.glen[k] >= 0) ++k; return k; }
@@ -720,7 +734,9 @@ __device__ double gep_longup_half(const GepDev &g, const SList df, const DList d
         if (gi > pos - gep_oldest(g, 0)) lunp += df.freq[k];
         else break;
     }
-    gep_shift1(g, 0, pos);
+    gep_wave_sync();                                           // (every lane has read ring 0 before lane 0 moves it)
+    if (threadIdx.x == 0) gep_shift1(g, 0, pos);
+    gep_wave_sync();
     return lunp;
 }
 __device__ double gep_longup_both(const GepDev &g, const SList df, const DList dld, const uint8_t *res, int pos)
@@ -856,7 +872,7 @@ g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const
                    double *out, int *status, int *gepws, const long long *gep_off)
 {
     const int ip = blockIdx.x;
-    if (ip >= nprob || threadIdx.x != 0) return;
+    if (ip >= nprob) return;                                   // (all 64 lanes walk the chain in lockstep, see GepDev)
     const DevProb &P = probs[ip];
     out[2 * ip] = 0; out[2 * ip + 1] = 0;
     if (P.kind < 0) { status[ip] = -1; return; }
