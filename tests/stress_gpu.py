@@ -1,6 +1,7 @@
 """Randomised GPU-vs-oracle parity stress (run by hand on the GPU box: python tests/stress_gpu.py [seed] [families]).
 Random families over group sizes, lengths, indel rates/lengths, protein/DNA, ls 1/3, tgapf 1/0.5, weighted or not;
-every division of every family is aligned by the product and compared bit for bit with the CPU oracle.  Kernel paths
+every division of every family is aligned by the product and compared bit for bit with the CPU oracle (score, skeleton,
+and the sum-of-pairs score of calcSpScore along the new path).  Kernel paths
 can be forced with the G2G_* environment variables listed in DESIGN.md section 4."""
 import sys, os, random, time
 R=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,12 +24,15 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 14):
     if dna: akw.update(molc=op.DNA,max_code=17)
     sw=sweep.Sweep(fam, op.AlnParam(**akw), weighted=rng.random()<0.7)
     res=op.align2_batch(ctx, sw.pwds)
+    fs=op.calcSpScore_batch(ctx, sw.pwds, [skl for (_,skl,_) in res])      # f1: sum-of-pairs score along the new path
     modes=set()
-    for pw,(scr,skl,st) in zip(sw.pwds,res):
+    for pw,(scr,skl,st),(val,gap,fst) in zip(sw.pwds,res,fs):
         class H: c=pw.problem
         oscr,oc,otr=oraclelib.forward(L,H)
         ok = st==0 and scr==oscr and np.array_equal(skl, oraclelib.stdskl(L,otr))
+        rc,oval,ogap=oraclelib.spscore(L,H,op.spparams(pw),skl)
+        ok = ok and ((fst==0)==(rc==0)) and (rc!=0 or (val==oval and gap==ogap))
         tot+=1; bad+= (not ok); modes.add((pw.alnmode,pw.problem.noll))
-        if not ok: print('MISMATCH', kw, akw, pw.alnmode, st, scr, oscr)
+        if not ok: print('MISMATCH', kw, akw, pw.alnmode, st, scr, oscr, fst, rc, val, oval)
     print(it, kw, akw, 'divisions', len(sw.pwds), 'modes', sorted(modes), 'bad so far', bad, flush=True)
 print('total', tot, 'bad', bad, 'sec', round(time.time()-t0,1))
