@@ -48,7 +48,7 @@ def test_oracle_homscore(L, path):
     assert [rr[0], rr[1]] == d["homscore_rr"].tolist()
 
 
-SP_GOLD = [f for f in GOLD if int(np.load(f)["alnmode"][0]) in (6, 8, 9)]            # Noll 2 and 3 (Gep1st)
+SP_GOLD = [f for f in GOLD if int(np.load(f)["alnmode"][0]) in (6, 8, 9, 10)]        # Noll 2 and 3 (Gep1st); naive units
 
 
 def sp_from_golden(d):
@@ -67,8 +67,6 @@ def test_oracle_spscore(L, path):
 
 
 def test_oracle_spscore_scope(L):
-    assert len(SP_GOLD) >= 20
-    other = [f for f in GOLD if f not in SP_GOLD]
-    d = dict(np.load(other[0]))
-    rc, _, _ = oraclelib.spscore(L, _abi.problem_from_arrays(d), sp_from_golden(d), d["align2_skl"])
-    assert rc == -2                                  # naive units: G2G_ERR_MODE
+    """every reference golden pins calcSpScore: plain, half- and full-profile units with Noll 2 and 3, and the naive units
+    SPunit_nv / _w11 / _w22 (SPunit_w21 -- weights, b a single, a several -- has no golden and reports G2G_ERR_MODE)"""
+    assert len(SP_GOLD) == len(GOLD) >= 53
