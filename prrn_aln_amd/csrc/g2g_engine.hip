@@ -920,14 +920,16 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
     const size_t o_skl = 0, o_off = (b_skl + 15) & ~(size_t) 15, o_cnt = o_off + ((b_int + 15) & ~(size_t) 15),
                  o_sp = o_cnt + ((b_int + 15) & ~(size_t) 15), o_out = o_sp + ((b_sp + 15) & ~(size_t) 15),
                  o_st = o_out + ((b_out + 15) & ~(size_t) 15);
-    // Gep1st rings (Noll 3, gap-profile units): (a.many + b.many) x (codonk1 + 1) ints per problem, zeroed
+    // Gep1st rings (Noll 3): (a.many + b.many) x (codonk1 + 1) ints per problem; naive units: their gap-length arrays; zeroed
     std::vector<long long> goff(n, -1);
     size_t gints = 0;
     for (int i = 0; i < n; ++i) {
         const DevProb &dp = b->dp[i];
-        if (dp.kind >= 1 && dp.kind <= 2 && dp.noll == 3 && dp.codonk1 > 0 && dp.codonk1 < (1 << 20)) {
+        const bool rings = dp.kind >= 1 && dp.noll == 3 && dp.codonk1 > 0 && dp.codonk1 < (1 << 20);
+        if (rings || dp.kind == 3) {                      // kind 3 (naive units): + gla[an], glb[bn] in front of the rings
             goff[i] = (long long) gints;
-            gints += (size_t) (dp.a.many + dp.b.many) * ((size_t) dp.codonk1 + 1);
+            if (dp.kind == 3) gints += (size_t) dp.a.many + dp.b.many + 2;
+            if (rings) gints += (size_t) (dp.a.many + dp.b.many) * ((size_t) dp.codonk1 + 1);
         }
     }
     const size_t b_goff = sizeof(long long) * n, o_goff = (o_st + b_int + 15) & ~(size_t) 15,

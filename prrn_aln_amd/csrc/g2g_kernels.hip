@@ -838,12 +838,159 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
         }
     }
 }
+
+// ---- naive units of calcSpScore (NTV modes): SPunit_nv / _w11 / _w22, reference src/fspscore.h:34-78, calcstat
+// src/fspscore.cc:60-340, calscr :365-470.  Groups are tiny (2 nj + ni < 8): every lane replays everything.
+struct NtvState { int unit; int *gla, *glb; };            // unit: 0 nv, 1 w11, 2 w22; per member running gap lengths
+__device__ __forceinline__ bool gep_long1(const GepDev &g, int i, int n, int tgl) { return tgl > n - gep_oldest(g, i); }
+__device__ void sp_incrgap(int *gg, const uint8_t *ss, int n)
+{   // incrgap, mgaps.cc:431-440
+    for (int i = 0; i < n; ++i) { if (!ss || ss[i] <= 1) ++gg[i]; else gg[i] = 0; }
+}
+__device__ void sp_pregap(const DevSide &sd, int *gl)
+{   // Seq::pregap, seq.cc:1870-1883
+    for (int i = 0; i < sd.many; ++i) {
+        int n = sd.left;
+        for ( ; n > 0; --n) if (res_at(sd, n - 1)[i] > 1) break;
+        gl[i] = sd.left - n;
+    }
+}
+__device__ void sp_calcstat_ntv(const DevProb &P, const NtvState &N, int d3, int apos, int bpos, double &scr, double &tgap,
+                                const bool gep, const GepDev &agep, const GepDev &bgep, double &lunp)
+{
+    const DevSide &a = P.a, &b = P.b;
+    const int an = a.many, bn = b.many;
+    const uint8_t *as = res_at(a, apos), *bs = res_at(b, bpos);
+    const double *agd = a.gapdens + (size_t) (apos + 1) * an, *bgd = b.gapdens + (size_t) (bpos + 1) * bn;
+    const double *apg = a.postgapdens + (size_t) (apos + 1) * an, *bpg = b.postgapdens + (size_t) (bpos + 1) * bn;
+    scr += d3 == 0 ? sim2(P, apos, bpos) : d3 > 0 ? unpa(P, apos, bpos) : unpb(P, bpos, apos);
+    if (N.unit == 1) {                                         // SPunit_w11: scalars, member 0 of either side
+        const int gla = N.gla[0], glb = N.glb[0];
+        if (d3 == 0) {
+            const bool ar = as[0] > 1, br = bs[0] > 1;
+            const double au = agd[0], bu = bgd[0];
+            if (ar && br) ;
+            else if (ar && bu > 0) {
+                if (glb <= gla) tgap += bu;
+                else if (gep) lunp += gep_longup_res(agep, as, apos, glb + 1, true) * bu;
+            } else if (au > 0 && br) {
+                if (gla <= glb) tgap += au;
+                else if (gep) lunp += gep_longup_res(bgep, bs, bpos, gla + 1, true) * au;
+            }
+        } else if (d3 > 0) {
+            if (as[0] > 1) {
+                const double bu = thk_at(b, bpos)[2];
+                if (bu > 0) {
+                    if (glb <= gla) tgap += bu;
+                    else if (gep) lunp += gep_longup_res(agep, as, apos, glb + 1, true) * bu;
+                }
+            }
+        } else {
+            if (bs[0] > 1) {
+                const double au = thk_at(a, apos)[2];
+                if (au > 0) {
+                    if (gla <= glb) tgap += au;
+                    else if (gep) lunp += gep_longup_res(bgep, bs, bpos, gla + 1, true) * au;
+                }
+            }
+        }
+        return;
+    }
+    const bool w = N.unit == 2;                                // SPunit_w22 weighs the inner sums, SPunit_nv adds them raw
+    const double *wta = a.weight, *wtb = b.weight;
+    if (d3 == 0) {
+        for (int i = 0; i < an; ++i) {
+            const bool ar = as[i] > 1;
+            const double au = agd[i];
+            double g = 0, l = 0;
+            for (int j = 0; j < bn; ++j) {
+                const bool br = bs[j] > 1;
+                const double bu = bgd[j];
+                if (ar && br) ;
+                else if (ar && bu > 0) {
+                    if (N.glb[j] <= N.gla[i]) { if (w) g += wtb[j] * bu; else tgap += bu; }
+                    else if (gep && gep_long1(agep, i, apos, N.glb[j] + 1)) { if (w) l += wtb[j] * bu; else lunp += bu; }
+                } else if (au > 0 && br) {
+                    if (N.gla[i] <= N.glb[j]) { if (w) g += wtb[j] * au; else tgap += au; }
+                    else if (gep && gep_long1(bgep, j, bpos, N.gla[i] + 1)) { if (w) l += wtb[j] * au; else lunp += au; }
+                }
+            }
+            if (w) { tgap += g * wta[i]; lunp += l * wta[i]; }
+            if (ar && gep) gep_shift1(agep, i, apos);
+        }
+        if (gep) { gep_wave_sync(); gep_shift(bgep, bs, bpos); }
+    } else if (d3 > 0) {
+        for (int i = 0; i < an; ++i)
+            if (as[i] > 1) {
+                double g = 0, l = 0;
+                for (int j = 0; j < bn; ++j) {
+                    const double bu = bpg[j];
+                    if (bu > 0) {
+                        if (N.glb[j] <= N.gla[i]) { if (w) g += wtb[j] * bu; else tgap += bu; }
+                        else if (gep && gep_long1(agep, i, apos, N.glb[j] + 1)) { if (w) l += wtb[j] * bu; else lunp += bu; }
+                    }
+                }
+                if (w) { tgap += g * wta[i]; lunp += l * wta[i]; }
+                if (gep) gep_shift1(agep, i, apos);
+            }
+    } else {
+        for (int j = 0; j < bn; ++j)
+            if (bs[j] > 1) {
+                double g = 0, l = 0;
+                for (int i = 0; i < an; ++i) {
+                    const double au = apg[i];
+                    if (au > 0) {
+                        if (N.gla[i] <= N.glb[j]) { if (w) g += wta[i] * au; else tgap += au; }
+                        else if (gep && gep_long1(bgep, j, bpos, N.gla[i] + 1)) { if (w) l += wta[i] * au; else lunp += au; }
+                    }
+                }
+                if (w) { tgap += g * wtb[j]; lunp += l * wtb[j]; }
+                if (gep) gep_shift1(bgep, j, bpos);
+            }
+    }
+    if (gep) gep_wave_sync();
+}
+__device__ void sp_calscr_ntv(const DevProb &P, const NtvState &N, int mi, int ni, int &apos, int &bpos, double &scr, double &tgap,
+                              const bool gep, const GepDev &agep, const GepDev &bgep, double &lunp)
+{
+    const int an = P.a.many, bn = P.b.many;
+    if (mi == ni) {
+        while (mi--) {
+            ++apos; ++bpos;
+            sp_calcstat_ntv(P, N, 0, apos, bpos, scr, tgap, gep, agep, bgep, lunp);
+            if (N.unit == 1) { N.gla[0] = 0; N.glb[0] = 0; }
+            else { sp_incrgap(N.gla, res_at(P.a, apos), an); sp_incrgap(N.glb, res_at(P.b, bpos), bn); }
+        }
+    } else if (mi) {
+        while (mi--) {
+            ++apos;
+            sp_calcstat_ntv(P, N, 1, apos, bpos, scr, tgap, gep, agep, bgep, lunp);
+            if (N.unit == 1) { N.gla[0] = 0; ++N.glb[0]; }
+            else { sp_incrgap(N.gla, res_at(P.a, apos), an); sp_incrgap(N.glb, (const uint8_t *) 0, bn); }
+        }
+    } else if (ni) {
+        while (ni--) {
+            ++bpos;
+            sp_calcstat_ntv(P, N, -1, apos, bpos, scr, tgap, gep, agep, bgep, lunp);
+            if (N.unit == 1) { ++N.gla[0]; N.glb[0] = 0; }
+            else { sp_incrgap(N.gla, (const uint8_t *) 0, an); sp_incrgap(N.glb, res_at(P.b, bpos), bn); }
+        }
+    }
+}
 template <int KIND>
 __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *skl, int nskl, double *out, int *gepws)
 {
     // Gep1st of both sides (fspscore.h:146-147: alprm.ls > 2); the workspace arrives zeroed
     const bool gep = KIND >= 1 && P.noll == 3 && gepws != 0;
     GepDev agep, bgep;
+    NtvState N;
+    N.unit = 0; N.gla = N.glb = 0;
+    if (KIND == 3) {                                           // workspace: gla[an], glb[bn], then the rings (Noll 3)
+        N.gla = gepws; N.glb = gepws + P.a.many;
+        gepws += P.a.many + P.b.many + 2;
+        N.unit = (P.a.weight && P.b.weight) ? (P.a.many == 1 ? 1 : 2) : 0;      // PreSpScore::calcSpScore, fspscore.cc:598-610
+        if (N.unit != 1) { sp_pregap(P.a, N.gla); sp_pregap(P.b, N.glb); }
+    }
     agep.many = P.a.many; bgep.many = P.b.many; agep.k1 = bgep.k1 = P.codonk1;
     agep.w = P.a.weight; bgep.w = P.b.weight;
     agep.q = gepws; agep.qp = gepws + (size_t) P.a.many * P.codonk1;
@@ -851,18 +998,23 @@ __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *
     double lunp = 0;
     DList dla, dlb;
     dla.p = P.dla[XH]; dla.s = P.width; dlb.p = P.dlb[XH]; dlb.s = P.width;
-    if (KIND >= 1) cleardelta(dla);
+    if (KIND == 1 || KIND == 2) cleardelta(dla);
     if (KIND == 2) cleardelta(dlb);
     int m = skl[0].x, n = skl[0].y, glb = 0;
     int apos = m - 1, bpos = n - 1;
     double scr = 0, tgap = 0;
     for (int k = 1; k < nskl; ++k) {
         const int mi = skl[k].x - m, ni = skl[k].y - n, i = mi - ni;
-        if (!i || !mi || !ni) sp_calscr<KIND>(P, sp, mi, ni, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp);
-        else if (i > 0) { sp_calscr<KIND>(P, sp, ni, ni, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp); sp_calscr<KIND>(P, sp, i, 0, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp); }
-        else { sp_calscr<KIND>(P, sp, mi, mi, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp); sp_calscr<KIND>(P, sp, 0, -i, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp); }
+        auto run = [&](int mi_, int ni_) {
+            if (KIND == 3) sp_calscr_ntv(P, N, mi_, ni_, apos, bpos, scr, tgap, gep, agep, bgep, lunp);
+            else sp_calscr<(KIND == 3 ? 0 : KIND)>(P, sp, mi_, ni_, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp);
+        };
+        if (!i || !mi || !ni) run(mi, ni);
+        else if (i > 0) { run(ni, ni); run(i, 0); }
+        else { run(mi, mi); run(0, -i); }
         m = skl[k].x; n = skl[k].y;
     }
+    gep_wave_sync();
     scr += tgap * (KIND == 1 ? P.weighted_gop : P.basic_gop) + sp.diff_u * lunp;    // wgop(tgap, lunp), maln.h:321-325
     out[0] = scr / sp.vab;                                                       // rescale
     out[1] = tgap / sp.vab;
@@ -876,13 +1028,15 @@ g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const
     const DevProb &P = probs[ip];
     out[2 * ip] = 0; out[2 * ip + 1] = 0;
     if (P.kind < 0) { status[ip] = -1; return; }
-    if (P.kind == 3) { status[ip] = -2; return; }                               // naive units: not on this path
     int *ws = (gepws && gep_off[ip] >= 0) ? gepws + gep_off[ip] : (int *) 0;
-    if (P.noll == 3 && P.kind >= 1 && !ws) { status[ip] = -2; return; }
+    if (((P.noll == 3 && P.kind >= 1) || P.kind == 3) && !ws) { status[ip] = -2; return; }
+    if (P.kind == 3 && P.a.weight && P.b.weight && P.a.many > 1 && P.b.many == 1) { status[ip] = -2; return; }   // SPunit_w21: not restated
+    if (P.kind == 3 && (!P.a.gapdens || !P.b.gapdens)) { status[ip] = -1; return; }
     if (nskl[ip] < 2) { status[ip] = -1; return; }
     const int2 *s = skl + skl_off[ip];
     if (P.kind == 0) sp_calcskl<0>(P, sp[ip], s, nskl[ip], out + 2 * ip, ws);
     else if (P.kind == 1) sp_calcskl<1>(P, sp[ip], s, nskl[ip], out + 2 * ip, ws);
-    else sp_calcskl<2>(P, sp[ip], s, nskl[ip], out + 2 * ip, ws);
+    else if (P.kind == 2) sp_calcskl<2>(P, sp[ip], s, nskl[ip], out + 2 * ip, ws);
+    else sp_calcskl<3>(P, sp[ip], s, nskl[ip], out + 2 * ip, ws);
     status[ip] = 0;
 }
