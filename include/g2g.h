@@ -201,9 +201,9 @@ const g2g_problem *g2g_pwdm_problem(const g2g_pwdm *p);
  * (src/fspscore.h:202-254, calscr src/fspscore.cc:346-541) followed by PwdM::rescale (src/maln2.cc:245-252): the score is
  * re-evaluated ALONG the path (column scores, unpaired-column penalties and the gap-open counts of the gap-profile
  * algebra) and returned per unit pair weight; Prrn::onecycle takes fstat.val of the old and the new alignment as the
- * acceptance delta.  On this path: NGP / HLF / RHF / GPF modes and the naive units SPunit_nv / _w11 / _w22 of the NTV
- * modes, with Noll 2 and 3 (-yl3: the long-gap bookkeeping `Gep1st`, src/mseq.cc:658-758, included).  SPunit_w21
- * (weights, b a single sequence, a several) reports G2G_ERR_MODE; mch/mmc/unp of FSTAT (PwdM::stt2) are not computed. */
+ * acceptance delta.  On this path: NGP / HLF / RHF / GPF modes and the naive units SPunit_nv / _w11 / _w21 / _w22 of the
+ * NTV modes, with Noll 2 and 3 (-yl3: the long-gap bookkeeping `Gep1st`, src/mseq.cc:658-758, included).  mch/mmc/unp of
+ * FSTAT (PwdM::stt2) are not computed.                                                                             */
 typedef struct {
     double vab;          /* PwdM::Vab = scale * wa * wb (src/maln2.cc:234)                         */
     double basic_gep;    /* PwdB::BasicGEP = -u * axbscale (src/aln2.cc:103)                       */

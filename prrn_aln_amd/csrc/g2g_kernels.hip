@@ -841,7 +841,7 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
 
 // ---- naive units of calcSpScore (NTV modes): SPunit_nv / _w11 / _w22, reference src/fspscore.h:34-78, calcstat
 // src/fspscore.cc:60-340, calscr :365-470.  Groups are tiny (2 nj + ni < 8): every lane replays everything.
-struct NtvState { int unit; int *gla, *glb; };            // unit: 0 nv, 1 w11, 2 w22; per member running gap lengths
+struct NtvState { int unit; int *gla, *glb; };            // unit: 0 nv, 1 w11, 2 w22, 3 w21; per member running gap lengths
 __device__ __forceinline__ bool gep_long1(const GepDev &g, int i, int n, int tgl) { return tgl > n - gep_oldest(g, i); }
 __device__ void sp_incrgap(int *gg, const uint8_t *ss, int n)
 {   // incrgap, mgaps.cc:431-440
@@ -894,6 +894,48 @@ __device__ void sp_calcstat_ntv(const DevProb &P, const NtvState &N, int d3, int
                 }
             }
         }
+        return;
+    }
+    if (N.unit == 3) {                                         // SPunit_w21 (fspscore.cc:192-250): a several with weights, b a single
+        const double *wa = a.weight;
+        const bool br = bs[0] > 1;
+        const int glb = N.glb[0];
+        const double bu = thk_at(b, bpos)[2];
+        if (d3 == 0) {
+            for (int i = 0; i < an; ++i) {
+                const bool ar = as[i] > 1;
+                const double au = agd[i];
+                if (ar && br) ;
+                else if (ar && bu > 0) {
+                    if (glb <= N.gla[i]) tgap += wa[i] * bu;
+                    else if (gep && gep_long1(agep, i, apos, glb + 1)) lunp += wa[i] * bu;
+                } else if (au > 0 && br) {
+                    if (N.gla[i] <= glb) tgap += wa[i] * au;
+                    else if (gep && gep_long1(bgep, 0, bpos, N.gla[i] + 1)) lunp += wa[i] * au;
+                }
+                if (ar && gep) gep_shift1(agep, i, apos);
+            }
+            if (br && gep) gep_shift1(bgep, 0, bpos);
+        } else if (d3 > 0) {
+            for (int i = 0; i < an; ++i)
+                if (as[i] > 1) {
+                    if (bu > 0) {
+                        if (glb <= N.gla[i]) tgap += wa[i] * bu;
+                        else if (gep && gep_long1(agep, i, apos, glb + 1)) lunp += wa[i] * bu;
+                    }
+                    if (gep) gep_shift1(agep, i, apos);
+                }
+        } else if (br) {
+            for (int i = 0; i < an; ++i) {
+                const double au = apg[i];
+                if (au > 0) {
+                    if (N.gla[i] <= glb) tgap += wa[i] * au;
+                    else if (gep && gep_long1(bgep, 0, bpos, N.gla[i] + 1)) lunp += wa[i] * au;
+                }
+            }
+            if (gep) gep_shift1(bgep, 0, bpos);
+        }
+        if (gep) gep_wave_sync();
         return;
     }
     const bool w = N.unit == 2;                                // SPunit_w22 weighs the inner sums, SPunit_nv adds them raw
@@ -959,6 +1001,7 @@ __device__ void sp_calscr_ntv(const DevProb &P, const NtvState &N, int mi, int n
             ++apos; ++bpos;
             sp_calcstat_ntv(P, N, 0, apos, bpos, scr, tgap, gep, agep, bgep, lunp);
             if (N.unit == 1) { N.gla[0] = 0; N.glb[0] = 0; }
+            else if (N.unit == 3) { sp_incrgap(N.gla, res_at(P.a, apos), an); N.glb[0] = 0; }
             else { sp_incrgap(N.gla, res_at(P.a, apos), an); sp_incrgap(N.glb, res_at(P.b, bpos), bn); }
         }
     } else if (mi) {
@@ -966,6 +1009,7 @@ __device__ void sp_calscr_ntv(const DevProb &P, const NtvState &N, int mi, int n
             ++apos;
             sp_calcstat_ntv(P, N, 1, apos, bpos, scr, tgap, gep, agep, bgep, lunp);
             if (N.unit == 1) { N.gla[0] = 0; ++N.glb[0]; }
+            else if (N.unit == 3) { sp_incrgap(N.gla, res_at(P.a, apos), an); ++N.glb[0]; }
             else { sp_incrgap(N.gla, res_at(P.a, apos), an); sp_incrgap(N.glb, (const uint8_t *) 0, bn); }
         }
     } else if (ni) {
@@ -973,6 +1017,7 @@ __device__ void sp_calscr_ntv(const DevProb &P, const NtvState &N, int mi, int n
             ++bpos;
             sp_calcstat_ntv(P, N, -1, apos, bpos, scr, tgap, gep, agep, bgep, lunp);
             if (N.unit == 1) { ++N.gla[0]; N.glb[0] = 0; }
+            else if (N.unit == 3) { sp_incrgap(N.gla, (const uint8_t *) 0, an); N.glb[0] = 0; }
             else { sp_incrgap(N.gla, (const uint8_t *) 0, an); sp_incrgap(N.glb, res_at(P.b, bpos), bn); }
         }
     }
@@ -988,8 +1033,9 @@ __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *
     if (KIND == 3) {                                           // workspace: gla[an], glb[bn], then the rings (Noll 3)
         N.gla = gepws; N.glb = gepws + P.a.many;
         gepws += P.a.many + P.b.many + 2;
-        N.unit = (P.a.weight && P.b.weight) ? (P.a.many == 1 ? 1 : 2) : 0;      // PreSpScore::calcSpScore, fspscore.cc:598-610
-        if (N.unit != 1) { sp_pregap(P.a, N.gla); sp_pregap(P.b, N.glb); }
+        N.unit = (P.a.weight && P.b.weight) ? (P.a.many == 1 ? 1 : P.b.many == 1 ? 3 : 2) : 0;   // PreSpScore::calcSpScore, fspscore.cc:598-610
+        if (N.unit == 3) sp_pregap(P.a, N.gla);                // (glb = 0, fspscore.h:58-66)
+        else if (N.unit != 1) { sp_pregap(P.a, N.gla); sp_pregap(P.b, N.glb); }
     }
     agep.many = P.a.many; bgep.many = P.b.many; agep.k1 = bgep.k1 = P.codonk1;
     agep.w = P.a.weight; bgep.w = P.b.weight;
@@ -1030,7 +1076,6 @@ g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const
     if (P.kind < 0) { status[ip] = -1; return; }
     int *ws = (gepws && gep_off[ip] >= 0) ? gepws + gep_off[ip] : (int *) 0;
     if (((P.noll == 3 && P.kind >= 1) || P.kind == 3) && !ws) { status[ip] = -2; return; }
-    if (P.kind == 3 && P.a.weight && P.b.weight && P.a.many > 1 && P.b.many == 1) { status[ip] = -2; return; }   // SPunit_w21: not restated
     if (P.kind == 3 && (!P.a.gapdens || !P.b.gapdens)) { status[ip] = -1; return; }
     if (nskl[ip] < 2) { status[ip] = -1; return; }
     const int2 *s = skl + skl_off[ip];

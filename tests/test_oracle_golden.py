@@ -68,5 +68,5 @@ def test_oracle_spscore(L, path):
 
 def test_oracle_spscore_scope(L):
     """every reference golden pins calcSpScore: plain, half- and full-profile units with Noll 2 and 3, and the naive units
-    SPunit_nv / _w11 / _w22 (SPunit_w21 -- weights, b a single, a several -- has no golden and reports G2G_ERR_MODE)"""
-    assert len(SP_GOLD) == len(GOLD) >= 53
+    SPunit_nv / _w11 / _w21 / _w22"""
+    assert len(SP_GOLD) == len(GOLD) >= 59

@@ -151,8 +151,29 @@ def job_protein_tgapf():
         split_case(R, fam, b, w, "prot12x80_tgapf05_k%d" % k)
 
 
+def _w21_cases(R, tag, **kw):
+    """weighted tiny families whose division is NTV with a several and b a single sequence: the SPunit_w21 unit of
+    PreSpScore::calcSpScore (reference src/fspscore.cc:598-610, calcstat :192-250)"""
+    from prrn_aln_amd.synth import make_family, tree_branches, tree_weights
+    for seed, n in ((1, 3), (1, 4), (3, 3)):
+        fam = make_family(n, 70, seed, indel=0.04, **kw)
+        w = tree_weights(fam.tree, n)
+        split_case(R, fam, tree_branches(fam.tree)[0], w, "%s%dx70_w21_s%d" % (tag, n, seed))
+
+
+def job_w21_protein():
+    import refdump
+    _w21_cases(refdump.RefLib(molc=refdump.PROTEIN), "prot")
+
+
+def job_w21_dna_ls3():
+    import refdump
+    from prrn_aln_amd.synth import DNA
+    _w21_cases(refdump.RefLib(molc=refdump.DNA, ls=3), "dna_ls3_", alphabet=DNA)
+
+
 JOBS = {"protein": job_protein, "dna_ls3": job_dna_ls3, "protein_ls3": job_protein_ls3,
-        "protein_tgapf": job_protein_tgapf}
+        "protein_tgapf": job_protein_tgapf, "w21_protein": job_w21_protein, "w21_dna_ls3": job_w21_dna_ls3}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
