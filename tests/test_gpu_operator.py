@@ -108,6 +108,29 @@ def test_calcspscore_noll3_sweep_vs_oracle(ctx):
         assert n > 10
 
 
+def test_calcspscore_tiny_families_vs_oracle(ctx):
+    """the naive units (NTV modes: SPunit_nv / _w11 / _w21 / _w22) on families of 3-6 sequences, weighted or not, Noll 2 and 3"""
+    L = oraclelib.load()
+    seen = set()
+    for n in (3, 4, 5, 6):
+        for weighted in (True, False):
+            for ls in (1, 3):
+                fam = make_family(n, 70, 40 + n, indel=0.05, max_indel=12)
+                if min(len(r.replace("-", "")) for r in fam.msa) == 0:
+                    continue
+                sw = sweep.Sweep(fam, op.AlnParam(ls=ls), weighted=weighted)
+                res = op.align2_batch(ctx, sw.pwds)
+                fs = op.calcSpScore_batch(ctx, sw.pwds, [skl for (_, skl, _) in res])
+                for pw, (scr, skl, st), (val, gap, fst) in zip(sw.pwds, res, fs):
+                    class H:
+                        c = pw.problem
+                    rc, oval, ogap = oraclelib.spscore(L, H, op.spparams(pw), skl)
+                    assert st == 0 and fst == 0 and rc == 0, (n, weighted, ls, pw.alnmode, st, fst, rc)
+                    assert val == oval and gap == ogap, (n, weighted, ls, pw.alnmode, val, oval)
+                    seen.add((pw.alnmode, pw.problem.noll, weighted))
+    assert {m for (m, _, _) in seen} >= {10}, seen
+
+
 def test_sweep_batch_vs_oracle_and_properties(ctx):
     """A whole (small) sweep as one batch: every DP bit-equal to the oracle; skeleton properties hold."""
     fam = make_family(40, 160, 21)
