@@ -247,6 +247,10 @@ bool on_gpu_path(mSeq* seqs[], PwdM* pwdm, Gsinfo* GsI)
 	// and synchronisation, about 3e4 cells of a host core); default 0 = everything on the path goes to the GPU
 	static const double	min_cells = getenv("G2G_BIND_MIN_CELLS")? atof(getenv("G2G_BIND_MIN_CELLS")): 0;
 	if (min_cells > 0 && (double) (seqs[0]->right - seqs[0]->left) * (seqs[1]->right - seqs[1]->left) < min_cells) return false;
+	// Intron-position bonus (PfqItr::match_score, fwd2c.h:367-379,446-452): live when BOTH inputs carry exon-boundary
+	// annotations (`;C join(...)` lines -> Seq::sigII) and SpbFact != 0.  libg2g.so does not evaluate it, so such pairs
+	// stay with the reference's own forwardB (e.g. `aln -s sample/pas ce13a1 ce13a2`).
+	if (SpbFact != 0 && seqs[0]->sigII && seqs[1]->sigII && seqs[0]->sigII->pfqnum && seqs[1]->sigII->pfqnum) return false;
 	switch (pwdm->alnmode) {
 	    case NGP_ALB: case HLF_ALB: case RHF_ALB: case GPF_ALB: case NTV_ALB: return true;
 	    default: return false;

@@ -147,6 +147,9 @@ struct Blob {                       // host image of the input part of the arena
     size_t size() const { return sz; }
 };
 
+// the problem index of a batch sits in a grid y / z dimension of some launches (limit 65535)
+#define G2G_MAX_BATCH 32768
+extern "C" void g2g_batch_free(g2g_batch *b);
 struct g2g_batch {
     g2g_ctx *ctx;
     int n;
@@ -365,6 +368,7 @@ static void release_arena(g2g_batch *b)
 extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *prob, g2g_batch **out)
 {
     if (!ctx || n < 0 || !out) return G2G_ERR_ARG;
+    if (n > G2G_MAX_BATCH) { g2g_set_error("%s", "g2g_batch_prepare: more than 32768 problems in one batch (use g2g_forward_batch, which cuts chunks)"); return G2G_ERR_ARG; }
     if (!ctx->ok) return G2G_ERR_NODEVICE;
     HIPCHK(hipSetDevice(ctx->device));
     const bool prep_dbg = getenv("G2G_DEBUG_PREP") != 0;
@@ -504,7 +508,10 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
                 // lists too long for registers: the LDS-list one-lane-per-cell kernel, unless its LDS footprint leaves fewer than
                 // three waves per CU and the 8-lanes-per-cell kernel fits (a 512 x 2048 nt DNA sweep with 17-32 entry lists and
                 // Noll 3: 87 KB per strip; 28.3 s with it, 22.4 s on v2)
-                const bool v2fit = v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist, b->v2_threads) + 4 * b->v2_threads <= V2_LDS_MAX;
+                // (v2 caches static gap lengths as SIGNED 16-bit with negative = terminator: a gap run can be as long as the
+                // group has columns, so sides of 32768 columns or more are not eligible -- they stay on v3 / v1, which keep 32 bits)
+                const bool v2fit = std::max(p->a.len, p->b.len) < 32768 &&
+                    v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist, b->v2_threads) + 4 * b->v2_threads <= V2_LDS_MAX;
                 const int v3tot = (!getenv("G2G_FORCE_V2") && (d.kind == 1 || getenv("G2G_V3_PF"))) ? v3_need(d, p, b->v3_cols).total : (int) V2_LDS_MAX + 1;
                 if (v3tot <= (int) V2_LDS_MAX && (v3tot <= (int) V2_LDS_MAX / 3 || !v2fit || getenv("G2G_NO_AREG"))) d.v2_ok = 2;
                 else if (v2fit) d.v2_ok = 1;
@@ -679,7 +686,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             if (e2 == hipSuccess && b->np) e2 = hipMemcpy(b->d_idxp, ip.data(), sizeof(int) * ip.size(), hipMemcpyHostToDevice);
             if (e2 == hipSuccess) e2 = hipMalloc((void **) &b->d_flags, sizeof(int) * flags.size());
             if (e2 == hipSuccess) e2 = hipMemcpy(b->d_flags, flags.data(), sizeof(int) * flags.size(), hipMemcpyHostToDevice);
-            if (e2 != hipSuccess) { g2g_set_error("tiles: %s", hipGetErrorString(e2)); (void) hipGetLastError(); release_arena(b); delete b; return G2G_ERR_NOMEM; }
+            if (e2 != hipSuccess) { g2g_set_error("tiles: %s", hipGetErrorString(e2)); (void) hipGetLastError(); g2g_batch_free(b); return G2G_ERR_NOMEM; }
         }
     }
     prep_lap("descriptors, tiles, flags");
@@ -687,7 +694,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     b->d_probs = (DevProb *) (b->d_arena + probs_off);
     e = hipMemcpyAsync(b->d_arena, bl.data(), bl.size(), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { g2g_set_error("upload: %s", hipGetErrorString(e)); release_arena(b); delete b; return G2G_ERR_DEVICE; }
+    if (e != hipSuccess) { g2g_set_error("upload: %s", hipGetErrorString(e)); g2g_batch_free(b); return G2G_ERR_DEVICE; }
     prep_lap("upload");
     *out = b;
     return G2G_OK;
@@ -1001,22 +1008,27 @@ extern "C" int g2g_forward_batch(g2g_ctx *ctx, int n, const g2g_problem *const *
     size_t budget = (size_t) 64 << 30;              // per chunk (128 GB chunks were no faster on a 3.3e10-cell DNA sweep)
     { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr) budget = std::min(budget, (size_t) (0.7 * (double) fr)); }
     if (const char *e = getenv("G2G_ARENA_LIMIT_GB")) { const double g = atof(e); if (g > 0) budget = (size_t) (g * (double) ((size_t) 1 << 30)); }
+    for (int i = 0; i < n; ++i) { res[i].trace = 0; res[i].ntrace = 0; }
     int lo = 0;
     while (lo < n) {
         size_t acc = 0;
         int hi = lo;
         while (hi < n) {
             const size_t pb = problem_bytes(prob[hi]);
-            if (hi > lo && acc + pb > budget) break;
+            if (hi > lo && (acc + pb > budget || hi - lo >= G2G_MAX_BATCH)) break;
             acc += pb; ++hi;
         }
         g2g_batch *b = 0;
         int rc = g2g_batch_prepare(ctx, hi - lo, prob + lo, &b);
-        if (rc) return rc;
-        rc = g2g_batch_run(b);
-        if (!rc) rc = g2g_batch_fetch(b, res + lo);
-        g2g_batch_free(b);
-        if (rc) return rc;
+        if (!rc) {
+            rc = g2g_batch_run(b);
+            if (!rc) rc = g2g_batch_fetch(b, res + lo);
+            g2g_batch_free(b);
+        }
+        if (rc) {             // the call fails as a whole: nothing of the finished chunks is handed out
+            for (int i = 0; i < hi; ++i) { free(res[i].trace); res[i].trace = 0; res[i].ntrace = 0; }
+            return rc;
+        }
         lo = hi;
     }
     return G2G_OK;

@@ -728,7 +728,10 @@ extern "C" int g2g_align2_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *pw, double
         for (int i : todo) pp.push_back(&pw[i]->prob);
         std::vector<g2g_result> rr(pp.size());
         int rc = g2g_forward_batch(ctx, (int) pp.size(), pp.data(), rr.data());
-        if (rc) return rc;
+        if (rc) {                                             // (a failed call hands out nothing: pass 0's skeletons go too)
+            for (int i = 0; i < n; ++i) { g2g_free(skl[i]); skl[i] = 0; nskl[i] = 0; scr[i] = 0; }
+            return rc;
+        }
         std::vector<int> again;
         for (size_t k = 0; k < todo.size(); ++k) {
             const int i = todo[k];

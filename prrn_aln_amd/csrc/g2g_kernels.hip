@@ -618,7 +618,7 @@ extern "C" __global__ void __launch_bounds__(64) g2g_traceback_kernel(const DevP
     int2 *out = P.otrace;
     const int tcap = P.tcap;
     // walker state (meaningful in lane 0, broadcast at every window change)
-    int m = ar - 1, n = br - 1, cnt = 0, state = 0, ext = 0, fin = 0;
+    int m = ar - 1, n = br - 1, cnt = 0, state = 0, ext = 0, fin = 0, bad = 0;
     int rr0 = bl - al, rr0_set = 0;
     if (lane == 0) out[cnt++] = make_int2(ar, br);       // fwd2c.h:476
     int budget = 4 * (ar - al + br - bl) + 16;
@@ -642,7 +642,7 @@ extern "C" __global__ void __launch_bounds__(64) g2g_traceback_kernel(const DevP
         __syncthreads();
         if (lane == 0) {
             for (;;) {
-                if (--budget < 0) { fin = 1; break; }
+                if (--budget < 0) { fin = 1; bad = 1; break; }                 // longer than any path: corrupt trace
                 if (state == 0 && (m < al || n < bl)) { fin = 1; break; }      // reached an initB boundary corner
                 const int L = dtop - (m + n);
                 if (L >= TB_W) break;
@@ -656,7 +656,7 @@ extern "C" __global__ void __launch_bounds__(64) g2g_traceback_kernel(const DevP
                     if (dc == 1 || dc == 2) { --m; --n; }
                     else if (dc == 3 || dc == 4) { ext = (t & T_SEL2) ? T_G2EXT : T_GEXT; state = 1; }   // H copied G or G2
                     else if (dc == 5 || dc == 6) { ext = (t & T_SEL2) ? T_F2EXT : T_FEXT; state = 2; }
-                    else { fin = 1; break; }                                   // never written: corrupt
+                    else { fin = 1; bad = 1; break; }                          // never written: corrupt
                 }
                 if (state == 1) {                                              // walk the vertical run
                     --m;
@@ -672,7 +672,7 @@ extern "C" __global__ void __launch_bounds__(64) g2g_traceback_kernel(const DevP
     }
     if (lane == 0) {
         out[cnt++] = make_int2(al, bl);                   // origin record, fwd2c.h:144
-        *P.ntrace = cnt;
+        *P.ntrace = bad ? -1 : cnt;                       // -1: the forward pass left a hole (g2g_batch_fetch -> G2G_ERR_DEVICE)
         P.ntrace[1] = rr0;
     }
 }

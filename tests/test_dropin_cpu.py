@@ -53,3 +53,11 @@ def test_prrn5_wrapped_equals_reference_on_cpu(tmp_path, mode):
     m = re.search(r"g2g_bind: (\d+) align2 calls, (\d+) on the GPU, (\d+) by the reference", err)
     assert m and int(m.group(1)) > 0 and int(m.group(2)) == 0 and int(m.group(3)) == int(m.group(1)), err[-500:]
     assert out == ref_out
+
+
+def test_aln_ce13a_pair_score():
+    """BASELINE configs[0] (plumbing): `aln -s sample/pas ce13a1 ce13a2` through the wrapped program = the reference's output."""
+    pas = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pas")
+    ref_out, _ = _run("aln", ["-s", pas, "ce13a1", "ce13a2"], pas)
+    out, err = _run("aln_g2g", ["-s", pas, "ce13a1", "ce13a2"], pas, G2G_BIND="off")
+    assert "Score = 2325.0" in out and out == ref_out

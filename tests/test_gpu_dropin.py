@@ -108,3 +108,17 @@ def test_prrn5_threaded_calls_are_batched(tmp_path):
     assert gpu >= 0.9 * calls and bad == 0
     assert largest > 1 and batches < gpu, (batches, largest, gpu)
     assert out == ref_out
+
+
+def test_aln_intron_annotated_pair_stays_with_the_reference():
+    """BASELINE configs[0]: `aln -s sample/pas ce13a1 ce13a2` (tests/golden/pas/ holds the two data files of the
+    reference's sample/).  Both inputs carry `;C join(...)` exon annotations, so the intron-position bonus
+    (PfqItr::match_score, reference src/fwd2c.h:446-452) is live; libg2g.so does not evaluate it and the binding must
+    route the pair to the reference's own forwardB: Score = 2325.0, byte-identical output, DP counted by the reference."""
+    pas = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pas")
+    ref_out, _ = _run("aln", ["-s", pas, "ce13a1", "ce13a2"], pas)
+    out, err = _run("aln_g2g", ["-s", pas, "ce13a1", "ce13a2"], pas)
+    calls, gpu, cpu, bad = _stats(err)
+    assert calls == 1 and gpu == 0 and cpu == 1 and bad == 0, err[-500:]
+    assert "Score = 2325.0" in out
+    assert out == ref_out

@@ -1,0 +1,88 @@
+"""Oracle parity at BASELINE sizes (not self-comparison): divisions of the 256 x 1024 aa bench family (configs[2]) and
+DPs of configs[4]'s per-DP shape (DNA, -yl3 = Noll 3, 4096 nt, static gap-profile lists longer than 16 entries).
+
+The oracle (oracle/g2g_oracle.c, pinned on the reference's goldens) fills a 6e6-cell DP in under a second, so full-size
+parity is affordable for a handful of divisions: score bit for bit, traceback record by record, standardised skeleton."""
+import numpy as np
+import pytest
+
+import oraclelib
+from prrn_aln_amd import engine, operator as op, sweep
+from prrn_aln_amd.synth import DNA, make_family, tree_branches, tree_weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = engine.Context()
+    yield c
+    c.close()
+
+
+def _division(codes, weights, side, alp):
+    a, b, ia, ib = sweep.division_groups(codes, side)
+    ga, gb = op.mSeq(a, alp, weights[ia]), op.mSeq(b, alp, weights[ib])
+    return (ga, gb), op.PwdM([ga, gb], alp)
+
+
+def _maxlist(q):
+    mx = 0
+    for s in (q.a, q.b):
+        if s.has_gfq:
+            for v in range(3):
+                off = np.ctypeslib.as_array(s.gfq.off[v], shape=(s.len + 2,))
+                mx = max(mx, int(np.diff(off).max()))
+    return mx
+
+
+def _check_vs_oracle(ctx, pwds):
+    L = oraclelib.load()
+    res = op.align2_batch(ctx, pwds)
+    hs = []
+    for pw in pwds:
+        class H:
+            c = pw.problem
+        hs.append(H)
+    raw = ctx.forward_batch(hs)
+    for pw, H, (scr, skl, st), (rscr, rcells, rtr, rst) in zip(pwds, hs, res, raw):
+        assert st == 0 and rst == 0
+        oscr, ocells, otr = oraclelib.forward(L, H)
+        assert rcells == ocells
+        assert scr == oscr and rscr == oscr, (pw.alnmode, scr, oscr)
+        assert np.array_equal(rtr, otr), pw.alnmode
+        assert np.array_equal(skl, oraclelib.stdskl(L, otr))
+
+
+def test_bench_family_divisions_vs_oracle(ctx):
+    """256 proteins x 1024 aa (the bench workload): smallest, median and largest division of BOTH engines
+    (HLF/RHF = DPunit_hf, GPF = DPunit_pf), 3.5e6 .. 1.2e7 cells each, in one batch."""
+    fam = make_family(256, 1024, 1)
+    alp = op.AlnParam()
+    sw = sweep.Sweep(fam, alp, weighted=True)
+    hf = [k for k in sw.order if sw.pwds[k].alnmode in (7, 8)]
+    pf = [k for k in sw.order if sw.pwds[k].alnmode == 9]
+    assert len(hf) > 3 and len(pf) > 3
+    pick = [hf[0], hf[len(hf) // 2], hf[-1], pf[0], pf[1], pf[len(pf) // 2], pf[-1]]
+    assert min(sw.cells[k] for k in pick) > 1e6
+    _check_vs_oracle(ctx, [sw.pwds[k] for k in pick])
+
+
+def test_dna_ls3_4096nt_divisions_vs_oracle(ctx):
+    """configs[4]'s per-DP shape: DNA family of 4096-nt sequences, double-affine penalty (-yl3: Noll 3 kernels, codonk1 = 21),
+    static gap-profile lists of more than 16 entries (beyond what the register-list kernel holds), 0.8-1.8e8 cells per DP."""
+    n = 224
+    fam = make_family(n, 4096, 2, alphabet=DNA, indel=0.012, max_indel=8)
+    alp = op.AlnParam(ls=3, molc=op.DNA, max_code=17)
+    codes = op.encode(fam.msa, alp.molc)
+    w = np.asarray(tree_weights(fam.tree, n))
+    br = sorted(tree_branches(fam.tree), key=lambda s: -min(len(s), n - len(s)))
+    sides = [[s for s in br if min(len(s), n - len(s)) == 6][0], br[-1]]
+    keep, pwds = [], []
+    for s in sides:
+        g, pw = _division(codes, w, s, alp)
+        keep.append(g); pwds.append(pw)
+    assert {pw.alnmode for pw in pwds} == {8, 9} or {pw.alnmode for pw in pwds} == {7, 9}
+    assert all(pw.problem.noll == 3 and pw.problem.codonk1 == 21 for pw in pwds)
+    assert max(_maxlist(pw.problem) for pw in pwds) > 16
+    _check_vs_oracle(ctx, pwds)

@@ -172,7 +172,27 @@ def job_w21_dna_ls3():
     _w21_cases(refdump.RefLib(molc=refdump.DNA, ls=3), "dna_ls3_", alphabet=DNA)
 
 
-JOBS = {"protein": job_protein, "dna_ls3": job_dna_ls3, "protein_ls3": job_protein_ls3,
+def job_sim23():
+    """gap-free groups with the SMALL group first: a = 2-3 raw members, b = a profile -> PwdM::sim23i / sim23w
+    (reference src/maln2.cc:347-399 selection table, scorers :570-600,1273-1285); no swap in the NGP modes"""
+    import refdump
+    from prrn_aln_amd.synth import make_family, tree_branches, tree_weights
+    R = refdump.RefLib(molc=refdump.PROTEIN)
+    fam = make_family(30, 60, 29, sub=0.2, indel=0.0)
+    w = tree_weights(fam.tree, 30)
+    n = 30
+    done = set()
+    for b in tree_branches(fam.tree):
+        small = list(b) if len(b) <= n - len(b) else [i for i in range(n) if i not in set(b)]
+        k = len(small)
+        if k not in (2, 3, 4) or k in done:
+            continue
+        done.add(k)
+        split_case(R, fam, small, w, "syn30x60_nogap_small%d_first_w" % k)
+        split_case(R, fam, small, None, "syn30x60_nogap_small%d_first_i" % k)
+
+
+JOBS = {"sim23": job_sim23, "protein": job_protein, "dna_ls3": job_dna_ls3, "protein_ls3": job_protein_ls3,
         "protein_tgapf": job_protein_tgapf, "w21_protein": job_w21_protein, "w21_dna_ls3": job_w21_dna_ls3}
 
 if __name__ == "__main__":
