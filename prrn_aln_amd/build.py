@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "g2g_engine.hip")]
 EXTRA_CPP = [os.path.join(HERE, "csrc", f) for f in ("g2g_host.cpp",)]
 DEPS = [os.path.join(HERE, "csrc", f) for f in
-        ("g2g_engine.hip", "g2g_kernels.hip", "g2g_kernels_v2.hip", "g2g_kernels_v3.hip", "g2g_kernels_v4.hip", "g2g_device.h", "g2g_internal.h", "g2g_host.cpp")] + \
+        ("g2g_engine.hip", "g2g_kernels.hip", "g2g_kernels_v2.hip", "g2g_kernels_v3.hip", "g2g_kernels_v6.hip", "g2g_device.h", "g2g_internal.h", "g2g_host.cpp")] + \
        [os.path.join(os.path.dirname(HERE), "include", "g2g.h")]
 LIB = os.path.join(HERE, "libg2g.so")
 
@@ -30,7 +30,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = SRC + [f for f in EXTRA_CPP if os.path.exists(f)]
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + srcs
+    cmd = [hipcc] + FLAGS + os.environ.get("G2G_EXTRA_FLAGS", "").split() + ["-o", LIB] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -18,7 +18,7 @@
 #include "g2g_kernels.hip"          // one translation unit: kernels + launcher (no -fgpu-rdc needed)
 #include "g2g_kernels_v2.hip"
 #include "g2g_kernels_v3.hip"
-#include "g2g_kernels_v4.hip"
+#include "g2g_kernels_v6.hip"
 
 static thread_local std::string g_err;
 void g2g_set_error(const char *fmt, const char *a)
@@ -37,9 +37,9 @@ struct g2g_ctx {
     int device;
     int ok;
     hipStream_t stream;
-    hipStream_t vstream[4];         // one per v2 kernel variant: their tile wavefronts are independent
+    hipStream_t vstream[6];         // one per concurrently running kernel variant: their tile wavefronts are independent
     hipEvent_t ev[4];
-    hipEvent_t vev[5];
+    hipEvent_t vev[7];              // 0-3, 5-6: join events of the variant streams; 4: fork event
     char *stage; size_t stage_cap;  // pinned host staging buffer of g2g_batch_prepare, kept between calls
     char *spare; size_t spare_bytes; // one device arena kept from the last freed batch (hipMalloc/hipFree of tens of GB per
                                     // call cost up to a second); contents are as undefined as a fresh allocation's
@@ -62,8 +62,8 @@ extern "C" g2g_ctx *g2g_create(int device)
     c->spare = 0; c->spare_bytes = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; g2g_set_error("%s", "stream"); return NULL; }
     for (int i = 0; i < 4; ++i) hipEventCreate(&c->ev[i]);
-    for (int i = 0; i < 4; ++i) hipStreamCreateWithFlags(&c->vstream[i], hipStreamNonBlocking);
-    for (int i = 0; i < 5; ++i) hipEventCreateWithFlags(&c->vev[i], hipEventDisableTiming);
+    for (int i = 0; i < 6; ++i) hipStreamCreateWithFlags(&c->vstream[i], hipStreamNonBlocking);
+    for (int i = 0; i < 7; ++i) hipEventCreateWithFlags(&c->vev[i], hipEventDisableTiming);
     // the code object must contain an image for this GPU (the library is built for gfx950 only)
     hipFuncAttributes fa;
     hipError_t e = hipFuncGetAttributes(&fa, (const void *) g2g_forward_kernel);
@@ -79,8 +79,8 @@ extern "C" void g2g_destroy(g2g_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
-    for (int i = 0; i < 5; ++i) hipEventDestroy(c->vev[i]);
-    for (int i = 0; i < 4; ++i) hipStreamDestroy(c->vstream[i]);
+    for (int i = 0; i < 7; ++i) hipEventDestroy(c->vev[i]);
+    for (int i = 0; i < 6; ++i) hipStreamDestroy(c->vstream[i]);
     hipStreamDestroy(c->stream);
     if (c->stage) hipHostFree(c->stage);
     if (c->spare) hipFree(c->spare);
@@ -175,8 +175,7 @@ struct g2g_batch {
     V2Tile *d_tiles;                // tiles: per variant (v2: hf2, hf3, pf2, pf3; v3: the same four) a queue ordered by wavefront i + j
     int var_off[17];                // variant v owns tiles [var_off[v], var_off[v+1])
     V3Lds v3lds[8];                 // LDS plan of the v3 variants
-    V4Lds v4lds[4];                 // LDS plan of the v4 (_pf, 8 lanes per cell) variants
-    int v4_cols;
+    V6Lds v6lds[4];                 // LDS plans of the v6 (_pf, one lane per cell, rank-form merges) launches: Noll 2, 3 x {small, large} footprint
     int v2_cols;
     int v2_threads;                 // workgroup size of the v2 kernels: 256 (32-row strips) or 128 (16-row strips)
     int v2_sweep;                   // v2 (_pf): the same
@@ -219,26 +218,45 @@ static V3Lds v3_layout(int rows_bytes, int ca4max, int apool, int bpool, int C)
     L.total = o;
     return L;
 }
-static V4Lds v4_layout(int rows_bytes, int ca4max, int C, int RC = V4_RC)
+// LDS plan of the v6 kernel (g2g_kernels_v6.hip): ring rows of dynamic lists, black lists, staging scalars, the ring of
+// b's static lists (3 views x rs entries x 16 B), queue scratch, sinks
+static V6Lds v6_layout(int rows_bytes, int ca4max, int rs)
 {
-    V4Lds L;
+    V6Lds L;
     int o = 0;
     auto take = [&](int bytes) { int r = o; o = (o + bytes + 15) & ~15; return r; };
     L.rows = take(rows_bytes);
-    L.black = take(4 * (ca4max + 4));
+    L.black = take(4 * (ca4max + 8));
     L.stsc = take(4 * 28);
-    L.boff = take(4 * 3 * (C + 2));
-    L.bring_g = take(4 * RC * 3 * V4_MLB);
-    L.bring_f = take(8 * RC * 3 * V4_MLB);
+    L.ring = take(3 * 16 * rs);
     L.svals = take(4 * 64);
-    L.sink = take(4 * 64);
+    L.sink = take(4 * 64 + 16 * 64);
     L.total = o;
+    L.rs = rs;
     return L;
 }
-static int v4_rows_bytes(const DevProb &d, int R = V4_R)
+static const int V6_SMALL_LDS = 48 * 1024;          // launches are split at this footprint
+static int v6_rows_bytes(const DevProb &d)
 {
     const int lsz = ((d.capa + 3) & ~3) + ((d.capb + 3) & ~3);
-    return (R + 1) * v3_pitch(d.noll == 3 ? 9 : 6, lsz) * 4;
+    return 65 * v3_pitch(d.noll == 3 ? 9 : 6, lsz) * 4 + 32;
+}
+// ring entries the v6 kernel needs per view for this problem: the most pool entries any window of V6_WINDOW consecutive
+// columns of b holds (the ring is indexed by pool position & (rs - 1))
+static int v6_ring_need(const g2g_problem *p)
+{
+    int need = 1;
+    const int lo = p->b.left, hi = p->b.right;
+    for (int v = 0; v < 3; ++v) {
+        const int32_t *off = p->b.gfq.off[v];
+        for (int c = lo; c < hi; ++c) {
+            const int e = std::min(c + V6_WINDOW, hi);
+            need = std::max(need, off[e + 1] - off[c + 1]);
+        }
+    }
+    int rs = 64;
+    while (rs < need) rs <<= 1;
+    return rs;
 }
 struct V3Need { int rows_bytes, ca4, apool, bpool, total; };
 static V3Need v3_need(const DevProb &d, const g2g_problem *p, int C, bool areg = false)
@@ -381,7 +399,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     };
     g2g_batch *b = new g2g_batch();
     b->ctx = ctx; b->n = n; b->d_arena = 0; b->d_probs = 0; b->fwd_ms = b->tb_ms = 0;
-    b->v3_cols = 128; b->v4_cols = 64; b->v2_cols = G2G_V2_TILE_COLS;
+    b->v3_cols = 128; b->v2_cols = G2G_V2_TILE_COLS;
 
     b->dp.resize(n); b->status.assign(n, G2G_OK); b->cells.assign(n, 0); b->out_off.assign(n, 0); b->tcap.assign(n, 0); b->rr1.assign(n, 0);
     Blob bl(ctx);
@@ -449,12 +467,10 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         if (pick(2, 16, 128, 64, ncu * 6) != 128) b->v2_threads = 256;      // (measured crossover: between 1/4 and 1/8 of the bench sweep)
         if (const char *e = getenv("G2G_V2_THREADS")) { const int t = atoi(e); if (t == 128 || t == 256) b->v2_threads = t; }
         b->v2_cols = pick(2, b->v2_threads / 8, G2G_V2_TILE_COLS, 64, ncu * (768 / b->v2_threads));
-        b->v4_cols = 64;
         if (const char *e = getenv("G2G_V2_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v2_cols = c; }
         if (const char *e = getenv("G2G_V3_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v3_cols = c; }
         b->v3_sweep = getenv("G2G_V3_SWEEP") ? atoi(getenv("G2G_V3_SWEEP")) : 1;
         b->v2_sweep = getenv("G2G_V2_SWEEP") ? atoi(getenv("G2G_V2_SWEEP")) : 1;
-        if (const char *e = getenv("G2G_V4_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v4_cols = c; }
     }
     // index lists for the two forward kernels (filled below, once eligibility is known)
     const size_t idx_off = bl.put(0, 0);
@@ -498,10 +514,9 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         // v2 kernel (gap-profile engines): packed 16-bit gap lengths and an LDS budget decide eligibility
         d.v2_ok = 0;
         if ((d.kind == 1 || d.kind == 2) && !getenv("G2G_FORCE_V1") && p->a.len + p->b.len < 65000) {
-            if (!getenv("G2G_FORCE_V2") && getenv("G2G_V5") && !getenv("G2G_V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V3_NA && d.b.maxlist <= V4_MLB &&
-                v4_layout(v4_rows_bytes(d, V5_R), (d.capa + 3) & ~3, b->v4_cols, V5_RC).total <= (int) V2_LDS_MAX) d.v2_ok = 5;
-            else if (!getenv("G2G_FORCE_V2") && getenv("G2G_V4") && !getenv("G2G_V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V3_NA && d.b.maxlist <= V4_MLB &&
-                v4_layout(v4_rows_bytes(d), (d.capa + 3) & ~3, b->v4_cols).total <= (int) V2_LDS_MAX) d.v2_ok = 4;
+            // _pf: one lane per cell with rank-form merges (v6) when the rows' static lists fit the register file
+            if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_V6") && !getenv("G2G_V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V6_NA &&
+                v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(p)).total <= (int) V2_LDS_MAX) d.v2_ok = 6;
             else if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_AREG") && (d.kind == 1 || getenv("G2G_V3_PF")) && d.a.maxlist <= G2G_V3_NA &&
                 v3_need(d, p, b->v3_cols, true).total <= (int) V2_LDS_MAX) d.v2_ok = 3;
             else {
@@ -599,7 +614,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         std::vector<V2Tile> pre[16];                      // boundary chains of sweep-mode DPs: they head their variant's queue
         std::vector<int> ip;                              // the other DPs: chains in the prologue kernel
         const bool chainq = !getenv("G2G_NO_CHAINQ");
-        int v4rows[4] = {0, 0, 0, 0}, v4ca4[4] = {0, 0, 0, 0};
+        int v6rows[4] = {0, 0, 0, 0}, v6ca4[4] = {0, 0, 0, 0}, v6rs[4] = {64, 64, 64, 64};
         V3Need need[8];
         memset(need, 0, sizeof need);
         for (int i = 0; i < n; ++i) {
@@ -614,15 +629,18 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
                 b->simtile_lds = std::max(b->simtile_lds, (size_t) 8 * SIM_TR * ((d.a.nelm - d.a.felm + 1) & ~1) + (vecb ? (size_t) 8 * SIM_TC * (d.b.felm > 0 ? d.b.felm : 0) : (size_t) SIM_TC * d.b.many) + 64);
             }
             const int al = d.a.left, ar = d.a.right, bl_ = d.b.left, br = d.b.right;
-            const int R = d.v2_ok == 5 ? V5_R : d.v2_ok == 4 ? V4_R : d.v2_ok >= 2 ? 64 : b->v2_threads / 8;
+            const int R = d.v2_ok >= 2 ? 64 : b->v2_threads / 8;
             const bool swp3 = (d.v2_ok == 3 || d.v2_ok == 2) && d.kind == 1 && b->v3_sweep;   // one tile per strip, pipelined (kind 1 only: no column pool)
-            const bool swp2 = d.v2_ok == 1 && b->v2_sweep;
-            const int C = (swp3 || swp2) ? (1 << 20) : d.v2_ok >= 4 ? b->v4_cols : d.v2_ok >= 2 ? b->v3_cols : b->v2_cols;
+            const bool swp2 = (d.v2_ok == 1 && b->v2_sweep) || d.v2_ok == 6;     // (v6 knows sweep mode only)
+            const int C = (swp3 || swp2) ? (1 << 20) : d.v2_ok >= 2 ? b->v3_cols : b->v2_cols;
             const int nstrip = (ar - al + R - 1) / R, nblk = (br - bl_ + C - 1) / C;
-            const int var = d.v2_ok >= 4 ? 12 + 2 * (d.v2_ok - 4) + (d.noll == 3 ? 1 : 0) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
-            if (d.v2_ok >= 4) {
-                v4rows[var - 12] = std::max(v4rows[var - 12], v4_rows_bytes(d, d.v2_ok == 5 ? V5_R : V4_R));
-                v4ca4[var - 12] = std::max(v4ca4[var - 12], (d.capa + 3) & ~3);
+            // (one LDS plan per launch = the largest of its DPs: DPs whose column lists need a big ring get a launch of their own,
+            //  or a handful of balanced divisions would cost every strip of the sweep its occupancy)
+            const int var = d.v2_ok == 6 ? 12 + (d.noll == 3 ? 1 : 0) + (v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(prob[i])).total > V6_SMALL_LDS ? 2 : 0) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
+            if (d.v2_ok == 6) {
+                v6rows[var - 12] = std::max(v6rows[var - 12], v6_rows_bytes(d));
+                v6ca4[var - 12] = std::max(v6ca4[var - 12], (d.capa + 3) & ~3);
+                v6rs[var - 12] = std::max(v6rs[var - 12], v6_ring_need(prob[i]));
             } else if (d.v2_ok >= 2) {
                 const V3Need nd = v3_need(d, prob[i], C, d.v2_ok == 3);
                 V3Need &x = need[var - 4];
@@ -674,7 +692,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             for (size_t k = 0; k < q[v].size(); ++k) all.insert(all.end(), q[v][k].begin(), q[v][k].end());
         }
         b->var_off[16] = (int) all.size();
-        for (int v = 0; v < 4; ++v) b->v4lds[v] = v4_layout(v4rows[v], v4ca4[v], b->v4_cols, v < 2 ? V4_RC : V5_RC);
+        for (int v = 0; v < 4; ++v) b->v6lds[v] = v6_layout(v6rows[v], v6ca4[v], v6rs[v]);
         for (int v = 0; v < 8; ++v) b->v3lds[v] = v3_layout(need[v].rows_bytes, need[v].ca4, need[v].apool, need[v].bpool, b->v3_cols);
         b->ntiles = (long long) all.size();
         b->nflags = (int) flags.size();
@@ -803,27 +821,31 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipEventRecord(ctx->vev[v & 3], vs));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[v & 3], 0));
         }
-        for (int v = 0; v < 4; ++v) {
+        for (int vi = 0; vi < 4; ++vi) {
+            const int v = 3 - vi;                    // (large-footprint launches first: they hold the longest DPs)
             const int cnt = b->var_off[v + 13] - b->var_off[v + 12];
             if (!cnt) continue;
-            typedef void (*v4k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V4Lds, int);
-            static const v4k_t v4k[4] = {g2g_v4_pf2, g2g_v4_pf3, g2g_v5_pf2, g2g_v5_pf3};
-            hipStream_t vs = ctx->vstream[2 + (v & 1)];
-            const V4Lds &LO = b->v4lds[v];
-            if (LO.total > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *) v4k[v], hipFuncAttributeMaxDynamicSharedMemorySize, LO.total));
+            typedef void (*v6k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V6Lds, int, int);
+            static const v6k_t v6k[4] = {g2g_v6_pf2, g2g_v6_pf3, g2g_v6_pf2, g2g_v6_pf3};
+            hipStream_t vs = ctx->vstream[v < 2 ? 2 + v : 2 + v];        // small: streams 2, 3; large footprint: 4, 5
+            const int jev = v < 2 ? 2 + v : 3 + v;
+            const V6Lds &LO = b->v6lds[v];
+            if (LO.total > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *) v6k[v], hipFuncAttributeMaxDynamicSharedMemorySize, LO.total));
             HIPCHK(hipStreamWaitEvent(vs, ctx->vev[4], 0));
-            int wpc = (int) (V2_LDS_MAX / (size_t) LO.total);              // resident tiles per CU (LDS-bound)
-            if (wpc < 1) wpc = 1; if (wpc > 4 * G2G_V4_WPE) wpc = 4 * G2G_V4_WPE;
-            if (const char *e = getenv("G2G_V4_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc = w; }
+            int wpc = (int) (V2_LDS_MAX / (size_t) LO.total);              // resident strips per CU (LDS-bound)
+            if (wpc < 1) wpc = 1; if (wpc > 8) wpc = 8;
+            if (const char *e = getenv("G2G_V6_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc = w; }
             const int grid = std::min(cnt, ncu * wpc);
-            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v4 variant %d: %d tiles, grid %d, lds %d, cols %d, gen %d\n", v, cnt, grid, LO.total, b->v4_cols, b->gen); fflush(stderr); }
-            hipLaunchKernelGGL(v4k[v], dim3(grid), dim3(64), (size_t) LO.total, vs,
+            const int pint = b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= ncu * wpc ? 4 : cnt < 4 * ncu * wpc ? 16 : 32;   // publish interval (power of 2)
+            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v6 variant %d: %d strips, grid %d, lds %d (ring %d entries), publish every %d, gen %d\n", v, cnt, grid, LO.total, LO.rs, pint, b->gen); fflush(stderr); }
+            hipLaunchKernelGGL(v6k[v], dim3(grid), dim3(64), (size_t) LO.total, vs,
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v + 12]), cnt,
-                               b->d_flags + 12 + v, b->d_flags, b->gen, LO, b->v4_cols);
+                               b->d_flags + 12 + v, b->d_flags, b->gen, LO, pint,
+                               (pro_off && pro_off + (int) PRO_LDS_BYTES <= LO.svals) ? pro_off : 0);
             HIPCHK(hipGetLastError());
-            if (getenv("G2G_DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v4 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
-            HIPCHK(hipEventRecord(ctx->vev[2 + (v & 1)], vs));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[2 + (v & 1)], 0));
+            if (getenv("G2G_DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v6 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
+            HIPCHK(hipEventRecord(ctx->vev[jev], vs));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[jev], 0));
         }
     }
     if (b->n1) {
@@ -904,6 +926,13 @@ extern "C" void g2g_batch_free(g2g_batch *b)
     delete b;
 }
 
+#ifdef G2G_V6_STAMP
+extern "C" void g2g_v6_stamps(unsigned long long *out, int reset)
+{
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g2g_v6_stamp_acc), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g2g_v6_stamp_acc), z, sizeof z); }
+}
+#endif
 #ifdef G2G_V2_STAMP
 extern "C" void g2g_stamps(unsigned long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g2g_stamp_acc), sizeof(unsigned long long) * 16); }
 extern "C" void g2g_waits(unsigned long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g2g_wait_acc), sizeof(unsigned long long) * 4); }

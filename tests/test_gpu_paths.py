@@ -1,7 +1,7 @@
 """Every forward-kernel generation and tile geometry against the reference goldens and the oracle.
 
 The engine picks a kernel per problem (g2g_engine.hip: v3r = one lane per cell with the rows' static lists in
-registers, v3 = the same with the lists in LDS, v4 = 8-lane teams in single-wave tiles (_pf), v2 = 8-lane teams
+registers, v3 = the same with the lists in LDS, v6 = one lane per cell with rank-form merges (_pf), v2 = 8-lane teams
 in 4-wave workgroups, v1 = anti-diagonal sweep with the state in HBM).  The selection can be forced through environment variables that are read at batch-prepare time; each
 forced configuration must reproduce the reference bit for bit.  Narrow tiles (G2G_V3_COLS) make even the small
 golden DPs span several column blocks and strips."""
@@ -29,10 +29,8 @@ CONFIGS = {
     "v3lds_all": {"G2G_NO_AREG": "1", "G2G_V3_PF": "1"},
     "v3lds_all_cols32": {"G2G_NO_AREG": "1", "G2G_V3_PF": "1", "G2G_V3_COLS": "32", "G2G_V3_SWEEP": "0"},   # tile mode
     "v3_pf": {"G2G_V3_PF": "1", "G2G_V3_COLS": "64"},
-    "v4": {"G2G_V4": "1"},
-    "v4_cols16": {"G2G_V4": "1", "G2G_V4_COLS": "16"},
-    "v5": {"G2G_V5": "1"},
-    "v5_cols16": {"G2G_V5": "1", "G2G_V4_COLS": "16"},
+    "no_v6": {"G2G_NO_V6": "1"},                                     # _pf on the 8-lanes-per-cell kernel instead of v6
+    "v6_publish4": {"G2G_V2_SWEEP": "4"},                            # progress counters published every 4 steps
     "v2": {"G2G_FORCE_V2": "1"},
     "v2_t128": {"G2G_FORCE_V2": "1", "G2G_V2_THREADS": "128"},
     "v2_tiles": {"G2G_FORCE_V2": "1", "G2G_V2_SWEEP": "0"},
@@ -80,7 +78,7 @@ FAMILIES = [
 ]
 
 
-@pytest.mark.parametrize("name", ["v3r_cols32", "v3r_tiles", "v3lds_all", "v3_pf", "v4", "v5", "v2", "v2_t128", "v2_tiles", "v2_tiles_t128"])
+@pytest.mark.parametrize("name", ["default", "v6_publish4", "no_v6", "v3r_cols32", "v3r_tiles", "v3lds_all", "v3_pf", "v2", "v2_t128", "v2_tiles", "v2_tiles_t128"])
 @pytest.mark.parametrize("fam", FAMILIES, ids=[f[0] for f in FAMILIES])
 def test_large_divisions_every_path(ctx, L, monkeypatch, name, fam):
     """Group-vs-rest divisions of a 650-700 column family (many strips and blocks) per forced path."""

@@ -13,6 +13,12 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/stats -o s --output-for
 cp $O/stats/s_kernel_stats.csv $O/kernel_stats.csv
 echo "[profile] kernel stats done"
 k=0
+# QUICK=1: instruction / wait counters only (one pass) -- for iterating on a kernel
+if [ -n "$QUICK" ]; then
+    timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $O/pmc_3 -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/pmc_3.err || exit 1
+    python3 $R/tools/summarize_pmc.py $O
+    exit 0
+fi
 for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
            "SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY"; do

@@ -28,4 +28,4 @@ json.dump({"hbm_bytes_per_launch": hbm,
 print("[profile] hbm bytes per sweep: %.4g" % hbm)
 for k in sorted(per):
     v = per[k]
-    print(k, {c: v[c] for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY") if c in v})
+    print(k, {c: v[c] for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY") if c in v})
