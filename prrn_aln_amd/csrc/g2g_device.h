@@ -15,6 +15,8 @@
 struct DevSide {
     int many, len, left, right, nils, nelm, felm, hetero;
     int maxlist;         // longest static gap-profile list incl. its terminator (any view, any position)
+    int r_from_t;        // every r list = [optional head {glen 0}] + the t list of the position with glen + 1 (how Gfq builds it,
+                         // gfreq.cc:218-226): checked at pack time; lets a kernel keep s and t only
     const uint8_t *seq;
     const double  *weight;
     const double  *pseq;

@@ -349,6 +349,20 @@ static void pack_side(Blob &bl, const g2g_side &s, DevSide &d, int kind, bool ne
     d.thk = OFF<const double>(bl.put(s.thk, sizeof(double) * cols * 3));
     if (need_gfq) {
         d.hetero = s.gfq.hetero;
+        {   // r = [head?] + (t with glen + 1): the structure Gfq::seq2gfq gives the r view (reference src/gfreq.cc:218-226)
+            bool ok = true;
+            const int32_t *to = s.gfq.off[1], *ro = s.gfq.off[2], *tg = s.gfq.glen[1], *rg = s.gfq.glen[2];
+            const double *tf = s.gfq.freq[1], *rf = s.gfq.freq[2];
+            for (int i = 1; i <= s.len && ok; ++i) {            // positions 0 .. len-1 (position -1 is the boundary's: only the chains read it)
+                const int tl = to[i + 1] - to[i] - 1, rl = ro[i + 1] - ro[i] - 1;        // entries without the terminator
+                if (tl < 0 || rl < 0) { ok = false; break; }
+                const int h = (rl > 0 && rg[ro[i]] == 0) ? 1 : 0;
+                if (rl != tl + h) { ok = false; break; }
+                for (int k = 0; k < tl; ++k)
+                    if (rg[ro[i] + h + k] != tg[to[i] + k] + 1 || rf[ro[i] + h + k] != tf[to[i] + k]) { ok = false; break; }
+            }
+            d.r_from_t = ok ? 1 : 0;
+        }
         for (int v = 0; v < 3; ++v) {
             const int nlist = s.len + 2;                       // offsets for positions -1..len-1 + end
             const int pool = s.gfq.off[v][s.len + 1];
@@ -515,8 +529,8 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         d.v2_ok = 0;
         if ((d.kind == 1 || d.kind == 2) && !getenv("G2G_FORCE_V1") && p->a.len + p->b.len < 65000) {
             // _pf: one lane per cell with rank-form merges (v6) when the rows' static lists fit the register file
-            if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_V6") && !getenv("G2G_V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V6_NA &&
-                v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(p)).total <= (int) V2_LDS_MAX) d.v2_ok = 6;
+            if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_V6") && !getenv("G2G_V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V6_NA && d.a.r_from_t &&
+                v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(p)).total <= (getenv("G2G_V6_LARGE") ? (int) V2_LDS_MAX : V6_SMALL_LDS)) d.v2_ok = 6;
             else if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_AREG") && (d.kind == 1 || getenv("G2G_V3_PF")) && d.a.maxlist <= G2G_V3_NA &&
                 v3_need(d, p, b->v3_cols, true).total <= (int) V2_LDS_MAX) d.v2_ok = 3;
             else {

@@ -49,10 +49,10 @@ struct V6Lds { int rows, black, stsc, ring, svals, sink, total, rs; };     // by
 // ---- register heads of dynamic lists ---------------------------------------------------------------------
 // {glen,nins} packed 16+16, ascending in both, terminator 0xFFFF0000; the first entry is never the terminator.  Behind the
 // terminator memory is stale: the head replaces it by terminators, so a lookup is a chain of unsigned compares of the
-// packed key (g << 16 | 0xFFFF) with no validity tests.  NE leading entries are held (4: one ds_read_b128; 8: two);
+// packed key (g << 16 | 0xFFFF) with no validity tests.  NE leading entries are held (5: ds_read_b128 + b64; 8: two b128);
 // x = entry NE, sanitised the same way: x < T says the list is longer than the head.
-// The cell exists in three instances (v6_cell_pf): NE = 4 and NE = 8 WITHOUT any per-lookup test -- they leave at once
-// when some lane's list is longer than the head (0.06 % of the lists have five entries or more, 4e-6 nine or more) -- and
+// The cell exists in three instances (v6_cell_pf): NE = 5 and NE = 8 WITHOUT any per-lookup test -- they leave at once
+// when some lane's list is longer than the head (0.012 % of the lists have six entries or more, 4e-6 nine or more) -- and
 // NE = 8 with an inline scan of LDS behind the head (SCAN), which is correct for any length.
 #define V6_UNROLL _Pragma("clang loop unroll(full)")
 template <int NE> struct DH { unsigned e[NE]; unsigned x; const lu32 *p; };
@@ -63,8 +63,9 @@ __device__ __forceinline__ DH<NE> dh_load6(const lu32 *p)
     DH<NE> h;
     const v4u32 v = *(const LDS v4u32 *) p;
     h.e[0] = v.x; h.e[1] = v.y; h.e[2] = v.z; h.e[3] = v.w;
-    if (NE == 8) { const v4u32 w = *(const LDS v4u32 *) (p + 4); h.e[4] = w.x; h.e[5] = w.y; h.e[6] = w.z; h.e[7] = w.w; }
-    h.x = p[NE];
+    if (NE == 8) { const v4u32 w = *(const LDS v4u32 *) (p + 4); h.e[4] = w.x; h.e[5] = w.y; h.e[6] = w.z; h.e[7] = w.w; h.x = p[8]; }
+    else if (NE == 5) { const unsigned long long w = *(const LDS unsigned long long *) (p + 4); h.e[4] = (unsigned) w; h.x = (unsigned) (w >> 32); }
+    else h.x = p[NE];
     V6_UNROLL
     for (int k = 2; k < NE; ++k) h.e[k] = (h.e[k - 1] >= T) ? T : h.e[k];
     h.x = (h.e[NE - 1] >= T) ? T : h.x;
@@ -115,12 +116,24 @@ __device__ __forceinline__ void v6_incdelta(const bool on, const DH<NE> &h, lu32
     w.x = h.e[0] + 1; w.y = h.e[1] >= T ? T : h.e[1] + 1; w.z = h.e[2] >= T ? T : h.e[2] + 1; w.w = h.e[3] >= T ? T : h.e[3] + 1;
     *(LDS v4u32 *) (on ? d1 : sink16) = w;
     *(LDS v4u32 *) ((on && d2) ? d2 : sink16) = w;
+    if (NE == 5) {                                          // entry 4 and the terminator behind it (a list of this instance has five entries at most)
+        const bool m4 = on && h.e[3] < T;
+        if (__ballot(m4)) {
+            const unsigned long long w45 = ((unsigned long long) T << 32) | (h.e[4] >= T ? T : h.e[4] + 1);
+            *(LDS unsigned long long *) (m4 ? d1 + 4 : sink16) = w45;
+            *(LDS unsigned long long *) ((m4 && d2) ? d2 + 4 : sink16) = w45;
+        }
+    }
     if (NE == 8) {                                          // (entry 4 is only looked at when entry 3 is not the terminator)
         const bool m4 = on && h.e[3] < T;
         if (__ballot(m4)) {
             w.x = h.e[4] >= T ? T : h.e[4] + 1; w.y = h.e[5] >= T ? T : h.e[5] + 1; w.z = h.e[6] >= T ? T : h.e[6] + 1; w.w = h.e[7] >= T ? T : h.e[7] + 1;
             *(LDS v4u32 *) (m4 ? d1 + 4 : sink16) = w;
             *(LDS v4u32 *) ((m4 && d2) ? d2 + 4 : sink16) = w;
+        }
+        if (!SCAN) {                                        // eight entries: the terminator sits behind the head
+            const bool m8 = on && h.e[7] < T;
+            if (__ballot(m8)) { *(m8 ? d1 + 8 : sink16) = T; *((m8 && d2) ? d2 + 8 : sink16) = T; }
         }
     }
     if (SCAN) {
@@ -172,21 +185,25 @@ __device__ __forceinline__ SE6 se6_read(const lchar *ring, const int idx)
 
 // the row's static lists in registers: glen as lookup key ((g << 16) | 0xFFFF; slots behind the list: key 0xFFFF, freq 0) and freq;
 // ls / lt / lr: the lane's list lengths
-template <int N> struct A6 { const unsigned (&sk)[N]; const double (&sf)[N]; const unsigned (&tk)[N]; const double (&tf)[N]; const unsigned (&rk)[N]; const double (&rf)[N]; int ls, lt, lr; };
+// The r view is not held: r = [head {glen 0, freq rhf}, if present] + the t list with glen + 1 (DevSide::r_from_t).
+template <int N> struct A6 { const unsigned (&sk)[N]; const double (&sf)[N]; const unsigned (&tk)[N]; const double (&tf)[N]; double rhf; int ls, lt; };
 struct B6 { const lchar *rs, *rt, *rr; int os, ot, orr, lens, mask; };      // the lane's column: ring bases, list starts, length of s
 
 // one "X" merge: cf = the column's s list (ring, stretched by dlb of the record), df = a row list in registers (stretched by
-// dla): newgap(b.s, dlb, a.t|a.r, dla).  lmax: the wave's longest s list; dlen: this lane's df length.
-template <int N, int NE, bool SCAN>
-__device__ __forceinline__ double v6_xmerge(const DH<NE> &ha, const DH<NE> &hb, const unsigned (&dk)[N], const double (&dfq)[N], const int dlen,
+// dla): newgap(b.s, dlb, a.t|a.r, dla).  RV: df is the r view = an optional head entry {glen 0, freq hf} followed by the t
+// entries with glen + 1 (hf = 0: no head; its term is then +0).  lmax: the wave's longest s list.  Slots behind the row's
+// list hold key 0xFFFF / freq 0: their terms are +0 as well, so validity needs no test.
+template <int N, int NE, bool SCAN, bool RV>
+__device__ __forceinline__ double v6_xmerge(const DH<NE> &ha, const DH<NE> &hb, const unsigned (&dk)[N], const double (&dfq)[N], const double hf,
                                             const int TA, const B6 &B, const int lmax)
 {
-    unsigned j[N];
-    double S[N];
+    unsigned j[N], jh = 0;
+    double S[N], Sh = 0;
+    if (RV) jh = dh_stretch<NE, SCAN>(0xFFFFu, ha);
     V6_UNROLL
     for (int d = 0; d < N; ++d) {
         if (d < TA) {
-            j[d] = d < dlen ? dh_stretch<NE, SCAN>(dk[d], ha) : 0xFFFFFFFFu;          // (behind the list: never reached)
+            j[d] = dh_stretch<NE, SCAN>(dk[d] + (RV ? 0x10000u : 0u), ha);
             S[d] = 0;
         }
     }
@@ -194,11 +211,13 @@ __device__ __forceinline__ double v6_xmerge(const DH<NE> &ha, const DH<NE> &hb, 
         const bool valid = kk < B.lens;
         const SE6 e = se6_read(B.rs, (B.os + (valid ? kk : 0)) & B.mask);
         const unsigned i = valid ? dh_stretch<NE, SCAN>(e.key, hb) : 0u;
+        if (RV) Sh = i >= jh ? e.f : Sh;
         V6_UNROLL
         for (int d = 0; d < N; ++d)
             if (d < TA) S[d] = i >= j[d] ? e.f : S[d];
     }
     double g = 0;
+    if (RV) g += Sh * hf;
     V6_UNROLL
     for (int d = 0; d < N; ++d)
         if (d < TA) g += S[d] * dfq[d];
@@ -208,7 +227,7 @@ __device__ __forceinline__ double v6_xmerge(const DH<NE> &ha, const DH<NE> &hb, 
 // ---- one cell by one lane ----------------------------------------------------------------------------------
 // Returns false -- before anything is stored -- when !SCAN and some lane's list is longer than the heads of this instance.
 template <bool NOLL3, int N, int NE, bool SCAN>
-__device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, const A6<N> &A, const int TAs, const int TAt, const int TAr,
+__device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, const A6<N> &A, const int TAs, const int TAt,
     const B6 &B, lu32 *sink, lu32 *sink16,
     const RS &hd, const lu32 *hdl, const RS &hu, const lu32 *hul, const RS &gu, const lu32 *gul,
     const RS &g2u, const lu32 *g2ul, const RS &hl, const lu32 *hll, const RS &fl, const lu32 *fll,
@@ -236,20 +255,22 @@ __device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, cons
     }
     V6_STAMP(1)
     Costs c;
+    c.d0 = c.d1 = c.gnpv = c.gopv = c.gnph = c.goph = c.gnpv2 = c.gnph2 = 0;
+#ifndef V6_SKIP_Y
     // ---- "Y" merges: cf = the row's s list (registers), df = a column list (ring): diagonal part 0 (b.t, record hd),
     // vertical gnp / gop (b.r, records gu / hu), vertical2 (b.r, g2u) -- gfreq.cc:507-521 in rank form
     {
-        unsigned i_hd[N], i_gu[N], i_hu[N], i_g2[N];          // stretched keys; 0 behind the list (below every j)
+        unsigned i_hd[N], i_gu[N], i_hu[N], i_g2[N];          // stretched keys
         unsigned m_hd = 0, m_gu = 0, m_hu = 0, m_g2 = 0;
         V6_UNROLL
         for (int k = 0; k < N; ++k) {
             if (k < TAs) {
-                const bool v = k < A.ls;
+                // (slots behind the list: key 0xFFFF, freq 0 -- a hit there selects freq 0, which is what an exhausted cf adds)
                 const unsigned key = A.sk[k];
-                i_hd[k] = v ? dh_stretch<NE, SCAN>(key, a_hd) : 0u;
-                i_gu[k] = v ? dh_stretch<NE, SCAN>(key, a_gu) : 0u;
-                i_hu[k] = v ? dh_stretch<NE, SCAN>(key, a_hu) : 0u;
-                if (NOLL3) i_g2[k] = v ? dh_stretch<NE, SCAN>(key, a_g2) : 0u;
+                i_hd[k] = dh_stretch<NE, SCAN>(key, a_hd);
+                i_gu[k] = dh_stretch<NE, SCAN>(key, a_gu);
+                i_hu[k] = dh_stretch<NE, SCAN>(key, a_hu);
+                if (NOLL3) i_g2[k] = dh_stretch<NE, SCAN>(key, a_g2);
                 m_hd = i_hd[k] > m_hd ? i_hd[k] : m_hd;
                 m_gu = i_gu[k] > m_gu ? i_gu[k] : m_gu;
                 m_hu = i_hu[k] > m_hu ? i_hu[k] : m_hu;
@@ -268,15 +289,16 @@ __device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, cons
             const unsigned j3 = NOLL3 ? dh_stretch<NE, SCAN>(er.key, b_g2) : 0u;
             l0 = l0 && m_hd >= j0; l1 = l1 && m_gu >= j1; l2 = l2 && m_hu >= j2; l3 = l3 && m_g2 >= j3;       // cf exhausted: break
             double S0 = 0, S1 = 0, S2 = 0, S3 = 0;
-            V6_UNROLL
-            for (int k = N - 1; k >= 0; --k) {
-                if (k < TAs) {
-                    S0 = i_hd[k] >= j0 ? A.sf[k] : S0;
-                    S1 = i_gu[k] >= j1 ? A.sf[k] : S1;
-                    S2 = i_hu[k] >= j2 ? A.sf[k] : S2;
-                    if (NOLL3) S3 = i_g2[k] >= j3 ? A.sf[k] : S3;
-                }
+            // from the wave's last s entry down to entry 0: a fall-through switch (a guarded unrolled loop is turned into
+            // selects over all N entries by the compiler; the jump is wave-uniform)
+#define V6_YCH(k) if (N > (k)) { S0 = i_hd[k] >= j0 ? A.sf[k] : S0; S1 = i_gu[k] >= j1 ? A.sf[k] : S1; S2 = i_hu[k] >= j2 ? A.sf[k] : S2; \
+                                 if (NOLL3) S3 = i_g2[k] >= j3 ? A.sf[k] : S3; }
+            switch (TAs) {
+            default: V6_YCH(15) case 15: V6_YCH(14) case 14: V6_YCH(13) case 13: V6_YCH(12) case 12: V6_YCH(11) case 11: V6_YCH(10)
+            case 10: V6_YCH(9) case 9: V6_YCH(8) case 8: V6_YCH(7) case 7: V6_YCH(6) case 6: V6_YCH(5) case 5: V6_YCH(4)
+            case 4: V6_YCH(3) case 3: V6_YCH(2) case 2: V6_YCH(1) case 1: V6_YCH(0) case 0: ;
             }
+#undef V6_YCH
             g0 = l0 ? g0 + S0 * et.f : g0;
             g1 = l1 ? g1 + S1 * er.f : g1;
             g2 = l2 ? g2 + S2 * er.f : g2;
@@ -284,22 +306,26 @@ __device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, cons
         }
         c.d0 = g0 * P.basic_gop; c.gnpv = g1 * P.basic_gop; c.gopv = g2 * P.basic_gop; c.gnpv2 = NOLL3 ? g3 * P.basic_gop : 0;
     }
+#endif
     V6_STAMP(2)
+#ifndef V6_SKIP_X
     // ---- "X" merges: cf = the column's s list, df = a row list: diagonal part 1 (a.t, hd), horizontal gnp / gop (a.r, fl / hl)
     {
         int lmax = 0;
         while (__ballot(B.lens > lmax)) ++lmax;
-        c.d1 = v6_xmerge<N, NE, SCAN>(a_hd, b_hd, A.tk, A.tf, A.lt, TAt, B, lmax) * P.basic_gop;
-        c.gnph = v6_xmerge<N, NE, SCAN>(a_fl, b_fl, A.rk, A.rf, A.lr, TAr, B, lmax) * P.basic_gop;
-        c.goph = v6_xmerge<N, NE, SCAN>(a_hl, b_hl, A.rk, A.rf, A.lr, TAr, B, lmax) * P.basic_gop;
-        c.gnph2 = NOLL3 ? v6_xmerge<N, NE, SCAN>(a_f2, b_f2, A.rk, A.rf, A.lr, TAr, B, lmax) * P.basic_gop : 0;
+        c.d1 = v6_xmerge<N, NE, SCAN, false>(a_hd, b_hd, A.tk, A.tf, 0., TAt, B, lmax) * P.basic_gop;
+        c.gnph = v6_xmerge<N, NE, SCAN, true>(a_fl, b_fl, A.tk, A.tf, A.rhf, TAt, B, lmax) * P.basic_gop;
+        c.goph = v6_xmerge<N, NE, SCAN, true>(a_hl, b_hl, A.tk, A.tf, A.rhf, TAt, B, lmax) * P.basic_gop;
+        c.gnph2 = NOLL3 ? v6_xmerge<N, NE, SCAN, true>(a_f2, b_f2, A.tk, A.tf, A.rhf, TAt, B, lmax) * P.basic_gop : 0;
     }
+#endif
     V6_STAMP(3)
     const Dec d = v3_decide<2, NOLL3>(P, c, hd, hu, gu, g2u, hl, fl, f2l, do_vert, do_hori, dab, pua, pub);
     const int win = d.win;
     V6_STAMP(4)
     // ---- list updates (update(), fwd2c.cc:216-231); the winner's lists are also the new H's -------------------
     lu32 *const nul = (lu32 *) 0;
+#ifndef V6_SKIP_ND
     {   // a side: newdelta over a.t for G (G2) and a diagonal H; incdelta for F (F2)
         const DHn h_gs = dh_sel6<NE>(d.g_from_h, a_hu, a_gu), h_gs2 = dh_sel6<NE>(d.g2_from_h, a_hu, a_g2);
         ND6 n_g = {0, 0, 0, do_vert}, n_h = {0, 0, 0, win == 0}, n_g2 = {0, 0, 0, do_vert && NOLL3};
@@ -337,6 +363,7 @@ __device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, cons
         v6_incdelta<NE, SCAN>(do_vert, dh_sel6<NE>(d.g_from_h, b_hu, b_gu), dg + ca4, win == 1 ? dh + ca4 : nul, sink16);
         if (NOLL3) v6_incdelta<NE, SCAN>(do_vert, dh_sel6<NE>(d.g2_from_h, b_hu, b_g2), dg2 + ca4, win == 2 ? dh + ca4 : nul, sink16);
     }
+#endif
     V6_STAMP(6)
     v3_outputs<2, NOLL3>(d, 0, 0, do_vert, do_hori, oH, oG, oG2, oF, oF2, trb);
     V6_STAMP(7)
@@ -413,23 +440,24 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
         p[ca4] = 0; p[ca4 + 1] = DL_END << 16;
     }
     // ---- the row's static lists -> registers; the wave's longest list per view bounds the unrolled loops
-    unsigned a_sk[NA], a_tk[NA], a_rk[NA];
-    double a_sf[NA], a_tf[NA], a_rf[NA];
-    int ls = 0, lt = 0, lr = 0;
+    unsigned a_sk[NA], a_tk[NA];
+    double a_sf[NA], a_tf[NA], a_rhf = 0;
+    int ls = 0, lt = 0;
     {
         int g[NA];
         rl_load(g, a_sf, a, 0, m, row_ok);
         V6_UNROLL for (int k = 0; k < NA; ++k) { a_sk[k] = v6_key(g[k]); ls += g[k] >= 0; }
         rl_load(g, a_tf, a, 1, m, row_ok);
         V6_UNROLL for (int k = 0; k < NA; ++k) { a_tk[k] = v6_key(g[k]); lt += g[k] >= 0; }
-        rl_load(g, a_rf, a, 2, m, row_ok);
-        V6_UNROLL for (int k = 0; k < NA; ++k) { a_rk[k] = v6_key(g[k]); lr += g[k] >= 0; }
+        if (row_ok) {                                      // the r view's head entry, if any (glen 0; the t entries follow with glen + 1)
+            const int o = a.off[2][m + 1];
+            if (a.off[2][m + 2] - o - 1 > lt) a_rhf = a.freq[2][o];
+        }
     }
-    const A6<NA> A = {a_sk, a_sf, a_tk, a_tf, a_rk, a_rf, ls, lt, lr};
-    int TAs = 0, TAt = 0, TAr = 0;
+    const A6<NA> A = {a_sk, a_sf, a_tk, a_tf, a_rhf, ls, lt};
+    int TAs = 0, TAt = 0;
     while (__ballot(ls > TAs)) ++TAs;
     while (__ballot(lt > TAt)) ++TAt;
-    while (__ballot(lr > TAr)) ++TAr;
     // ---- the ring of the columns' static lists
     const int rmask = LO.rs - 1;
     lchar *const ringS = lds + LO.ring, *const ringT = ringS + (size_t) LO.rs * 16, *const ringR = ringT + (size_t) LO.rs * 16;
@@ -639,12 +667,12 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
             const double pua = a.nils ? unpa(P, m, n) : pua_row;
             const double pub = bc_cur * a_efq * -P.u;                       // unp1(bsi, asi), maln.h:185-187
             int trb = 0;
-// three instances of the cell: heads of 4 entries, of 8, and 8 + scan (see dh_load6); the first that applies runs
-            if (!v6_cell_pf<NOLL3, NA, 4, false>(P, ca4, A, TAs, TAt, TAr, B, sink, sink16, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
+// three instances of the cell: heads of 5 entries, of 8, and 8 + scan (see dh_load6); the first that applies runs
+            if (!v6_cell_pf<NOLL3, NA, 5, false>(P, ca4, A, TAs, TAt, B, sink, sink16, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
                                   dh, dg, dg2, df, df2, do_vert, do_hori, sim_cur, pua, pub, myH, myG, myG2, oF, oF2, trb V6_STAMP_PASS))
-                if (!v6_cell_pf<NOLL3, NA, 8, false>(P, ca4, A, TAs, TAt, TAr, B, sink, sink16, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
+                if (!v6_cell_pf<NOLL3, NA, 8, false>(P, ca4, A, TAs, TAt, B, sink, sink16, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
                                   dh, dg, dg2, df, df2, do_vert, do_hori, sim_cur, pua, pub, myH, myG, myG2, oF, oF2, trb V6_STAMP_PASS))
-                    v6_cell_pf<NOLL3, NA, 8, true>(P, ca4, A, TAs, TAt, TAr, B, sink, sink16, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
+                    v6_cell_pf<NOLL3, NA, 8, true>(P, ca4, A, TAs, TAt, B, sink, sink16, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
                                   dh, dg, dg2, df, df2, do_vert, do_hori, sim_cur, pua, pub, myH, myG, myG2, oF, oF2, trb V6_STAMP_PASS);
             const int d = m + n;
             int mlo, mhi;
