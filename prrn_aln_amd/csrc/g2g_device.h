@@ -45,6 +45,7 @@ struct DevProb {
     int2    *dla[NX];
     int2    *dlb[NX];
     int     *glb[NX];    // _hf: running gap length of b ; _nv: gla/glb member arrays [(an+bn)][width]
+    int      spw;        // stride of the two scratch lists g2g_spscore_kernel keeps in dla/dlb[XH] (width for v1 DPs, else 1)
     // v2 kernel: strip boundary (one record per column) and left boundary chain (one per row) in HBM
     void    *v2_rowH, *v2_rowG, *v2_rowG2, *v2_colH;   // rowX: 3 buffers of v2_rowstride records
     void    *v2_cbH, *v2_cbF, *v2_cbF2;                // per row: records at the current column-block edge

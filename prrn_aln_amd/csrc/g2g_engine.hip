@@ -501,15 +501,18 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         if (d.kind == 1) { d.capa = p->a.gfq.hetero + 1; d.capb = 0; }
         else if (d.kind == 2) { d.capa = p->a.gfq.hetero + 1; d.capb = p->b.gfq.hetero + 1; }
         else if (d.kind == 3) { d.capa = p->a.many; d.capb = p->b.many; }
-        for (int x = 0; x < NX; ++x) {
-            if (d.noll != 3 && (x == XG2 || x == XF2)) continue;
-            d.val[x] = OFF<double>(take(sizeof(double) * W));
-            d.dir[x] = OFF<uint8_t>(take(W));
-            if (d.kind == 1 || d.kind == 2) d.dla[x] = OFF<int2>(take(sizeof(int2) * W * d.capa));
-            if (d.kind == 2) d.dlb[x] = OFF<int2>(take(sizeof(int2) * W * d.capb));
-            if (d.kind == 1) d.glb[x] = OFF<int>(take(sizeof(int) * W));
-            if (d.kind == 3) d.glb[x] = OFF<int>(take(sizeof(int) * W * (d.capa + d.capb)));
-        }
+        auto v1_state = [&]() {                // the diagonal-indexed row buffers of g2g_forward_kernel (v1): only for DPs it runs
+            for (int x = 0; x < NX; ++x) {
+                if (d.noll != 3 && (x == XG2 || x == XF2)) continue;
+                d.val[x] = OFF<double>(take(sizeof(double) * W));
+                d.dir[x] = OFF<uint8_t>(take(W));
+                if (d.kind == 1 || d.kind == 2) d.dla[x] = OFF<int2>(take(sizeof(int2) * W * d.capa));
+                if (d.kind == 2) d.dlb[x] = OFF<int2>(take(sizeof(int2) * W * d.capb));
+                if (d.kind == 1) d.glb[x] = OFF<int>(take(sizeof(int) * W));
+                if (d.kind == 3) d.glb[x] = OFF<int>(take(sizeof(int) * W * (d.capa + d.capb)));
+            }
+            d.spw = (int) W;
+        };
         // anti-diagonal extent and the widest anti-diagonal
         const int al = p->a.left, ar = p->a.right, bl_ = p->b.left, br = p->b.right;
         d.d0 = al + bl_; d.d1 = (ar - 1) + (br - 1);
@@ -545,6 +548,12 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
                 if (v3tot <= (int) V2_LDS_MAX && (v3tot <= (int) V2_LDS_MAX / 3 || !v2fit || getenv("G2G_NO_AREG"))) d.v2_ok = 2;
                 else if (v2fit) d.v2_ok = 1;
             }
+        }
+        if (!d.v2_ok) v1_state();
+        else {                                  // g2g_spscore_kernel keeps its two dynamic lists in dla/dlb[XH] (stride spw)
+            d.spw = 1;
+            d.dla[XH] = OFF<int2>(take(sizeof(int2) * (size_t) (d.capa + 1)));
+            if (d.kind == 2) d.dlb[XH] = OFF<int2>(take(sizeof(int2) * (size_t) (d.capb + 1)));
         }
         if (d.v2_ok) {
             const size_t recsz = (16 + 4 * (size_t) (d.capa + (d.kind == 2 ? d.capb : 0)) + 15) & ~(size_t) 15;

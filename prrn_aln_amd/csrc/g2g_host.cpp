@@ -110,90 +110,85 @@ void exg_seq(g2g_group &g, int gl, int gr)
     }
 }
 
-// mSeq::mkthick, src/mseq.cc:149-354 (quick mode / DiThk is off this path)
+// ---- column thickness -----------------------------------------------------------------------------------------
+// What the reference leaves in mSeq's SeqThk table (mSeq::mkthick, src/mseq.cc:149-354, without the quick-mode DiThk
+// part): per table row {cfq, dfq, efq} = weight of the members holding a residue, a gap, and the weight that counts as
+// "present" for an unpaired column of the other group.  Three kinds of groups:
+//   * no gap and no terminal nil anywhere : one constant row;
+//   * terminal nils only                  : rows for the leading zone, one interior row, rows for the trailing zone;
+//   * internal gaps                       : one row per column.
+// Members inside their leading / trailing run of nil codes count with the terminal-gap factor of that end.  Bit-exact
+// sums fix the ORDER of the additions: members ascending, except in the trailing zone, which the reference scans from
+// the last member down.
+struct ColumnTally { double nil, gap, res; int n_nil; };
+
 void mkthick(g2g_group &g)
 {
     if (g.thk_done) return;
     g.thk_done = true;
     const int many = g.many, len = g.len;
-    const bool vwt1 = g.has_weight && many > 1;              // weight && unit_mode(), inex.prof == 0
-    if (vwt1 && g.sumwt == 0) { for (int i = 0; i < many; ++i) g.sumwt += g.weight[i]; }
-    else if (g.sumwt == 0) g.sumwt = many;
-    const double sumwt = g.sumwt;
-    double wt1 = 1;
-    const double ltgapf = g.exgl ? 0 : g.tgapf, rtgapf = g.exgr ? 0 : g.tgapf;
+    const bool own_weights = g.has_weight && many > 1;
+    auto weight_of = [&](int i) { return own_weights ? g.weight[i] : 1.0; };
+    if (g.sumwt == 0) {
+        if (own_weights) for (int i = 0; i < many; ++i) g.sumwt += g.weight[i];
+        else g.sumwt = many;
+    }
+    const double total = g.sumwt;
+    const double lead_f = g.exgl ? 0 : g.tgapf, trail_f = g.exgr ? 0 : g.tgapf;
     g.has_internalres = g.dels || g.nils;
     if (g.has_internalres) g.internal_pos.assign(many, 0);
-    const int thk_len = g.thk_len = g.dels ? len : (g.has_internalres ? 2 : 0);
-    g.thk.assign((size_t) (thk_len + 2) * 3, 0.);
-    if (thk_len == 0) {
-        double *t = g.T(-1); t[0] = sumwt; t[1] = 0; t[2] = sumwt;
-        t = g.T(0); t[0] = sumwt; t[1] = 0; t[2] = sumwt;
-        return;
-    }
-    { double *t = g.T(-1); t[0] = 0; t[1] = t[2] = sumwt * ltgapf; }
-    { double *t = g.T(thk_len); t[0] = t[2] = 0; t[1] = sumwt * rtgapf; }
-    std::vector<char> egap(many);
-    int fpos = 0, rk = 0;
-    if (ltgapf < 1.) {                                        // right-most left end gap
-        std::fill(egap.begin(), egap.end(), 1);
-        while (fpos < len) {
-            double w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-            int c = 0;
-            for (int i = 0; i < many; ++i) {
-                if (vwt1) wt1 = g.weight[i];
-                const uint8_t ch = g.at(fpos, i);
-                if (ch == NIL_CODE) { w0 += wt1; ++c; }
-                else {
-                    if (egap[i]) { egap[i] = 0; g.internal_pos[i] = fpos; w3 += wt1; }
-                    if (ch == GAP_CODE) w1 += wt1; else w2 += wt1;
-                }
+    const int rows = g.thk_len = g.dels ? len : (g.has_internalres ? 2 : 0);
+    g.thk.assign((size_t) (rows + 2) * 3, 0.);
+    auto put = [&](int row, double cfq, double dfq, double efq) { double *t = g.T(row); t[0] = cfq; t[1] = dfq; t[2] = efq; };
+    if (rows == 0) { put(-1, total, 0, total); put(0, total, 0, total); return; }
+    put(-1, 0, total * lead_f, total * lead_f);              // before the first column: everybody is a leading end gap
+    put(rows, 0, total * trail_f, 0);                         // behind the last column
+    // tally of one column, members in the given order
+    auto tally = [&](int col, bool descending, auto &&on_member) {
+        ColumnTally c = {0, 0, 0, 0};
+        for (int k = 0; k < many; ++k) {
+            const int i = descending ? many - 1 - k : k;
+            const double w = weight_of(i);
+            const uint8_t code = g.at(col, i);
+            if (code == NIL_CODE) { c.nil += w; ++c.n_nil; }
+            else {
+                on_member(i, w);
+                if (code == GAP_CODE) c.gap += w; else c.res += w;
             }
-            double *t = g.T(rk);
-            t[0] = w2; t[1] = w1 + w0 * ltgapf; t[2] = w1 + w2 + w0 * ltgapf;
-            ++rk; ++fpos;
-            (void) w3;
-            if (c == 0) break;
         }
-    } else if (g.has_internalres) {
-        for (int i = 0; i < many; ++i) g.internal_pos[i] = 0;
-        double *t = g.T(rk); t[0] = sumwt; t[1] = 0; t[2] = sumwt;
-    }
-    const int lk = rk;
-    int rpos = len;
-    if (rtgapf < 1.) {                                        // left-most right end gap
-        std::fill(egap.begin(), egap.end(), 1);
-        int rk2 = thk_len;
-        while (rpos > 0) {
-            double w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0;
-            int c = 0;
-            for (int i = many; --i >= 0; ) {
-                if (vwt1) wt1 = g.weight[i];
-                const uint8_t ch = g.at(rpos - 1, i);
-                if (ch == NIL_CODE) { w0 += wt1; ++c; }
-                else {
-                    if (egap[i]) { w3 += wt1; egap[i] = 0; } else w4 += wt1;
-                    if (ch == GAP_CODE) w1 += wt1; else w2 += wt1;
-                }
-            }
-            --rk2;
-            if (rk2 >= -1) { double *t = g.T(rk2); t[0] = w2; t[1] = w1 + w0 * rtgapf; t[2] = w4 + (w0 + w3) * rtgapf; }
-            --rpos;
-            if (c == 0) break;
+        return c;
+    };
+    // leading zone: columns up to and including the first one without a nil; remembers where each member's body starts
+    int col = 0, row = 0;
+    if (lead_f < 1.) {
+        std::vector<char> waiting(many, 1);
+        for (bool more = true; more && col < len; ++col, ++row) {
+            const ColumnTally c = tally(col, false, [&](int i, double) { if (waiting[i]) { waiting[i] = 0; g.internal_pos[i] = col; } });
+            put(row, c.res, c.gap + c.nil * lead_f, c.gap + c.res + c.nil * lead_f);
+            more = c.n_nil != 0;
+        }
+    } else put(row, total, 0, total);                         // (has_internalres holds here: every body starts at column 0)
+    const int body_row = row;
+    // trailing zone, from the last column backwards to the first one without a nil.  efq: members seen for the first time
+    // (coming from the right) count like the nils, the others fully.
+    int end_col = len;
+    if (trail_f < 1.) {
+        std::vector<char> waiting(many, 1);
+        int r = rows;
+        for (bool more = true; more && end_col > 0; --end_col) {
+            double fresh = 0, seen = 0;
+            const ColumnTally c = tally(end_col - 1, true, [&](int i, double w) { if (waiting[i]) { waiting[i] = 0; fresh += w; } else seen += w; });
+            if (--r >= -1) put(r, c.res, c.gap + c.nil * trail_f, seen + (c.nil + fresh) * trail_f);
+            more = c.n_nil != 0;
         }
     }
-    if (g.dels) {
-        rk = lk;
-        while (fpos < rpos) {
-            double w1 = 0, w2 = 0;
-            for (int i = 0; i < many; ++i) {
-                if (vwt1) wt1 = g.weight[i];
-                if (g.at(fpos, i) == GAP_CODE) w1 += wt1; else w2 += wt1;
-            }
-            double *t = g.T(rk); t[0] = w2; t[1] = w1; t[2] = sumwt;
-            ++rk; ++fpos;
+    // interior columns of a group with internal gaps: gap weight against the rest
+    if (g.dels)
+        for (row = body_row; col < end_col; ++col, ++row) {
+            double gap = 0, rest = 0;
+            for (int i = 0; i < many; ++i) { if (g.at(col, i) == GAP_CODE) gap += weight_of(i); else rest += weight_of(i); }
+            put(row, rest, gap, total);
         }
-    }
 }
 
 // SeqThk per position as mSeqItr yields it (src/mseq.h:222-250, src/mseq.cc:768-790)
@@ -212,142 +207,136 @@ void flatten_thk(g2g_group &g)
     }
 }
 
-// ---- static gap profiles: Gfq::Gfq(mSeq*) + seq2gfq, src/gfreq.cc:86-114,134-228,247-312 -----------
-int ipack(Gfreq *gf, Gfreq a, int endg)
-{
-    Gfreq tmp;
-    Gfreq *kf = gf, *nf = gf;
-    do {
-        tmp = *kf++;
-        if (endg || a.nres) *nf++ = a;
-        a = tmp;
-    } while (neogfq(tmp));
-    *nf = delmgfq;
-    return (int) (nf - gf);
-}
-void accume(Gfreq *gf, Gfreq *kf)
-{
-    double s = 0;
-    while (--kf >= gf) kf->freq = s += kf->freq;
-}
+// ---- static gap profiles ---------------------------------------------------------------------------------------
+// The three per-column views the reference's Gfq holds (Gfq::Gfq(mSeq*) and seq2gfq, src/gfreq.cc:134-312), built here from
+// an explicit model instead of its three scratch arrays:
+//
+//   a GAP CLASS is the set of members whose current gap run opened at the same column, so all of them have the same
+//   running length; classes are kept youngest first (= ascending length).  Per column a class has two faces:
+//     t : weight still inside the run   (opening sum of weight x gap density, minus what members took out when they left)
+//     s : weight of the members whose run ENDS at this column (they hold a residue here)
+//   Besides the classes a column has: `opening` (t entry of length 0: runs that start here), `plain` (s entry of length 0:
+//   residues that follow a residue), `tail` (s entry behind all classes: residues that follow a leading nil run of zero
+//   density) and `post` (head of the r view: residue weight x density of the gap that may follow).
+//   Views of a column:  s = [plain] + classes.s + [tail], in suffix-sum form;  t = [opening] + classes.t;
+//                       r = [post] + t with every length + 1.
+//   Entries nobody belongs to are dropped -- except in t when a trailing nil run starts at this column, which keeps them.
+//
+// What is part of the contract because sums are floating point: additions happen in member order; a class's t weight is
+// the running value (added at the opening column, SUBTRACTED member by member later), never recomputed from its members.
+// Two reference behaviours that are kept on purpose: the tail entry's length is the run length of the FIRST member that
+// opens it, and a member of that kind arriving after a member that left a class is booked on THAT class's s face (the
+// reference reuses one cursor for both, src/gfreq.cc:190-207).
+struct GapEntry { int len; double w; int n; };
+struct GapClass { int len; double t_w; int t_n; double s_w; int s_n; };
 
 struct GfqBuilder {
     g2g_group &g;
-    int grain;
-    std::vector<Gfreq> buf;
-    Gfreq *sbuf, *tbuf, *rbuf;
-    std::vector<int> lbuf;
-    explicit GfqBuilder(g2g_group &gg) : g(gg), grain(1) {}
+    std::vector<GapClass> classes;       // youngest (shortest) first
+    std::vector<int> run;                // per member: length of the gap / nil run it is in (0: none)
+    std::vector<GapEntry> view[3];       // the column's packed views
+    int t_count;                         // entries of the previous column's t view (hetero is its maximum)
+    explicit GfqBuilder(g2g_group &gg) : g(gg), t_count(1) {}
 
-    int seq2gfq(int kk, int pos)
+    void column(int pos)
     {
-        Gfreq a = zerogfq, b = delmgfq;
-        Gfreq *cf = sbuf, *df = tbuf, *rf = rbuf;
-        double w = 1;
-        int endg = 0;
-        while (neogfq(*df)) {
-            df->glen += grain;
-            cf->glen = (df++)->glen;
-            cf->nres = 0;
-            (cf++)->freq = 0;
-        }
-        *cf = *df;
-        *rf = zerogfq;
+        // (a t view that kept only an unborn `opening` entry -- see below -- starts with length -1: whatever stands behind it
+        //  is dead for every reader, the reference's included, and falls away at the next packing)
+        size_t live = 0;
+        while (live < classes.size() && classes[live].len >= 0) ++live;
+        for (size_t k = 0; k < live; ++k) { classes[k].len += 1; classes[k].s_w = 0; classes[k].s_n = 0; }
+        GapEntry opening = {-1, 0, 0}, plain = {0, 0, 0}, tail = {-1, 0, 0}, post = {0, 0, 0};
+        int cursor = -1;                  // -1: the tail entry; k >= 0: class k (see the note above)
+        int trailing_starts = 0;
         for (int i = 0; i < g.many; ++i) {
-            int &ln = lbuf[i];
-            if (g.has_weight) w = g.weight[i];
-            const double bu = gapdensity(g, pos - 1, i);
-            const double cu = gapdensity(g, pos, i);
-            const double ru = postgapdensity(g, pos, i);
-            const uint8_t ch = g.at(pos, i);
-            if (cu > 0) {
-                if (ln == 0) { b.glen = 0; b.freq += w * cu; ++b.nres; }      // *-
-                ln += grain;                                                    // ?-
-            } else if (ch == NIL_CODE) {
-                if (ln == 0) ++endg;                                            // *.
-                ln += grain;                                                    // ..
-            } else if (g.at(pos - 1, i) == NIL_CODE && bu == 0) {               // .*
-                if (!neogfq(*cf)) {
-                    cf[1] = *cf;
-                    cf->freq = 0; cf->nres = 0;
-                    cf->glen = ln;
-                }
-                cf->freq += w; ++cf->nres;
-                if (ru > 0) { rf->freq += w * ru; ++rf->nres; }
-                ln = 0;
-            } else {
-                if (ru > 0) { rf->freq += w * ru; ++rf->nres; }                 // ?*
-                if (ln) {                                                       // -*
-                    Gfreq *hit = 0;                                             // bsearch over tbuf[0..kk) by glen
-                    int lo = 0, hi = kk - 1;
-                    while (lo <= hi) {
-                        int mid = (lo + hi) / 2;
-                        int d = ln - tbuf[mid].glen;
-                        if (d == 0) { hit = tbuf + mid; break; }
-                        if (d < 0) hi = mid - 1; else lo = mid + 1;
-                    }
-                    if (hit) {
-                        hit->freq -= bu * w; --hit->nres;
-                        cf = sbuf + (hit - tbuf);
-                        cf->freq += w; ++cf->nres;
-                    }
-                } else { a.freq += w; ++a.nres; }                               // **
-                ln = 0;
+            const double w = g.has_weight ? g.weight[i] : 1;
+            const double dens_prev = gapdensity(g, pos - 1, i), dens_here = gapdensity(g, pos, i), dens_next = postgapdensity(g, pos, i);
+            const uint8_t code = g.at(pos, i);
+            int &len_i = run[i];
+            if (dens_here > 0) {                                   // inside a gap that counts
+                if (len_i == 0) { opening.len = 0; opening.w += w * dens_here; ++opening.n; }
+                len_i += 1;
+                continue;
             }
+            if (code == NIL_CODE) {                                // terminal nil of zero density
+                if (len_i == 0) ++trailing_starts;
+                len_i += 1;
+                continue;
+            }
+            // a residue
+            const bool after_free_nil = g.at(pos - 1, i) == NIL_CODE && dens_prev == 0;
+            if (!after_free_nil && dens_next > 0) { post.w += w * dens_next; ++post.n; }
+            if (after_free_nil) {
+                if (cursor < 0) {
+                    if (tail.len < 0) { tail.len = len_i; tail.w = 0; tail.n = 0; }
+                    tail.w += w; ++tail.n;
+                } else { classes[cursor].s_w += w; ++classes[cursor].s_n; }
+                if (dens_next > 0) { post.w += w * dens_next; ++post.n; }
+            } else if (len_i) {                                    // leaves the class of its length, if there is one
+                int k = -1;
+                for (int c = 0; c < (int) classes.size() && c < t_count; ++c) if (classes[c].len == len_i) { k = c; break; }
+                if (k >= 0) {
+                    classes[k].t_w -= dens_prev * w; --classes[k].t_n;
+                    classes[k].s_w += w; ++classes[k].s_n;
+                    cursor = k;
+                }
+            } else { plain.w += w; ++plain.n; }
+            len_i = 0;
         }
-        kk = ipack(sbuf, a, 0);
-        accume(sbuf, sbuf + kk);
-        kk = ipack(tbuf, b, endg);
-        if (rf->nres == 0) --rf;
-        for (df = tbuf; neogfq(*df); ++df) {
-            *++rf = *df;
-            rf->glen += grain;
+        // s view: members present, suffix sums from the far end
+        view[0].clear();
+        if (plain.n) view[0].push_back(plain);
+        for (size_t k = 0; k < live; ++k) if (classes[k].s_n) view[0].push_back(GapEntry{classes[k].len, classes[k].s_w, classes[k].s_n});
+        if (tail.len >= 0 && tail.n) view[0].push_back(tail);
+        { double acc = 0; for (size_t k = view[0].size(); k-- > 0; ) view[0][k].w = acc += view[0][k].w; }
+        // t view and the classes that live on
+        view[1].clear();
+        std::vector<GapClass> next;
+        if (trailing_starts || opening.n) {
+            view[1].push_back(opening);
+            next.push_back(GapClass{opening.len, opening.w, opening.n, 0, 0});
         }
-        *++rf = *df;
-        return kk;
+        for (size_t k = 0; k < live; ++k) {
+            const GapClass &c = classes[k];
+            if (trailing_starts || c.t_n) { view[1].push_back(GapEntry{c.len, c.t_w, c.t_n}); next.push_back(c); }
+        }
+        classes.swap(next);
+        t_count = (int) view[1].size();
+        // r view
+        view[2].clear();
+        if (post.n) view[2].push_back(post);
+        for (const GapEntry &e : view[1]) { if (e.len < 0) break; view[2].push_back(GapEntry{e.len + 1, e.w, e.n}); }
     }
 
-    static void emit(GapProfile *gp, int v, const Gfreq *l)
+    static void emit(GapProfile *gp, int v, const std::vector<GapEntry> &l)
     {
         gp->off[v].push_back((int32_t) gp->glen[v].size());
-        for ( ; ; ++l) {
-            gp->glen[v].push_back(l->glen);
-            gp->freq[v].push_back(l->freq);
-            if (!neogfq(*l)) break;
-        }
+        for (const GapEntry &e : l) { if (e.len < 0) break; gp->glen[v].push_back(e.len); gp->freq[v].push_back(e.w); }
+        gp->glen[v].push_back(-1); gp->freq[v].push_back(0);           // the terminator is part of the pool
     }
 
     GapProfile *build()
     {
         // only groups with inex.dels get a gap profile (mSeq::convseq, src/mseq.cc:507)
         GapProfile *gp = new GapProfile();
-        const double ltgapf = g.exgl ? 0 : g.tgapf;
-        int kk = g.many + 2;
-        buf.assign((size_t) 3 * kk + 3, delmgfq);
-        sbuf = buf.data(); tbuf = sbuf + kk; rbuf = tbuf + kk;
-        lbuf.assign(g.many, 0);
-        int htr = 0;
-        // position -1 (gfreq.cc:264-282)
-        emit(gp, 0, &delmgfq);
-        if (ltgapf > 0) {
-            Gfreq lead[2] = {{0, g.sumwt * ltgapf, g.many}, delmgfq};
-            sbuf[0] = rbuf[0] = lead[0];
-            emit(gp, 1, lead);
-            emit(gp, 2, lead);
-        } else {
-            emit(gp, 1, &delmgfq);
-            emit(gp, 2, &delmgfq);
-        }
-        kk = 1;
+        run.assign(g.many, 0);
+        classes.clear();
+        // position -1 (src/gfreq.cc:264-282): everybody is a leading end gap of weight sumwt x terminal-gap factor
+        const double lead_f = g.exgl ? 0 : g.tgapf;
+        const std::vector<GapEntry> none;
+        emit(gp, 0, none);
+        if (lead_f > 0) {
+            const std::vector<GapEntry> lead(1, GapEntry{0, g.sumwt * lead_f, g.many});
+            emit(gp, 1, lead); emit(gp, 2, lead);
+        } else { emit(gp, 1, none); emit(gp, 2, none); }
+        int most = 0;
         for (int pos = 0; pos < g.len; ++pos) {
-            kk = seq2gfq(kk, pos);
-            if (kk > htr) htr = kk;
-            emit(gp, 0, sbuf);
-            emit(gp, 1, tbuf);
-            emit(gp, 2, rbuf);
+            column(pos);
+            most = std::max(most, t_count);
+            for (int v = 0; v < 3; ++v) emit(gp, v, view[v]);
         }
         for (int v = 0; v < 3; ++v) gp->off[v].push_back((int32_t) gp->glen[v].size());
-        gp->hetero = htr + 1;
+        gp->hetero = most + 1;
         return gp;
     }
 };
@@ -675,44 +664,46 @@ extern "C" int g2g_spscore_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *p, const 
 }
 extern "C" const g2g_problem *g2g_pwdm_problem(const g2g_pwdm *p) { return p ? &p->prob : 0; }
 
-// <-> stdskl(SKL**), reference src/gaps.cc:139-174: order the raw traceback by (m, n), drop repeats and
-// inconsistent steps, and make every diagonal/gap junction explicit.  Output: ascending corners
-// (the reference's skl[1..n]; its skl[0] header and EOS sentinel are left to the caller's wrapper).
+// <-> stdskl(SKL**), reference src/gaps.cc:139-174: turn the raw traceback records into the skeleton -- corners in
+// ascending order, every change between a diagonal run and a gap made explicit.  Output: the reference's skl[1..n]
+// (its skl[0] header and EOS sentinel are left to the caller's wrapper).
+// Own formulation in two passes: (1) order the records by (m, n) -- a total order, so any sort gives the reference's
+// sequence -- and keep the monotone chain (repeats and records that step back in n are passed over); (2) walk the chain
+// segment by segment.  A segment is a pure diagonal, a pure gap, or a diagonal followed by a gap; its start point is a
+// corner when the heading changes there (a run of horizontal gaps keeps every start point: the reference tests `!dm`),
+// and a mixed segment adds the point where its diagonal part ends.
 extern "C" g2g_skl *g2g_stdskl(const g2g_skl *in, int num, int *nout)
 {
     if (!nout || num < 0 || (num && !in)) return NULL;
-    if (num < 2) {
-        g2g_skl *one = (g2g_skl *) malloc(sizeof(g2g_skl) * (num > 0 ? num : 1));
-        if (num) one[0] = in[0];
-        *nout = num;
-        return one;
+    std::vector<g2g_skl> chain(in, in + num);
+    if (num >= 2) {
+        std::sort(chain.begin(), chain.end(), [](const g2g_skl &x, const g2g_skl &y) { return x.m != y.m ? x.m < y.m : x.n < y.n; });
+        size_t kept = 1;
+        for (int i = 1; i < num; ++i) {
+            const g2g_skl &last = chain[kept - 1], &p = chain[i];
+            if (p.m < last.m || p.n < last.n || (p.m == last.m && p.n == last.n)) continue;
+            chain[kept++] = p;
+        }
+        chain.resize(kept);
     }
-    g2g_skl *org = (g2g_skl *) malloc(sizeof(g2g_skl) * num);
-    memcpy(org, in, sizeof(g2g_skl) * num);
-    // scmpf (gaps.cc:116-121) is a total order on (m, n): any sort gives the reference's sequence
-    std::sort(org, org + num, [](const g2g_skl &x, const g2g_skl &y) { return x.m != y.m ? x.m < y.m : x.n < y.n; });
-    g2g_skl *std_ = (g2g_skl *) malloc(sizeof(g2g_skl) * (2 * (size_t) num + 1));
-    int w = 0, pr = 2;
-    const g2g_skl *prv = org;
-    for (int i = 1; i < num; ++i) {
-        const g2g_skl *cur = org + i;
-        const int dm = cur->m - prv->m, dn = cur->n - prv->n;
-        if (!dm && !dn) continue;                 // no increment
-        if (dm < 0 || dn < 0) continue;           // inconsistent
-        const int dd = std::min(dm, dn);
-        int df = dn - dm;
-        if (df) df = df > 0 ? 1 : -1;
-        if (dd && df) {                           // diagonal run followed by a gap: interpolate the junction
-            if (pr) std_[w++] = *prv;
-            std_[w].m = prv->m + dd; std_[w].n = prv->n + dd; ++w;
-        } else if (df != pr || !dm) std_[w++] = *prv;
-        pr = df;
-        prv = cur;
+    g2g_skl *out = (g2g_skl *) malloc(sizeof(g2g_skl) * (2 * chain.size() + 1));
+    int w = 0;
+    enum { NONE = 2 };                            // heading of a segment: -1 more rows than columns, 0 diagonal, +1 more columns
+    int heading = NONE;
+    for (size_t k = 0; k + 1 < chain.size(); ++k) {
+        const g2g_skl from = chain[k], to = chain[k + 1];
+        const int rows = to.m - from.m, cols = to.n - from.n;
+        const int diag = std::min(rows, cols);
+        const int turn = cols > rows ? 1 : cols < rows ? -1 : 0;
+        if (diag && turn) {                       // diagonal run, then a gap
+            if (heading != 0) out[w++] = from;    // (coming out of a diagonal the start point is not a corner)
+            out[w].m = from.m + diag; out[w].n = from.n + diag; ++w;
+        } else if (turn != heading || rows == 0) out[w++] = from;
+        heading = turn;
     }
-    std_[w++] = *prv;
-    free(org);
+    if (!chain.empty()) out[w++] = chain.back();
     *nout = w;
-    return std_;
+    return out;
 }
 
 // <-> align2(), src/maln2.cc:1875-1973 for the Fwd2c modes: forward + traceback on the GPU, stdskl,

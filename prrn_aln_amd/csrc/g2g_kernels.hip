@@ -1043,7 +1043,7 @@ __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *
     bgep.q = agep.qp + P.a.many; bgep.qp = bgep.q + (size_t) P.b.many * P.codonk1;
     double lunp = 0;
     DList dla, dlb;
-    dla.p = P.dla[XH]; dla.s = P.width; dlb.p = P.dlb[XH]; dlb.s = P.width;
+    dla.p = P.dla[XH]; dla.s = P.spw; dlb.p = P.dlb[XH]; dlb.s = P.spw;
     if (KIND == 1 || KIND == 2) cleardelta(dla);
     if (KIND == 2) cleardelta(dlb);
     int m = skl[0].x, n = skl[0].y, glb = 0;
