@@ -1,0 +1,104 @@
+// ref_trace.cc -- test infrastructure: a TRACE of the reference's own refinement loop (Prrn::rir, reference
+// src/prrn5.cc:633-666), taken from outside by `ld --wrap` on four functions the loop calls in other translation units.
+// Nothing of the reference is edited or copied; oracle/Makefile.ref links the reference's unmodified prrn5.cc with this
+// file into oracle/_ref/prrn5_trace.  The trace (text, one record per line, file named by $G2G_TRACE) is what
+// tools/make_refine_golden.py turns into tests/golden/refine_*.json:
+//   T tid left right parent vol cur        one line per node of the Kirchhoff tree the loop divides on (Ktree::lead[])
+//   C cycle nn                             Randiv::cycle, number of members
+//   D rnbr                                 every branch Randiv::nextrandiv() hands out, in order
+//   A na nb swp scr val | members of a | members of b     every align2() of the loop: groups by member NAME, result
+//   S n0 n1 | lst0 | lst1 | skeleton       every accepted move (synthgap()): member lists and the skeleton applied
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "aln.h"
+#include "mseq.h"
+#include "maln.h"
+#include "gaps.h"
+#include "mgaps.h"
+#include "phyl.h"
+#include "consreg.h"
+#include "randiv.h"
+#include "fspscore.h"
+
+namespace {
+FILE* trace_fd()
+{
+	static FILE*	fd = 0;
+	static bool	tried = false;
+	if (!tried) {
+	    tried = true;
+	    const char*	fn = getenv("G2G_TRACE");
+	    if (fn) fd = fopen(fn, "w");
+	}
+	return fd;
+}
+}
+
+extern "C" {
+void __real__ZN6RandivC1EP3SeqP5Ssrel7DivModei(Randiv*, Seq*, Ssrel*, DivMode, int);
+void __wrap__ZN6RandivC1EP3SeqP5Ssrel7DivModei(Randiv* self, Seq* sd, Ssrel* srl, DivMode dm, int rn)
+{
+	__real__ZN6RandivC1EP3SeqP5Ssrel7DivModei(self, sd, srl, dm, rn);
+	FILE*	fd = trace_fd();
+	if (!fd) return;
+	const int	nn = srl->ss? srl->ss->num: sd->many;
+	fprintf(fd, "C %ld %d\n", (long) self->cycle, nn);
+	if (srl->ktree && srl->ktree->lead) {
+	    Knode*	lead = srl->ktree->lead;
+	    for (int k = 0; k < 2 * nn - 1; ++k) {
+		Knode&	nd = lead[k];
+		fprintf(fd, "T %d %d %d %d %.17g %.17g\n", nd.tid, nd.left? nd.left->tid: -1, nd.right? nd.right->tid: -1,
+		    nd.parent? nd.parent->tid: -1, (double) nd.vol, (double) nd.cur);
+	    }
+	}
+	fflush(fd);
+}
+
+LRAND __real__ZN6Randiv10nextrandivEv(Randiv*);
+LRAND __wrap__ZN6Randiv10nextrandivEv(Randiv* self)
+{
+	LRAND	r = __real__ZN6Randiv10nextrandivEv(self);
+	FILE*	fd = trace_fd();
+	if (fd && self->mcr) fprintf(fd, "D %ld\n", (long) self->mcr->mcrand_now());
+	return r;
+}
+
+SKL* __real__Z6align2PP4mSeqP4PwdMPdP6Gsinfo(mSeq* seqs[], PwdM* pwdm, VTYPE* scr, Gsinfo* GsI);
+SKL* __wrap__Z6align2PP4mSeqP4PwdMPdP6Gsinfo(mSeq* seqs[], PwdM* pwdm, VTYPE* scr, Gsinfo* GsI)
+{
+	SKL*	skl = __real__Z6align2PP4mSeqP4PwdMPdP6Gsinfo(seqs, pwdm, scr, GsI);
+	FILE*	fd = trace_fd();
+	if (fd && GsI) {
+	    fprintf(fd, "A %d %d %d %.17g %.17g |", seqs[0]->many, seqs[1]->many, pwdm->swp? 1: 0, (double) *scr, (double) GsI->fstat.val);
+	    for (int k = 0; k < 2; ++k) {
+		for (int i = 0; i < seqs[k]->many; ++i) fprintf(fd, " %s", (*seqs[k]->sname)[i]);
+		fprintf(fd, " |");
+	    }
+	    if (seqs[0]->weight) for (int i = 0; i < seqs[0]->many; ++i) fprintf(fd, " %.17g", (double) seqs[0]->weight[i]);
+	    fprintf(fd, " |");
+	    if (seqs[1]->weight) for (int i = 0; i < seqs[1]->many; ++i) fprintf(fd, " %.17g", (double) seqs[1]->weight[i]);
+	    fprintf(fd, "\n");
+	}
+	return skl;
+}
+
+bool __real__Z8synthgapPP8GapsListP3SKLPPi(GapsList* glists[], SKL* skl, int* lst[]);
+bool __wrap__Z8synthgapPP8GapsListP3SKLPPi(GapsList* glists[], SKL* skl, int* lst[])
+{
+	FILE*	fd = trace_fd();
+	if (fd && skl) {
+	    int	n0 = 0, n1 = 0;
+	    while (lst[0][n0] >= 0) ++n0;
+	    while (lst[1][n1] >= 0) ++n1;
+	    fprintf(fd, "S %d %d |", n0, n1);
+	    for (int i = 0; i < n0; ++i) fprintf(fd, " %d", lst[0][i]);
+	    fprintf(fd, " |");
+	    for (int i = 0; i < n1; ++i) fprintf(fd, " %d", lst[1][i]);
+	    fprintf(fd, " |");
+	    for (int i = 1; i <= skl->n; ++i) fprintf(fd, " %d %d", skl[i].m, skl[i].n);
+	    fprintf(fd, "\n");
+	}
+	return __real__Z8synthgapPP8GapsListP3SKLPPi(glists, skl, lst);
+}
+}

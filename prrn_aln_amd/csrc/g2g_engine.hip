@@ -186,6 +186,7 @@ struct g2g_batch {
     std::vector<int> flags0;        // initial contents of d_flags (re-uploaded when the 11-bit generation of the progress counters wraps)
     long long ntiles;
     float fwd_ms, tb_ms;
+    double *simscr[20]; size_t simscr_cap[20];   // per sweep-mode launch: strip-local column-score blocks (3 x 32 KB per workgroup)
 };
 
 // LDS footprint of g2g_forward_kernel_v2 for one problem (see V2Geom): (slots * R + extras) records
@@ -413,6 +414,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     };
     g2g_batch *b = new g2g_batch();
     b->ctx = ctx; b->n = n; b->d_arena = 0; b->d_probs = 0; b->fwd_ms = b->tb_ms = 0;
+    for (int k = 0; k < 20; ++k) { b->simscr[k] = 0; b->simscr_cap[k] = 0; }
     b->v3_cols = 128; b->v2_cols = G2G_V2_TILE_COLS;
 
     b->dp.resize(n); b->status.assign(n, G2G_OK); b->cells.assign(n, 0); b->out_off.assign(n, 0); b->tcap.assign(n, 0); b->rr1.assign(n, 0);
@@ -566,7 +568,9 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
             d.v2_cbF = OFF<void>(take(recsz * ((size_t) (ar - al) + 3)));
             if (d.noll == 3) d.v2_cbF2 = OFF<void>(take(recsz * ((size_t) (ar - al) + 3)));
             d.v2_rowoff = OFF<long long>(take(sizeof(long long) * ((size_t) (ar - al) + 2)));
-            d.v2_sim = OFF<double>(take(sizeof(double) * (size_t) cells + 64));
+            // the column-score matrix: only for DPs whose kernel reads one (strips in sweep mode make their own, block by block)
+            const bool own_sim = !getenv("G2G_NO_SIMBLK") && (d.v2_ok == 6 || (d.v2_ok == 1 && b->v2_sweep) || ((d.v2_ok == 2 || d.v2_ok == 3) && d.kind == 1 && b->v3_sweep));
+            if (!own_sim) d.v2_sim = OFF<double>(take(sizeof(double) * (size_t) cells + 64));
         }
         b->rr1[i] = (long long) (bl_ - al) + (br - ar);
         d.tcap = (ar - al) + (br - bl_) + 4;
@@ -783,9 +787,9 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[3], 0));
         if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[g2g] prologue+sim done: %s\n", hipGetErrorString(e3)); fflush(stderr); }
         // persistent tile / strip kernels: one launch per kernel variant, each on its own stream (they are independent)
-        typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int, int, int, int);
+        typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int, int, int, int, double *);
         static const v2k_t v2k[4] = {g2g_v2_hf2, g2g_v2_hf3, g2g_v2_pf2, g2g_v2_pf3};
-        typedef void (*v3k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V3Lds, int, int, int);
+        typedef void (*v3k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V3Lds, int, int, int, double *);
         static const v3k_t v3k[8] = {g2g_v3_hf2, g2g_v3_hf3, g2g_v3_pf2, g2g_v3_pf3, g2g_v3r_hf2, g2g_v3r_hf3, g2g_v3r_pf2, g2g_v3r_pf3};
         // one persistent launch per variant, each on its own stream (they are independent of each other)
         ++b->gen;
@@ -797,6 +801,16 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         HIPCHK(hipEventRecord(ctx->vev[4], ctx->stream));
         int ncu = 256;
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) ncu = pr.multiProcessorCount; }
+        auto sim_scratch = [&](int slot, int grid) -> double * {
+            const size_t need = (size_t) grid * 3 * 4096 * sizeof(double);
+            if (b->simscr_cap[slot] < need) {
+                if (b->simscr[slot]) hipFree(b->simscr[slot]);
+                b->simscr[slot] = 0; b->simscr_cap[slot] = 0;
+                if (hipMalloc((void **) &b->simscr[slot], need) != hipSuccess) { (void) hipGetLastError(); return (double *) 0; }
+                b->simscr_cap[slot] = need;
+            }
+            return b->simscr[slot];
+        };
         for (int v = 0; v < 4; ++v) {
             const int cnt = b->var_off[v + 1] - b->var_off[v];
             if (!cnt) continue;
@@ -811,10 +825,15 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             const int res2 = ncu * std::max(1, std::min(wpc2, (int) (V2_LDS_MAX / (b->lds2 + 4 * (size_t) T2))));
             const int pint2 = !b->v2_sweep ? 0 : b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= res2 ? 4 : cnt < 4 * res2 ? 16 : 32;
             if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] variant %d: %d tiles, grid %d x %d threads, lds %zu, cols %d, gen %d\n", v, cnt, grid, T2, b->lds2, b->v2_cols, b->gen); fflush(stderr); }
+            double *simscr2 = 0;
+            if (b->v2_sweep && !getenv("G2G_NO_SIMBLK")) {
+                simscr2 = sim_scratch(v, grid);
+                if (!simscr2) { g2g_set_error("%s", "hipMalloc(column-score scratch)"); return G2G_ERR_NOMEM; }
+            }
             hipLaunchKernelGGL(v2k[v], dim3(grid), dim3(T2), b->lds2 + 4 * T2, ctx->vstream[v],
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v]), cnt,
                                b->d_flags + v, b->d_flags, b->gen, (int) b->lds2, b->v2_sweep ? (1 << 20) : b->v2_cols, pint2,
-                               (pro_off && pro_off + PRO_LDS_BYTES <= b->lds2) ? pro_off : 0);
+                               (pro_off && pro_off + PRO_LDS_BYTES <= b->lds2) ? pro_off : 0, simscr2);
             HIPCHK(hipGetLastError());
             if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->vstream[v]); fprintf(stderr, "[g2g] variant %d done: %s\n", v, hipGetErrorString(e3)); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[v], ctx->vstream[v]));
@@ -834,11 +853,16 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             if (const char *e = getenv("G2G_V3_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc = w; }
             const int grid = std::min(cnt, ncu * wpc);
             if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v3 variant %d: %d tiles, grid %d, lds %d (rows %d, apool@%d, bpool@%d), cols %d, gen %d\n", v, cnt, grid, LO.total, LO.black, LO.aglen, LO.bglen, b->v3_cols, b->gen); fflush(stderr); }
+            double *simscr3 = 0;
+            if (swpv && b->v3_sweep && !getenv("G2G_NO_SIMBLK")) {
+                simscr3 = sim_scratch(4 + v, grid);
+                if (!simscr3) { g2g_set_error("%s", "hipMalloc(column-score scratch)"); return G2G_ERR_NOMEM; }
+            }
             hipLaunchKernelGGL(v3k[v], dim3(grid), dim3(64), (size_t) LO.total, vs,
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v + 4]), cnt,
                                b->d_flags + 4 + v, b->d_flags, b->gen, LO, (swpv && b->v3_sweep) ? (1 << 20) : b->v3_cols,
                                !(swpv && b->v3_sweep) ? 0 : b->v3_sweep >= 2 ? b->v3_sweep : 4 * cnt <= ncu * std::min(wpc, 8) ? 4 : cnt < 4 * ncu * std::min(wpc, 8) ? 16 : 32,
-                               (pro_off && pro_off + (int) PRO_LDS_BYTES <= LO.svals) ? pro_off : 0);
+                               (pro_off && pro_off + (int) PRO_LDS_BYTES <= LO.svals) ? pro_off : 0, simscr3);
             HIPCHK(hipGetLastError());
             if (getenv("G2G_DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v3 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[v & 3], vs));
@@ -848,7 +872,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             const int v = 3 - vi;                    // (large-footprint launches first: they hold the longest DPs)
             const int cnt = b->var_off[v + 13] - b->var_off[v + 12];
             if (!cnt) continue;
-            typedef void (*v6k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V6Lds, int, int);
+            typedef void (*v6k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V6Lds, int, int, double *);
             static const v6k_t v6k[4] = {g2g_v6_pf2, g2g_v6_pf3, g2g_v6_pf2, g2g_v6_pf3};
             hipStream_t vs = ctx->vstream[v < 2 ? 2 + v : 2 + v];        // small: streams 2, 3; large footprint: 4, 5
             const int jev = v < 2 ? 2 + v : 3 + v;
@@ -861,10 +885,12 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             const int grid = std::min(cnt, ncu * wpc);
             const int pint = b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= ncu * wpc ? 4 : cnt < 4 * ncu * wpc ? 16 : 32;   // publish interval (power of 2)
             if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v6 variant %d: %d strips, grid %d, lds %d (ring %d entries), publish every %d, gen %d\n", v, cnt, grid, LO.total, LO.rs, pint, b->gen); fflush(stderr); }
+            double *simscr6 = sim_scratch(12 + v, grid);
+            if (!simscr6) { g2g_set_error("%s", "hipMalloc(column-score scratch)"); return G2G_ERR_NOMEM; }
             hipLaunchKernelGGL(v6k[v], dim3(grid), dim3(64), (size_t) LO.total, vs,
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v + 12]), cnt,
                                b->d_flags + 12 + v, b->d_flags, b->gen, LO, pint,
-                               (pro_off && pro_off + (int) PRO_LDS_BYTES <= LO.svals) ? pro_off : 0);
+                               (pro_off && pro_off + (int) PRO_LDS_BYTES <= LO.svals) ? pro_off : 0, simscr6);
             HIPCHK(hipGetLastError());
             if (getenv("G2G_DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v6 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[jev], vs));
@@ -946,6 +972,7 @@ extern "C" void g2g_batch_free(g2g_batch *b)
     release_arena(b);
     if (b->d_tiles) hipFree(b->d_tiles);
     if (b->d_flags) hipFree(b->d_flags);
+    for (int k = 0; k < 20; ++k) if (b->simscr[k]) hipFree(b->simscr[k]);
     delete b;
 }
 
@@ -1035,7 +1062,10 @@ static size_t problem_bytes(const g2g_problem *p)
         if (c > 0) cells += c;
         if (c > tmax) tmax = c;
     }
-    size_t bytes = (size_t) (ar - al + br - bl + 2) * tmax + 8 * (size_t) cells;          // trace + column scores
+    // trace (1 B per cell) + the column-score matrix (8 B per cell) where a kernel reads one: strips in sweep mode (the
+    // default of every tiled kernel) make their own scores
+    const bool matrix = getenv("G2G_NO_SIMBLK") || getenv("G2G_V2_SWEEP") || getenv("G2G_V3_SWEEP") || getenv("G2G_V3_PF");   // (tile-mode test configurations)
+    size_t bytes = (size_t) (ar - al + br - bl + 2) * tmax + (matrix ? 8 * (size_t) cells : 0);
     const g2g_side *sd[2] = {&p->a, &p->b};
     for (int k = 0; k < 2; ++k) {
         const size_t cols = (size_t) sd[k]->len + 2;

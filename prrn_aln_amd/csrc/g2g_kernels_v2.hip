@@ -724,6 +724,38 @@ __device__ __forceinline__ void uni_prob(DevProb &d, const DevProb &s)
     d.score = uni(s.score);
 }
 
+// ---- strip-local column scores (sweep mode) ----------------------------------------------------------------------
+// PwdM::sim2 of a cell does not depend on the recurrence.  Tile mode reads it from a matrix a separate kernel fills ahead
+// of the sweep (8 B per cell of HBM, written once and read once).  A strip in sweep mode makes its own instead, block by
+// block: every 64 steps it computes the (rows of the strip) x 64 columns its first row enters 64 steps later -- thread <->
+// column, rows in a loop, so a row's profile vector is a wave-uniform read and the stores are coalesced -- into one of
+// THREE 32 KB buffers of a per-workgroup scratch area (the rows of a skewed strip straddle two blocks while the third is
+// filled).  The scratch area is reused by every strip the workgroup runs: ~100 MB per launch, cache resident, instead of
+// 8 B per cell of the sweep.
+#define GLBV3 __attribute__((address_space(1)))
+struct SimBlk { GLBV3 double *buf; int cbase; };
+// (tid / nthr / rows: the filling threads -- one wave for the one-lane-per-cell kernels, the workgroup for v2 -- and the
+// rows of a strip; thread <-> column tid & 63, rows tid >> 6, tid >> 6 + nthr / 64, ...)
+__device__ __forceinline__ void simblk_fill(const DevProb &P, const SimBlk &S, const int bk, const int m0, const int tid,
+                                            const int nthr = 64, const int rows = 64)
+{
+    const int n = S.cbase + bk * 64 + (tid & 63);
+    if (bk < 0 || n >= P.b.right) return;
+    GLBV3 double *dst = S.buf + (size_t) (bk % 3) * 4096 + (tid & 63);
+    for (int r = tid >> 6; r < rows; r += nthr >> 6) {
+        const int m = m0 + r;
+        if (m >= P.a.right) break;
+        int nlo = m + P.lw; if (nlo < P.b.left) nlo = P.b.left;
+        int nhi = m + P.up + 1; if (nhi > P.b.right) nhi = P.b.right;
+        if (n >= nlo && n < nhi) dst[r * 64] = sim2(P, m, n);
+    }
+}
+__device__ __forceinline__ const GLBV3 double *simblk_at(const SimBlk &S, const int row, const int n)
+{
+    const int k = n - S.cbase;
+    return S.buf + (size_t) ((k >> 6) % 3) * 4096 + row * 64 + (k & 63);
+}
+
 // ---- one TILE = (strip of R rows) x (block of C columns) by one workgroup ------------
 // Tiles of a DP depend on their upper, left and upper-left neighbours only, so all tiles with the same
 // i + j (over every DP of the batch) run in one launch; a big DP is spread over many workgroups instead
@@ -737,7 +769,7 @@ __device__ __forceinline__ void uni_prob(DevProb &d, const DevProb &s)
 template <int KIND, bool NOLL3>
 __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nsteps, const int C,
                         const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0, const int pint = 32,
-                        const int *prog_left = 0)
+                        const int *prog_left = 0, double *simscr = 0)
 {
     // SWEEP MODE (prog_self != 0), as in g2g_kernels_v3.hip: the tile is a whole strip; the strip above publishes every
     // 32 steps up to which corner column its last row's records are in HBM, this strip waits only before its first
@@ -835,7 +867,10 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
     const double a_efq = row_ok ? thk_at(a, m)[2] : 0;
     int nf0 = m + P.lw; if (nf0 < b.left) nf0 = b.left;
     const double pua_row = row_ok ? unpa(P, m, nf0) : 0;                 // fwd2c.h:380 (402 when a.inex.nils)
-    const double *simrow = row_ok ? P.v2_sim + P.v2_rowoff[m - a.left] - nlo : 0;
+    const bool own_sim = prog_self != 0 && simscr != 0;    // sweep mode: the strip makes its column scores block by block (SimBlk)
+    const double *simrow = (row_ok && !own_sim) ? P.v2_sim + P.v2_rowoff[m - a.left] - nlo : 0;
+    SimBlk SB; SB.buf = (GLBV3 double *) simscr; SB.cbase = cbase;
+    if (own_sim) { simblk_fill(P, SB, 0, m0, tid, blockDim.x, R); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     double sim_cur = 0, bc_cur = 0;
     bool have = false;
     int rslot = (RC - team % RC) % RC;                     // ring slot of column cbase + s - team
@@ -880,10 +915,14 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         const bool active = row_ok && n >= lo && n < hi;
         if (prog_self && s > 0 && (s & (pint - 1)) == 0) publish(cbase + s - tl);
         need(cbase + s + 2);
+        if (own_sim && (s & 63) == 0) {                    // the block the first row enters 64 steps from now; visible to the
+            simblk_fill(P, SB, (s >> 6) + 1, m0, tid, blockDim.x, R);      // whole workgroup long before (a barrier every step)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         double sim_nx = 0, bc_nx = 0;
         if (active) {
-            if (!have) { sim_cur = simrow[n]; bc_cur = thk_at(b, n)[0]; }
-            if (n + 1 < hi) { sim_nx = simrow[n + 1]; bc_nx = thk_at(b, n + 1)[0]; }
+            if (!have) { sim_cur = own_sim ? (double) *simblk_at(SB, team, n) : simrow[n]; bc_cur = thk_at(b, n)[0]; }
+            if (n + 1 < hi) { sim_nx = own_sim ? (double) *simblk_at(SB, team, n + 1) : simrow[n + 1]; bc_nx = thk_at(b, n + 1)[0]; }
         }
         // prefetch the column the first row reaches next step into the ring (3 teams, one view each): the
         // loads are issued here, the LDS stores wait until the cell work of this step is done
@@ -1116,6 +1155,7 @@ extern "C" __global__ void __launch_bounds__(256)
 g2g_v2_sim_kernel(const DevProb *probs, const int *idx, int tiled)
 {
     const DevProb &P = probs[idx[blockIdx.y]];
+    if (!P.v2_sim) return;                                   // (strips in sweep mode make their own scores: SimBlk, g2g_kernels_v3.hip)
     if (tiled && sim_tiled_kind(P.sim2_kind)) return;        // done by g2g_v2_sim_tile_kernel
     const int m = P.a.left + blockIdx.x;
     if (m >= P.a.right) return;
@@ -1162,7 +1202,7 @@ g2g_v2_sim_tile_kernel(const DevProb *probs, const int *idx)
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];
     const DevProb &P = probs[idx[blockIdx.z]];
     const int kind = P.sim2_kind;
-    if (!sim_tiled_kind(kind)) return;                      // (those run in g2g_v2_sim_kernel)
+    if (!P.v2_sim || !sim_tiled_kind(kind)) return;         // (no matrix wanted / those run in g2g_v2_sim_kernel)
     const DevSide &a = P.a, &b = P.b;
     const int m0 = a.left + blockIdx.y * SIM_TR, c0 = b.left + blockIdx.x * SIM_TC;
     if (m0 >= a.right || c0 >= b.right) return;
@@ -1239,7 +1279,7 @@ __device__ unsigned long long g2g_wait_acc[4];
 // each thread adds (tid == 0) to the queue head, parks its result in LDS, and slot 0 is the tile.
 #define V2_KERNEL(NAME, KIND, N3)                                                                   \
 extern "C" __global__ void __launch_bounds__(G2G_V2_THREADS, G2G_V2_MINWAVES)                         \
-NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, int lds_tile_off, int C, int sweep, int pro_off) \
+NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, int lds_tile_off, int C, int sweep, int pro_off, double *simscr) \
 {                                                                                                   \
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];                                  \
     li32 *s_vals = (li32 *) ((lchar *) g2g_lds + lds_tile_off);   /* tail of the dynamic LDS */      \
@@ -1270,7 +1310,8 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         }                                                                                           \
         __syncthreads();                                                                            \
         V2_WAIT_T1                                                                                  \
-        v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen, sweep, pl); \
+        v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen, sweep, pl, \
+                          (sweep && simscr) ? simscr + (size_t) blockIdx.x * (3 * 4096) : (double *) 0); \
         V2_WAIT_T2                                                                                  \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \

@@ -598,7 +598,7 @@ __device__ __forceinline__ void v3_rec_store(unsigned *dst, int capa, int capb, 
 template <int KIND, bool NOLL3, int NA>
 __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V3Lds LO, const int ti, const int tj, const int nsteps, const int C,
                         const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0, const int pint = 32,
-                        const int *prog_left = 0)
+                        const int *prog_left = 0, double *simscr = 0)
 {
     // SWEEP MODE (prog_self != 0): the tile is a whole strip (C covers the row range) and the dependency on the strip
     // above is a progress counter instead of tile-completion flags: the strip above publishes, every pint (16/32) steps, up to
@@ -789,7 +789,10 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
     // per-row constants and one-step-ahead register pipelines (column score, b's column thickness)
     const double a_efq = row_ok ? thk_at(a, m)[2] : 0;
     const double pua_row = row_ok ? unpa(P, m, nlo) : 0;                 // fwd2c.h:380 (402 when a.inex.nils)
-    const double *simrow = row_ok ? P.v2_sim + P.v2_rowoff[m - a.left] - nlo : 0;
+    const bool own_sim = prog_self != 0 && simscr != 0;    // sweep mode: the strip makes its column scores block by block
+    const double *simrow = (row_ok && !own_sim) ? P.v2_sim + P.v2_rowoff[m - a.left] - nlo : 0;
+    SimBlk SB; SB.buf = (GLBV3 double *) simscr; SB.cbase = cbase;
+    if (own_sim) { simblk_fill(P, SB, 0, m0, lane); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     double sim_cur = 0, bc_cur = 0;
     bool have = false;
     RS hu = rs_black(), gu = rs_black(), g2u = rs_black(), hd;
@@ -837,6 +840,7 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
         if (p_act) P.trace[p_tri] = (uint8_t) p_trb;
         if (wr_rows && s > 0) flush_rows(n0 - 1 - llast);
         if (prog_self && s > 0 && (s & (pint - 1)) == 0) publish(n0 - llast);
+        if (own_sim && (s & 63) == 0) { simblk_fill(P, SB, (s >> 6) + 1, m0, lane); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         // -- hand-over from the row above: what lane t-1 produced one step ago is my upper neighbour, what it
         // produced two steps ago (= my previous upper neighbour) is my diagonal neighbour
         hd = hu;
@@ -861,8 +865,8 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
         // -- loads for the next step: next column's score/thickness; the strip above's records two columns ahead
         double sim_nx = 0, bc_nx = 0;
         if (active) {
-            if (!have) { sim_cur = simrow[n]; bc_cur = thk_at(b, n)[0]; }
-            if (n + 1 < hi) { sim_nx = simrow[n + 1]; bc_nx = thk_at(b, n + 1)[0]; }
+            if (!have) { sim_cur = own_sim ? (double) *simblk_at(SB, lane, n) : simrow[n]; bc_cur = thk_at(b, n)[0]; }
+            if (n + 1 < hi) { sim_nx = own_sim ? (double) *simblk_at(SB, lane, n + 1) : simrow[n + 1]; bc_nx = thk_at(b, n + 1)[0]; }
         }
         st_prev = n0 + 1 < hi0 && n0 + 2 <= c1;
         if (st_prev) { need(n0 + 2); stage_load(n0 + 2, vert0, st_h, st_g, st_g2); }
@@ -931,7 +935,7 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
 
 #define V3_KERNEL(NAME, KIND, N3, NA, WPE)                                                           \
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))      \
-NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V3Lds LO, int C, int sweep, int pro_off) \
+NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V3Lds LO, int C, int sweep, int pro_off, double *simscr) \
 {                                                                                                   \
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];                                  \
     li32 *s_vals = (li32 *) ((lchar *) g2g_lds + LO.svals);                                         \
@@ -961,7 +965,8 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
         }                                                                                           \
         __syncthreads();                                                                            \
-        v3_tile<KIND, N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen, sweep, pl); \
+        v3_tile<KIND, N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen, sweep, pl, \
+                              (sweep && simscr) ? simscr + (size_t) blockIdx.x * (3 * 4096) : (double *) 0); \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
         if (!sweep) {                                                                               \

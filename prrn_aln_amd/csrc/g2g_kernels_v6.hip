@@ -373,7 +373,8 @@ __device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, cons
 // ---- one STRIP (64 rows x all columns) by one wave, pipelined behind the strip above on progress counters -----------
 template <bool NOLL3, int NA>
 __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const V6Lds LO, const int ti, const int nsteps,
-                                         const int *prog_up, int *prog_self, int *dbg, const int pgen, const int pint, const int *prog_left)
+                                         const int *prog_up, int *prog_self, int *dbg, const int pgen, const int pint, const int *prog_left,
+                                         double *simscr)
 {
     DevProb P;
     uni_prob(P, Pmem);
@@ -551,7 +552,9 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
     // per-row constants and one-step-ahead register pipelines (column score, b's column thickness, list offsets)
     const double a_efq = row_ok ? thk_at(a, m)[2] : 0;
     const double pua_row = row_ok ? unpa(P, m, nlo) : 0;                 // fwd2c.h:380 (402 when a.inex.nils)
-    const GLB double *simrow = row_ok ? glb(P.v2_sim) + P.v2_rowoff[m - a.left] - nlo : 0;
+    SimBlk SB; SB.buf = (GLBV3 double *) simscr; SB.cbase = cbase;      // strip-local column scores (g2g_kernels_v3.hip)
+    simblk_fill(P, SB, 0, m0, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     double sim_cur = 0, bc_cur = 0;
     int os_cur = 0, oe_cur = 0, ot_cur = 0, or_cur = 0;
     bool have = false;
@@ -602,6 +605,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
         if (wr_rows && s > 0) flush_rows(n0 - 1 - llast);
         if (prog_self && s > 0 && (s & (pint - 1)) == 0) publish(n0 - llast);
         if ((s & (V6_FEED - 1)) == 0) { refill(n0 + V6_AHEAD); team_sync(); }
+        if ((s & 63) == 0) { simblk_fill(P, SB, (s >> 6) + 1, m0, lane); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         // -- hand-over from the row above
         hd = hu;
         hu = rs_up(oH); gu = rs_up(oG);
@@ -627,11 +631,11 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
         int os_nx = 0, oe_nx = 0, ot_nx = 0, or_nx = 0;
         if (active) {
             if (!have) {
-                sim_cur = simrow[n]; bc_cur = bthk[(size_t) (n + 1) * 3];
+                sim_cur = *simblk_at(SB, lane, n); bc_cur = bthk[(size_t) (n + 1) * 3];
                 os_cur = boff0[n + 1]; oe_cur = boff0[n + 2]; ot_cur = boff1[n + 1]; or_cur = boff2[n + 1];
             }
             if (n + 1 < hi) {
-                sim_nx = simrow[n + 1]; bc_nx = bthk[(size_t) (n + 2) * 3];
+                sim_nx = *simblk_at(SB, lane, n + 1); bc_nx = bthk[(size_t) (n + 2) * 3];
                 os_nx = oe_cur; oe_nx = boff0[n + 3]; ot_nx = boff1[n + 2]; or_nx = boff2[n + 2];
             }
         }
@@ -698,7 +702,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
 
 #define V6_KERNEL(NAME, N3, NA, WPE)                                                                 \
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))      \
-NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V6Lds LO, int pint, int pro_off) \
+NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V6Lds LO, int pint, int pro_off, double *simscr) \
 {                                                                                                   \
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];                                  \
     li32 *s_vals = (li32 *) ((lchar *) g2g_lds + LO.svals);                                         \
@@ -717,7 +721,8 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         const int *pl = T.dep_left >= 0 ? done + T.dep_left : (const int *) 0;                      \
         const int *pu = T.dep_up >= 0 ? done + T.dep_up : (const int *) 0;                          \
         __syncthreads();                                                                            \
-        v6_strip<N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, T.nsteps, pu, done + T.self, done + 16, gen, pint, pl); \
+        v6_strip<N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, T.nsteps, pu, done + T.self, done + 16, gen, pint, pl, \
+                         simscr + (size_t) blockIdx.x * (3 * 4096)); \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
     }                                                                                               \

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/refine_*.json: traces of the REFERENCE's own refinement loop (Prrn::rir, reference
+src/prrn5.cc:633-666) on seeded synthetic families, taken by oracle/_ref/prrn5_trace (the reference's unmodified prrn5.cc
+linked with oracle/ref_trace.cc: `ld --wrap` on Randiv's constructor / nextrandiv, align2 and synthgap).  Each fixture is
+data only: the start MSA, the weighting tree the reference built (topology, Kirchhoff vol / cur per node), the branch
+sequence, (DP score, fstat.val) of every align2() call, every accepted move (member lists + skeleton) and the final MSA.
+Run in THIS container (needs /root/reference); the GPU box only sees the committed JSON files."""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF = os.path.join(ROOT, "oracle", "_ref")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+CASES = [
+    ("prot12x80_s3", dict(n_seq=12, length=80, seed=3, indel=0.03, max_indel=6), False, []),
+    ("prot20x100_s11", dict(n_seq=20, length=100, seed=11, indel=0.03, max_indel=8), False, []),
+    ("dna16x120_s8_ls3", dict(n_seq=16, length=120, seed=8, indel=0.03, max_indel=8), True, ["-yl3"]),
+]
+
+
+def parse_msa(text):
+    rows = {}
+    order = []
+    for line in text.splitlines():
+        m = re.match(r"^\s*\d+ (.{60})\| (\S+)\s*$", line)
+        if m:
+            if m.group(2) not in rows:
+                rows[m.group(2)] = ""
+                order.append(m.group(2))
+            rows[m.group(2)] += m.group(1)
+    return [rows[k].rstrip() for k in order], order
+
+
+def main():
+    import refdump
+    from prrn_aln_amd.synth import DNA, make_family
+    env = dict(os.environ, ALN_TAB=os.path.join(REF, "table"))
+    for name, kw, dna, extra in CASES:
+        if dna:
+            kw = dict(kw, alphabet=DNA)
+        fam = make_family(**kw)
+        names = ["s%02d" % i for i in range(len(fam.msa))]
+        with tempfile.TemporaryDirectory() as tmp:
+            refdump.write_multi(os.path.join(tmp, "fam.msa"), names, list(fam.msa), "fam")
+            tr = os.path.join(tmp, "trace.txt")
+            opts = ["-YH0", "-R1"] + extra
+            subprocess.run([os.path.join(REF, "prrn5_trace")] + opts + ["-O4", "fam.msa"], cwd=tmp, env=dict(env, G2G_TRACE=tr),
+                           check=True, capture_output=True)
+            out = subprocess.run([os.path.join(REF, "prrn5")] + opts + ["fam.msa"], cwd=tmp, env=env, check=True,
+                                 capture_output=True, text=True).stdout
+            L = [l.rstrip("\n") for l in open(tr)]
+        final, order = parse_msa(out)
+        assert order == names and len({len(r) for r in final}) <= 2, (order[:3], [len(r) for r in final][:5])
+        width = max(len(r) for r in final)
+        final = [r.ljust(width, "-").replace(" ", "-") for r in final]
+        T = [l.split() for l in L if l.startswith("T ")]
+        fix = {
+            "name": name, "molc": 2 if dna else 1, "ls": 3 if "-yl3" in extra else 1, "options": opts,
+            "rows": list(fam.msa),
+            "tree": {"left": [int(t[2]) for t in T], "right": [int(t[3]) for t in T], "parent": [int(t[4]) for t in T],
+                     "vol": [float(t[5]) for t in T], "cur": [float(t[6]) for t in T]},
+            "cycle": int([l for l in L if l.startswith("C ")][0].split()[1]),
+            "branches": [int(l.split()[1]) for l in L if l.startswith("D ")],
+            "align2": [], "accepted": [], "final_rows": final,
+        }
+        assert [int(t[1]) for t in T] == list(range(len(T)))
+        for l in L:
+            if l.startswith("A "):
+                h = l.split("|")[0].split()
+                fix["align2"].append({"na": int(h[1]), "nb": int(h[2]), "swp": int(h[3]), "scr": float(h[4]), "val": float(h[5])})
+            elif l.startswith("S "):
+                p = l.split("|")
+                sk = [int(x) for x in p[3].split()]
+                fix["accepted"].append({"lst0": [int(x) for x in p[1].split()], "lst1": [int(x) for x in p[2].split()],
+                                        "skl": [sk[i:i + 2] for i in range(0, len(sk), 2)]})
+        json.dump(fix, open(os.path.join(GOLD, "refine_%s.json" % name), "w"))
+        print("%-22s members %d, cycle %d, %d divisions drawn, %d align2 calls, %d accepted, %d -> %d columns" % (
+            name, len(names), fix["cycle"], len(fix["branches"]), len(fix["align2"]), len(fix["accepted"]), len(fam.msa[0]), width))
+
+
+if __name__ == "__main__":
+    main()
