@@ -215,7 +215,7 @@ def main():
         fst = batch.spscore(sps, [skl for (_, skl, _) in out])
         sp_ms = 1e3 * (time.perf_counter() - t1)
         sp_bad = sum(1 for (_, _, st) in fst if st != 0)
-        gpu_sp = {int(k): float(v) for k, (v, _, st) in zip(mine, fst) if st == 0}
+        gpu_sp = {int(k): float(v) for k, (v, _, st) in zip(mine, [x[:3] for x in fst]) if st == 0}
     except Exception as e:                                   # never let the extra row break the benchmark line
         sp_ms, sp_bad = None, str(e)
         gpu_sp = None

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define G2G_ABI_VERSION 1
+#define G2G_ABI_VERSION 2
 
 /* error codes (negative) */
 enum {
@@ -211,7 +211,12 @@ typedef struct {
     double diff_u;       /* PwdM::diff_u = scale * (u - u1) (src/maln2.cc:233): weight of the long-gap count `lunp` in
                             PwdM::wgop (maln.h:321-325); only read when Noll = 3                                */
 } g2g_spparams;
-typedef struct { double val, gap; int32_t status; int32_t reserved; } g2g_fstat;
+typedef struct {
+    double  val, gap;    /* FSTAT::val / gap after PwdM::rescale: per unit pair weight (what align2 leaves in Gsinfo.fstat)      */
+    int32_t status, reserved;
+    double  raw;         /* the score BEFORE rescale = the return value of PreSpScore::calcSpScore(SKL*), src/fspscore.cc:544-582:
+                            Prrn::onecycle takes THIS for the current alignment and fstat.val for the new one (src/prrn5.cc:523,535) */
+} g2g_fstat;
 /* level 0: on a prepared batch (inputs resident in HBM); skl[i] = the standardised skeleton of problem i
  * (g2g_stdskl output: corners ascending, first = (a.left, b.left), last = (a.right, b.right))              */
 int        g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl,

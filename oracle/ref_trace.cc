@@ -6,7 +6,8 @@
 //   T tid left right parent vol cur        one line per node of the Kirchhoff tree the loop divides on (Ktree::lead[])
 //   C cycle nn                             Randiv::cycle, number of members
 //   D rnbr                                 every branch Randiv::nextrandiv() hands out, in order
-//   A na nb swp scr val | members of a | members of b     every align2() of the loop: groups by member NAME, result
+//   A na nb swp scr val gap Vab sumwt_a sumwt_b | names of a | names of b | weights of a | weights of b    every align2() of the loop
+//   O val | skeleton                       every PreSpScore::calcSpScore(SKL*) of the loop: the CURRENT alignment of a division
 //   S n0 n1 | lst0 | lst1 | skeleton       every accepted move (synthgap()): member lists and the skeleton applied
 #include <stdio.h>
 #include <stdlib.h>
@@ -70,7 +71,8 @@ SKL* __wrap__Z6align2PP4mSeqP4PwdMPdP6Gsinfo(mSeq* seqs[], PwdM* pwdm, VTYPE* sc
 	SKL*	skl = __real__Z6align2PP4mSeqP4PwdMPdP6Gsinfo(seqs, pwdm, scr, GsI);
 	FILE*	fd = trace_fd();
 	if (fd && GsI) {
-	    fprintf(fd, "A %d %d %d %.17g %.17g |", seqs[0]->many, seqs[1]->many, pwdm->swp? 1: 0, (double) *scr, (double) GsI->fstat.val);
+	    fprintf(fd, "A %d %d %d %.17g %.17g %.17g %.17g %.17g %.17g |", seqs[0]->many, seqs[1]->many, pwdm->swp? 1: 0, (double) *scr, (double) GsI->fstat.val,
+		(double) GsI->fstat.gap, (double) pwdm->Vab, (double) seqs[0]->sumwt, (double) seqs[1]->sumwt);
 	    for (int k = 0; k < 2; ++k) {
 		for (int i = 0; i < seqs[k]->many; ++i) fprintf(fd, " %s", (*seqs[k]->sname)[i]);
 		fprintf(fd, " |");
@@ -78,9 +80,30 @@ SKL* __wrap__Z6align2PP4mSeqP4PwdMPdP6Gsinfo(mSeq* seqs[], PwdM* pwdm, VTYPE* sc
 	    if (seqs[0]->weight) for (int i = 0; i < seqs[0]->many; ++i) fprintf(fd, " %.17g", (double) seqs[0]->weight[i]);
 	    fprintf(fd, " |");
 	    if (seqs[1]->weight) for (int i = 0; i < seqs[1]->many; ++i) fprintf(fd, " %.17g", (double) seqs[1]->weight[i]);
+	    if (getenv("G2G_TRACE_GROUPS")) {			// debugging aid: the groups themselves
+		for (int k = 0; k < 2; ++k) {
+		    mSeq*	sd = seqs[k];
+		    fprintf(fd, " | len %d left %d right %d exgl %d exgr %d nils %d dels %d ambs %d vect %d :", sd->len, sd->left, sd->right,
+			(int) sd->inex.exgl, (int) sd->inex.exgr, (int) sd->inex.nils, (int) sd->inex.dels, (int) sd->inex.ambs, (int) sd->inex.vect);
+		    for (int p = -1; p <= sd->len; ++p) { fputc(' ', fd); for (int i = 0; i < sd->many; ++i) fprintf(fd, "%x", (int) sd->at(p)[i]); }
+		}
+	    }
 	    fprintf(fd, "\n");
 	}
 	return skl;
+}
+
+VTYPE __real__ZN10PreSpScore11calcSpScoreEP3SKL(PreSpScore* self, SKL* wsk);
+VTYPE __wrap__ZN10PreSpScore11calcSpScoreEP3SKL(PreSpScore* self, SKL* wsk)
+{
+	const VTYPE	v = __real__ZN10PreSpScore11calcSpScoreEP3SKL(self, wsk);
+	FILE*	fd = trace_fd();
+	if (fd && wsk) {
+	    fprintf(fd, "O %.17g |", (double) v);
+	    for (int i = 1; i <= wsk->n; ++i) fprintf(fd, " %d %d", wsk[i].m, wsk[i].n);
+	    fprintf(fd, "\n");
+	}
+	return v;
 }
 
 bool __real__Z8synthgapPP8GapsListP3SKLPPi(GapsList* glists[], SKL* skl, int* lst[]);

@@ -126,4 +126,4 @@ class SpParams(C.Structure):
 
 
 class Fstat(C.Structure):
-    _fields_ = [("val", C.c_double), ("gap", C.c_double), ("status", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("val", C.c_double), ("gap", C.c_double), ("status", C.c_int32), ("reserved", C.c_int32), ("raw", C.c_double)]

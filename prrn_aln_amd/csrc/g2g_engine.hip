@@ -1001,7 +1001,7 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
     for (int i = 0; i < n; ++i) { off[i] = (int) tot; cnt[i] = (skl[i] && nskl[i] > 0) ? nskl[i] : 0; tot += cnt[i]; }
     std::vector<g2g_skl> all(tot ? tot : 1);
     for (int i = 0; i < n; ++i) if (cnt[i]) memcpy(&all[off[i]], skl[i], sizeof(g2g_skl) * cnt[i]);
-    const size_t b_skl = sizeof(g2g_skl) * all.size(), b_int = sizeof(int) * n, b_sp = sizeof(g2g_spparams) * n, b_out = sizeof(double) * 2 * n;
+    const size_t b_skl = sizeof(g2g_skl) * all.size(), b_int = sizeof(int) * n, b_sp = sizeof(g2g_spparams) * n, b_out = sizeof(double) * 3 * n;
     char *d = 0;
     const size_t o_skl = 0, o_off = (b_skl + 15) & ~(size_t) 15, o_cnt = o_off + ((b_int + 15) & ~(size_t) 15),
                  o_sp = o_cnt + ((b_int + 15) & ~(size_t) 15), o_out = o_sp + ((b_sp + 15) & ~(size_t) 15),
@@ -1034,7 +1034,7 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
                            gints ? (int *) (d + o_gws) : (int *) 0, (const long long *) (d + o_goff));
         e = hipGetLastError();
     }
-    std::vector<double> ho(2 * (size_t) n);
+    std::vector<double> ho(3 * (size_t) n);
     std::vector<int> hs(n);
     if (e == hipSuccess) e = hipMemcpyAsync(ho.data(), d + o_out, b_out, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(hs.data(), d + o_st, b_int, hipMemcpyDeviceToHost, ctx->stream);
@@ -1042,7 +1042,7 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
     hipFree(d);
     if (e != hipSuccess) { g2g_set_error("spscore: %s", hipGetErrorString(e)); return G2G_ERR_DEVICE; }
     for (int i = 0; i < n; ++i) {
-        out[i].val = ho[2 * i]; out[i].gap = ho[2 * i + 1]; out[i].reserved = 0;
+        out[i].val = ho[3 * i]; out[i].gap = ho[3 * i + 1]; out[i].raw = ho[3 * i + 2]; out[i].reserved = 0;
         out[i].status = b->status[i] ? b->status[i] : hs[i] == 0 ? G2G_OK : hs[i] == -2 ? G2G_ERR_MODE : G2G_ERR_ARG;
     }
     return G2G_OK;

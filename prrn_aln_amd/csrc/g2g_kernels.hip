@@ -1064,6 +1064,7 @@ __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *
     scr += tgap * (KIND == 1 ? P.weighted_gop : P.basic_gop) + sp.diff_u * lunp;    // wgop(tgap, lunp), maln.h:321-325
     out[0] = scr / sp.vab;                                                       // rescale
     out[1] = tgap / sp.vab;
+    out[2] = scr;
 }
 extern "C" __global__ void __launch_bounds__(64)
 g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const int2 *skl, const int *skl_off, const int *nskl,
@@ -1072,16 +1073,16 @@ g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const
     const int ip = blockIdx.x;
     if (ip >= nprob) return;                                   // (all 64 lanes walk the chain in lockstep, see GepDev)
     const DevProb &P = probs[ip];
-    out[2 * ip] = 0; out[2 * ip + 1] = 0;
+    out[3 * ip] = 0; out[3 * ip + 1] = 0; out[3 * ip + 2] = 0;
     if (P.kind < 0) { status[ip] = -1; return; }
     int *ws = (gepws && gep_off[ip] >= 0) ? gepws + gep_off[ip] : (int *) 0;
     if (((P.noll == 3 && P.kind >= 1) || P.kind == 3) && !ws) { status[ip] = -2; return; }
     if (P.kind == 3 && (!P.a.gapdens || !P.b.gapdens)) { status[ip] = -1; return; }
     if (nskl[ip] < 2) { status[ip] = -1; return; }
     const int2 *s = skl + skl_off[ip];
-    if (P.kind == 0) sp_calcskl<0>(P, sp[ip], s, nskl[ip], out + 2 * ip, ws);
-    else if (P.kind == 1) sp_calcskl<1>(P, sp[ip], s, nskl[ip], out + 2 * ip, ws);
-    else if (P.kind == 2) sp_calcskl<2>(P, sp[ip], s, nskl[ip], out + 2 * ip, ws);
-    else sp_calcskl<3>(P, sp[ip], s, nskl[ip], out + 2 * ip, ws);
+    if (P.kind == 0) sp_calcskl<0>(P, sp[ip], s, nskl[ip], out + 3 * ip, ws);
+    else if (P.kind == 1) sp_calcskl<1>(P, sp[ip], s, nskl[ip], out + 3 * ip, ws);
+    else if (P.kind == 2) sp_calcskl<2>(P, sp[ip], s, nskl[ip], out + 3 * ip, ws);
+    else sp_calcskl<3>(P, sp[ip], s, nskl[ip], out + 3 * ip, ws);
     status[ip] = 0;
 }

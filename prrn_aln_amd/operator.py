@@ -185,7 +185,7 @@ def spparams(pwd: PwdM) -> "_abi.SpParams":
 
 
 def calcSpScore_batch(ctx, pwds: Sequence[PwdM], skls):
-    """<-> PreSpScore::calcSpScore(GsI) (reference src/fspscore.cc:584): [(fstat.val, fstat.gap, status)] of the
+    """<-> PreSpScore::calcSpScore(GsI) (reference src/fspscore.cc:584): [(fstat.val, fstat.gap, status, raw score)] of the
     alignments the standardised skeletons describe."""
     L = lib()
     n = len(pwds)
@@ -195,4 +195,4 @@ def calcSpScore_batch(ctx, pwds: Sequence[PwdM], skls):
     rc = L.g2g_spscore_batch(ctx._h, n, hs, ptrs, cnt, out)
     if rc:
         raise G2GError("g2g_spscore_batch rc=%d: %s" % (rc, last_error()))
-    return [(out[i].val, out[i].gap, out[i].status) for i in range(n)]
+    return [(out[i].val, out[i].gap, out[i].status, out[i].raw) for i in range(n)]

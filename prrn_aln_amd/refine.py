@@ -267,8 +267,10 @@ class Refiner:
             if st != 0 or fs[i][2] != 0 or fs[k + i][2] != 0:
                 raise RuntimeError("division %d: status %d / %d / %d" % (d["branch"], st, fs[i][2], fs[k + i][2]))
             same = skl.shape == old[i].shape and np.array_equal(skl, old[i])
-            d["scr"], d["val_old"], d["val_new"] = scr, fs[i][0], fs[k + i][0]
-            d["delta"] = 0.0 if same else d["pwt"] * (fs[k + i][0] - fs[i][0])
+            # Prrn::onecycle (src/prrn5.cc:523,535): the NEW alignment enters with Gsinfo.fstat.val (rescaled by PwdM::Vab), the
+            # CURRENT one with the return value of calcSpScore(SKL*), which is not rescaled -- kept as the reference has it
+            d["scr"], d["val_old"], d["val_new"] = scr, fs[i][3], fs[k + i][0]
+            d["delta"] = 0.0 if same else d["pwt"] * (fs[k + i][0] - fs[i][3])
             d["skl1"] = skl[:, ::-1].copy() if d["pw"].swp else skl       # back to (larger group, smaller group)
         self.batches += 1
         return todo

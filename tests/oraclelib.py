@@ -67,6 +67,17 @@ def spscore(L, holder, sp: "_abi.SpParams", skl: np.ndarray):
     buf = (_abi.Skl * n)()
     for i in range(n):
         buf[i].m, buf[i].n = int(skl[i][0]), int(skl[i][1])
-    out = (C.c_double * 2)()
+    out = (C.c_double * 3)()
     rc = L.g2g_oracle_spscore(C.byref(holder.c), C.byref(sp), buf, n, out)
     return rc, out[0], out[1]
+
+
+def spscore_raw(L, holder, sp: "_abi.SpParams", skl: np.ndarray):
+    """the same, plus the score before PwdM::rescale (what PreSpScore::calcSpScore(SKL*) returns): (rc, val, gap, raw)"""
+    n = len(skl)
+    buf = (_abi.Skl * n)()
+    for i in range(n):
+        buf[i].m, buf[i].n = int(skl[i][0]), int(skl[i][1])
+    out = (C.c_double * 3)()
+    rc = L.g2g_oracle_spscore(C.byref(holder.c), C.byref(sp), buf, n, out)
+    return rc, out[0], out[1], out[2]

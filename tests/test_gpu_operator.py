@@ -62,7 +62,7 @@ def test_calcspscore_matches_reference_goldens(ctx):
     res = op.align2_batch(ctx, pws)
     fs = op.calcSpScore_batch(ctx, pws, [skl for (_, skl, _) in res])
     n_ok = 0
-    for name, d, (val, gap, st) in zip(names, want, fs):
+    for name, d, (val, gap, st, _raw) in zip(names, want, fs):
         # every mode of the path: plain / half / full profile units (Noll 2, and Noll 3 with the Gep1st long-gap
         # bookkeeping) and the naive units SPunit_nv / _w11 / _w22 of the NTV modes
         assert st == 0, name
@@ -78,7 +78,7 @@ def test_calcspscore_sweep_vs_oracle(ctx):
     res = op.align2_batch(ctx, sw.pwds)
     fs = op.calcSpScore_batch(ctx, sw.pwds, [skl for (_, skl, _) in res])
     L = oraclelib.load()
-    for pw, (scr, skl, st), (val, gap, fst) in zip(sw.pwds, res, fs):
+    for pw, (scr, skl, st), (val, gap, fst, _raw) in zip(sw.pwds, res, fs):
         class H:
             c = pw.problem
         rc, oval, ogap = oraclelib.spscore(L, H, op.spparams(pw), skl)
@@ -97,7 +97,7 @@ def test_calcspscore_noll3_sweep_vs_oracle(ctx):
         res = op.align2_batch(ctx, sw.pwds)
         fs = op.calcSpScore_batch(ctx, sw.pwds, [skl for (_, skl, _) in res])
         n = 0
-        for pw, (scr, skl, st), (val, gap, fst) in zip(sw.pwds, res, fs):
+        for pw, (scr, skl, st), (val, gap, fst, _raw) in zip(sw.pwds, res, fs):
             class H:
                 c = pw.problem
             rc, oval, ogap = oraclelib.spscore(L, H, op.spparams(pw), skl)
@@ -121,7 +121,7 @@ def test_calcspscore_tiny_families_vs_oracle(ctx):
                 sw = sweep.Sweep(fam, op.AlnParam(ls=ls), weighted=weighted)
                 res = op.align2_batch(ctx, sw.pwds)
                 fs = op.calcSpScore_batch(ctx, sw.pwds, [skl for (_, skl, _) in res])
-                for pw, (scr, skl, st), (val, gap, fst) in zip(sw.pwds, res, fs):
+                for pw, (scr, skl, st), (val, gap, fst, _raw) in zip(sw.pwds, res, fs):
                     class H:
                         c = pw.problem
                     rc, oval, ogap = oraclelib.spscore(L, H, op.spparams(pw), skl)
