@@ -225,20 +225,87 @@ class Step:
     skl: Optional[np.ndarray]
 
 
+def gpu_scorer(ctx):
+    """Scores a list of divisions on the GPU through the C ABI: g2g_align2_batch for the DPs, g2g_spscore_batch for the
+    sum-of-pairs scores of the current and the new alignment.  Returns [(DP score, new skeleton, raw score of the current
+    alignment, fstat.val of the new one)]."""
+    def score(divs):
+        pwds = [d["pw"] for d in divs]
+        res = op.align2_batch(ctx, pwds)
+        old = [d["old"] for d in divs]
+        new = [skl for (_, skl, _) in res]
+        fs = op.calcSpScore_batch(ctx, pwds + pwds, old + new)
+        k = len(divs)
+        out = []
+        for i, d in enumerate(divs):
+            scr, skl, st = res[i]
+            if st != 0 or fs[i][2] != 0 or fs[k + i][2] != 0:
+                raise RuntimeError("division %d: status %d / %d / %d" % (d["branch"], st, fs[i][2], fs[k + i][2]))
+            out.append((scr, skl, fs[i][3], fs[k + i][0]))
+        return out
+    return score
+
+
+class Exchange:
+    """The one exchange step of a sharded window: rank r scores divisions r, r + world, ... of the
+    size-ordered window, packs (DP score, the two sum-of-pairs scores, new skeleton) into fixed-size slots, and an
+    all-gather (RCCL when the tensors live on the GPU, gloo in the CPU tests) leaves every rank with every result --
+    every rank then takes the same accept / reject decisions and holds the same MSA, no broadcast needed."""
+
+    def __init__(self, cap: int = 4096):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.cap = cap
+
+    def share(self, order: Sequence[int]) -> List[int]:
+        return [int(k) for k in list(order)[self.rank::self.world]]
+
+    def gather(self, mine: Sequence[int], results, n_total: int, device=None):
+        import torch
+        nslots = (n_total + self.world - 1) // self.world
+        width = 9 + 2 * self.cap
+        buf = np.full((nslots, width), -1, np.int32)
+        for row, (k, (scr, skl, raw_old, val_new)) in enumerate(zip(mine, results)):
+            if len(skl) > self.cap:
+                raise RuntimeError("skeleton of %d corners exceeds the slot capacity %d" % (len(skl), self.cap))
+            buf[row, 0], buf[row, 1], buf[row, 2] = k, 0, len(skl)
+            buf[row, 3:9] = np.frombuffer(np.array([scr, raw_old, val_new], np.float64).tobytes(), np.int32)
+            buf[row, 9:9 + 2 * len(skl)] = np.asarray(skl, np.int32).reshape(-1)
+        t = torch.from_numpy(buf)
+        if device is not None:
+            t = t.to(device)
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        out = {}
+        for part in parts:
+            for row in part.cpu().numpy():
+                k = int(row[0])
+                if k < 0:
+                    continue
+                n = int(row[2])
+                scr, raw_old, val_new = np.frombuffer(row[3:9].astype(np.int32).tobytes(), np.float64)
+                out[k] = (float(scr), row[9:9 + 2 * n].reshape(n, 2).copy(), float(raw_old), float(val_new))
+        return [out[k] for k in range(n_total)]
+
+
 class Refiner:
-    """Prrn::rir over a matrix MSA, DPs batched `window` divisions at a time."""
+    """Prrn::rir over a matrix MSA, DPs batched `window` divisions at a time (and, with an Exchange, sharded over ranks).
+    `scorer`: callable(divisions) -> [(DP score, new skeleton, raw current score, new fstat.val)]; default: the GPU."""
 
     def __init__(self, ctx, codes: np.ndarray, tree: KTree, alp: op.AlnParam, seed: int = 1, maxitr: int = 10,
-                 window: int = 32):
-        self.ctx, self.codes, self.tree, self.alp = ctx, np.ascontiguousarray(codes, np.uint8), tree, alp
+                 window: int = 32, scorer=None, exchange: Optional[Exchange] = None, device=None):
+        self.codes, self.tree, self.alp = np.ascontiguousarray(codes, np.uint8), tree, alp
         self.div = TreeDivisions(tree, seed)
         self.maxitr, self.window = maxitr, window
+        self.scorer = scorer if scorer is not None else gpu_scorer(ctx)
+        self.exchange, self.device = exchange, device
         self.steps: List[Step] = []
         self.batches = 0
         self.wasted = 0
+        self.scored_here = 0
 
     def _evaluate(self, branches: Sequence[int]) -> List[dict]:
-        n = self.codes.shape[1]
         todo = []
         for t in branches:
             la, lb = self.div.members(t)
@@ -254,24 +321,26 @@ class Refiner:
             wb = w[lb] if len(lb) > 1 else np.ones(1)
             ga, gb = op.mSeq(a, self.alp, wa), op.mSeq(b, self.alp, wb)
             pw = op.PwdM([ga, gb], self.alp)
-            todo.append(dict(branch=t, la=la, lb=lb, pwt=pwt, a=a, b=b, skl0=skl0, groups=(ga, gb), pw=pw))
+            old = skl0[:, ::-1].copy() if pw.swp else skl0
+            todo.append(dict(branch=t, la=la, lb=lb, pwt=pwt, a=a, b=b, old=old, groups=(ga, gb), pw=pw))
         live = [d for d in todo if not d.get("skip")]
-        pwds = [d["pw"] for d in live]
-        res = op.align2_batch(self.ctx, pwds) if live else []
-        old = [d["skl0"][:, ::-1].copy() if d["pw"].swp else d["skl0"] for d in live]
-        new = [skl for (_, skl, _) in res]
-        fs = op.calcSpScore_batch(self.ctx, pwds + pwds, old + new) if live else []
-        k = len(live)
-        for i, d in enumerate(live):
-            scr, skl, st = res[i]
-            if st != 0 or fs[i][2] != 0 or fs[k + i][2] != 0:
-                raise RuntimeError("division %d: status %d / %d / %d" % (d["branch"], st, fs[i][2], fs[k + i][2]))
-            same = skl.shape == old[i].shape and np.array_equal(skl, old[i])
-            # Prrn::onecycle (src/prrn5.cc:523,535): the NEW alignment enters with Gsinfo.fstat.val (rescaled by PwdM::Vab), the
-            # CURRENT one with the return value of calcSpScore(SKL*), which is not rescaled -- kept as the reference has it
-            d["scr"], d["val_old"], d["val_new"] = scr, fs[i][3], fs[k + i][0]
-            d["delta"] = 0.0 if same else d["pwt"] * (fs[k + i][0] - fs[i][3])
-            d["skl1"] = skl[:, ::-1].copy() if d["pw"].swp else skl       # back to (larger group, smaller group)
+        if live:
+            if self.exchange is None:
+                res = self.scorer(live)
+                self.scored_here += len(live)
+            else:                                              # my share of the window, largest rectangles first
+                order = sorted(range(len(live)), key=lambda i: -(len(live[i]["a"]) * len(live[i]["b"])))
+                mine = self.exchange.share(order)
+                part = self.scorer([live[i] for i in mine]) if mine else []
+                self.scored_here += len(mine)
+                res = self.exchange.gather(mine, part, len(live), self.device)
+            for d, (scr, skl, raw_old, val_new) in zip(live, res):
+                same = skl.shape == d["old"].shape and np.array_equal(skl, d["old"])
+                # Prrn::onecycle (src/prrn5.cc:523,535): the NEW alignment enters with Gsinfo.fstat.val (rescaled by PwdM::Vab),
+                # the CURRENT one with the return value of calcSpScore(SKL*), which is not rescaled -- kept as the reference has it
+                d["scr"], d["val_old"], d["val_new"] = scr, raw_old, val_new
+                d["delta"] = 0.0 if same else d["pwt"] * (val_new - raw_old)
+                d["skl1"] = skl[:, ::-1].copy() if d["pw"].swp else skl       # back to (larger group, smaller group)
         self.batches += 1
         return todo
 

@@ -71,3 +71,58 @@ def test_two_rank_gloo_allgather():
         assert p.returncode == 0, err.decode()[-2000:]
         r = json.loads(out.decode().strip().splitlines()[-1])
         assert r["ok"], r
+
+
+# ---- a sharded refinement: two gloo ranks, each scoring half of every window, must hold the same MSA at the end --------
+REFINE_WORKER = r'''
+import os, sys, json, hashlib
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch.distributed as dist
+import oraclelib
+from prrn_aln_amd import operator as op
+from prrn_aln_amd.refine import KTree, Refiner, Exchange
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+f = json.load(open({fixture!r})); t = f["tree"]
+tree = KTree(t["left"], t["right"], t["parent"], t["vol"], t["cur"])
+alp = op.AlnParam(ls=f["ls"], molc=f["molc"], max_code=25 if f["molc"] == 1 else 17)
+L = oraclelib.load()
+def oracle_scorer(divs):          # (the DP needs a GPU: in this CPU test the CHECKER stands in for it)
+    out = []
+    for d in divs:
+        class H: c = d["pw"].problem
+        scr, cells, tr = oraclelib.forward(L, H)
+        skl = oraclelib.stdskl(L, tr)
+        sp = op.spparams(d["pw"])
+        raw_old = oraclelib.spscore_raw(L, H, sp, d["old"])[3]
+        val_new = oraclelib.spscore(L, H, sp, skl)[1]
+        out.append((scr, skl, raw_old, val_new))
+    return out
+r = Refiner(None, op.encode(f["rows"], f["molc"]), tree, alp, window=8, scorer=oracle_scorer, exchange=Exchange(cap=1024))
+final = r.run()
+want = op.encode(f["final_rows"], f["molc"])
+acc = [s for s in r.steps if s.accepted]
+dps = sum(1 for s in r.steps if s.delta != float("-inf"))
+dist.barrier(); dist.destroy_process_group()
+print(json.dumps({{"rank": int(os.environ["RANK"]), "same_as_reference": bool(np.array_equal(final, want)), "accepted": len(acc),
+                  "want_accepted": len(f["accepted"]), "digest": hashlib.sha1(final.tobytes()).hexdigest(), "scored_here": r.scored_here, "dps": dps}}))
+'''
+
+
+def test_two_rank_sharded_refinement_same_msa_on_every_rank():
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fixture = os.path.join(root, "tests", "golden", "refine_prot12x80_s3.json")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", REFINE_WORKER.format(root=root, fixture=fixture)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err.decode()[-2000:]
+        outs.append(json.loads(out.decode().strip().splitlines()[-1]))
+    assert all(o["same_as_reference"] and o["accepted"] == o["want_accepted"] for o in outs), outs
+    assert outs[0]["digest"] == outs[1]["digest"]
+    assert all(0 < o["scored_here"] < o["dps"] + 200 for o in outs) and outs[0]["scored_here"] != 0 and outs[1]["scored_here"] != 0
