@@ -41,9 +41,12 @@ struct g2g_ctx {
     hipEvent_t ev[4];
     hipEvent_t vev[7];              // 0-3, 5-6: join events of the variant streams; 4: fork event
     char *stage; size_t stage_cap;  // pinned host staging buffer of g2g_batch_prepare, kept between calls
+    double rt_ticks_per_ms;         // rate of s_memrealtime on this device, measured at g2g_create (the waits' time limit is wall clock)
     char *spare; size_t spare_bytes; // one device arena kept from the last freed batch (hipMalloc/hipFree of tens of GB per
                                     // call cost up to a second); contents are as undefined as a fresh allocation's
 };
+
+extern "C" __global__ void g2g_clock_kernel(unsigned long long *out) { *out = __builtin_amdgcn_s_memrealtime(); }
 
 extern "C" g2g_ctx *g2g_create(int device)
 {
@@ -71,6 +74,24 @@ extern "C" g2g_ctx *g2g_create(int device)
         g2g_set_error("no gfx950 kernel image usable on this device: %s", hipGetErrorString(e));
         (void) hipGetLastError();
     } else c->ok = 1;
+    c->rt_ticks_per_ms = 1.0e5;                              // nominal 100 MHz; measured below
+    if (c->ok) {
+        unsigned long long *d = 0, t[2] = {0, 0};
+        if (hipMalloc((void **) &d, sizeof(unsigned long long)) == hipSuccess) {
+            std::chrono::steady_clock::time_point h[2];
+            for (int k = 0; k < 2; ++k) {
+                hipLaunchKernelGGL(g2g_clock_kernel, dim3(1), dim3(1), 0, c->stream, d);
+                hipStreamSynchronize(c->stream);
+                h[k] = std::chrono::steady_clock::now();
+                hipMemcpy(&t[k], d, sizeof t[k], hipMemcpyDeviceToHost);
+                if (k == 0) std::this_thread::sleep_for(std::chrono::milliseconds(25));
+            }
+            const double ms = std::chrono::duration<double, std::milli>(h[1] - h[0]).count();
+            if (t[1] > t[0] && ms > 1) c->rt_ticks_per_ms = (double) (t[1] - t[0]) / ms;
+            hipFree(d);
+        }
+        (void) hipGetLastError();
+    }
     return c;
 }
 
@@ -186,7 +207,14 @@ struct g2g_batch {
     std::vector<int> flags0;        // initial contents of d_flags (re-uploaded when the 11-bit generation of the progress counters wraps)
     long long ntiles;
     float fwd_ms, tb_ms;
-    double *simscr[20]; size_t simscr_cap[20];   // per sweep-mode launch: strip-local column-score blocks (3 x 32 KB per workgroup)
+    double *simscr[20]; size_t simscr_cap[20];
+    std::vector<const g2g_problem *> src;        // the caller's problems (kept alive by the caller until the batch is freed): a DP
+                                                 // that lost a wait is re-run from here on the non-polling kernel
+    int fail_off;                                // offset of the per-DP fail flags in d_flags
+    int n_recovered;                             // DPs re-run after a time-out, over the life of the batch
+    std::vector<g2g_result> recovered;           // results of re-run DPs (trace owned by the batch until fetched)
+    std::vector<char> was_recovered;
+    bool force_v1;                               // recovery batches: everything on g2g_forward_kernel   // per sweep-mode launch: strip-local column-score blocks (3 x 32 KB per workgroup)
 };
 
 // LDS footprint of g2g_forward_kernel_v2 for one problem (see V2Geom): (slots * R + extras) records
@@ -398,7 +426,12 @@ static void release_arena(g2g_batch *b)
     b->d_arena = 0;
 }
 
+static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *prob, g2g_batch **out, bool force_v1);
 extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *prob, g2g_batch **out)
+{
+    return batch_prepare_impl(ctx, n, prob, out, false);
+}
+static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *prob, g2g_batch **out, bool force_v1)
 {
     if (!ctx || n < 0 || !out) return G2G_ERR_ARG;
     if (n > G2G_MAX_BATCH) { g2g_set_error("%s", "g2g_batch_prepare: more than 32768 problems in one batch (use g2g_forward_batch, which cuts chunks)"); return G2G_ERR_ARG; }
@@ -415,6 +448,8 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
     g2g_batch *b = new g2g_batch();
     b->ctx = ctx; b->n = n; b->d_arena = 0; b->d_probs = 0; b->fwd_ms = b->tb_ms = 0;
     for (int k = 0; k < 20; ++k) { b->simscr[k] = 0; b->simscr_cap[k] = 0; }
+    b->src.assign(prob, prob + n); b->fail_off = 0; b->force_v1 = force_v1; b->n_recovered = 0;
+    b->recovered.assign(n, g2g_result()); b->was_recovered.assign(n, 0);
     b->v3_cols = 128; b->v2_cols = G2G_V2_TILE_COLS;
 
     b->dp.resize(n); b->status.assign(n, G2G_OK); b->cells.assign(n, 0); b->out_off.assign(n, 0); b->tcap.assign(n, 0); b->rr1.assign(n, 0);
@@ -532,7 +567,7 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         d.trace = OFF<uint8_t>(take((size_t) (d.d1 - d.d0 + 1) * tmax));
         // v2 kernel (gap-profile engines): packed 16-bit gap lengths and an LDS budget decide eligibility
         d.v2_ok = 0;
-        if ((d.kind == 1 || d.kind == 2) && !getenv("G2G_FORCE_V1") && p->a.len + p->b.len < 65000) {
+        if ((d.kind == 1 || d.kind == 2) && !force_v1 && !getenv("G2G_FORCE_V1") && p->a.len + p->b.len < 65000) {
             // _pf: one lane per cell with rank-form merges (v6) when the rows' static lists fit the register file
             if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_V6") && !getenv("G2G_V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V6_NA && d.a.r_from_t &&
                 v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(p)).total <= (getenv("G2G_V6_LARGE") ? (int) V2_LDS_MAX : V6_SMALL_LDS)) d.v2_ok = 6;
@@ -721,6 +756,16 @@ extern "C" int g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *
         b->var_off[16] = (int) all.size();
         for (int v = 0; v < 4; ++v) b->v6lds[v] = v6_layout(v6rows[v], v6ca4[v], v6rs[v]);
         for (int v = 0; v < 8; ++v) b->v3lds[v] = v3_layout(need[v].rows_bytes, need[v].ca4, need[v].apool, need[v].bpool, b->v3_cols);
+        // test hook: G2G_INJECT_STALL=<i> makes the first strip / tile of problem i depend on a flag nobody ever writes
+        if (const char *e = getenv("G2G_INJECT_STALL")) {
+            const int victim = atoi(e);
+            const int never = (int) flags.size();
+            flags.push_back(0);
+            for (size_t k = 0; k < all.size(); ++k)
+                if (all[k].prob == victim && all[k].ti >= 0) { all[k].dep_up = never; break; }
+        }
+        b->fail_off = (int) flags.size();                 // per-DP fail flags behind the tile flags
+        flags.resize(flags.size() + (size_t) (n > 0 ? n : 1), 0);
         b->ntiles = (long long) all.size();
         b->nflags = (int) flags.size();
         b->flags0 = flags;
@@ -752,6 +797,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
     g2g_ctx *ctx = b->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     if (b->n == 0) return G2G_OK;
+    std::fill(b->was_recovered.begin(), b->was_recovered.end(), 0);
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     if (b->n2) {
         const int T2 = b->v2_threads;
@@ -797,7 +843,16 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipMemcpyAsync(b->d_flags, b->flags0.data(), sizeof(int) * b->flags0.size(), hipMemcpyHostToDevice, ctx->stream));
             ++b->gen;
         }
-        HIPCHK(hipMemsetAsync(b->d_flags, 0, 20 * sizeof(int), ctx->stream));           // queue heads, incident report
+        {   // queue heads; header of the waits (g2g_wait_ge): time-outs, first slot, offset of the fail flags, wall-clock limit
+            int hdr[20];
+            memset(hdr, 0, sizeof hdr);
+            double limit_ms = 20000.;
+            if (const char *e = getenv("G2G_WAIT_LIMIT_MS")) { const double v = atof(e); if (v > 0) limit_ms = v; }
+            hdr[18] = b->fail_off;
+            hdr[19] = (int) std::min(2.0e9, limit_ms * ctx->rt_ticks_per_ms / 65536.) + 1;
+            HIPCHK(hipMemcpyAsync(b->d_flags, hdr, sizeof hdr, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemsetAsync(b->d_flags + b->fail_off, 0, sizeof(int) * (size_t) (b->n > 0 ? b->n : 1), ctx->stream));
+        }
         HIPCHK(hipEventRecord(ctx->vev[4], ctx->stream));
         int ncu = 256;
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) ncu = pr.multiProcessorCount; }
@@ -912,10 +967,30 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         int rep[20];
         HIPCHK(hipMemcpy(rep, b->d_flags, sizeof rep, hipMemcpyDeviceToHost));
         if (rep[16]) {
-            char msg[128];
-            snprintf(msg, sizeof msg, "%d tile waits timed out (first: queue slot %d on flag %d)", rep[16], rep[17], rep[18]);
-            g2g_set_error("v2 scheduler: %s", msg);
-            return G2G_ERR_DEVICE;
+            // Some wait ran into the wall-clock limit.  Only the DPs marked in the fail array are lost; they are re-run here, in
+            // the same call, on the kernel that polls nothing (one workgroup per DP, state in HBM).
+            std::vector<int> fail(b->n);
+            HIPCHK(hipMemcpy(fail.data(), b->d_flags + b->fail_off, sizeof(int) * (size_t) b->n, hipMemcpyDeviceToHost));
+            std::vector<int> lost;
+            for (int i = 0; i < b->n; ++i) if (fail[i] && !b->status[i]) lost.push_back(i);
+            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] s_memrealtime: %.0f ticks/ms; ", ctx->rt_ticks_per_ms); fprintf(stderr, "[g2g] %d waits timed out (first: queue slot %d): re-running %zu DP(s) on g2g_forward_kernel\n", rep[16], rep[17], lost.size()); fflush(stderr); }
+            if (b->force_v1 || lost.empty()) { g2g_set_error("%s", "scheduler: a wait timed out and no DP could be singled out"); return G2G_ERR_DEVICE; }
+            std::vector<const g2g_problem *> pp;
+            for (int i : lost) pp.push_back(b->src[i]);
+            g2g_batch *rb = 0;
+            int rc = batch_prepare_impl(ctx, (int) pp.size(), pp.data(), &rb, true);
+            if (!rc) {
+                rc = g2g_batch_run(rb);
+                std::vector<g2g_result> rr(pp.size());
+                if (!rc) rc = g2g_batch_fetch(rb, rr.data());
+                if (!rc) for (size_t k = 0; k < lost.size(); ++k) {
+                    free(b->recovered[lost[k]].trace);
+                    b->recovered[lost[k]] = rr[k]; b->was_recovered[lost[k]] = 1;
+                }
+                g2g_batch_free(rb);
+            }
+            if (rc) { g2g_set_error("%s", "scheduler: the re-run of timed-out DPs failed"); return rc; }
+            b->n_recovered += (int) lost.size();
         }
     }
     HIPCHK(hipEventElapsedTime(&b->fwd_ms, ctx->ev[0], ctx->ev[1]));
@@ -935,6 +1010,12 @@ extern "C" int g2g_batch_fetch(g2g_batch *b, g2g_result *res)
         res[i].cells = b->cells[i];
         res[i].trace = 0; res[i].ntrace = 0; res[i].score = 0;
         if (b->status[i]) continue;
+        if (b->was_recovered[i]) {                      // (re-run after a time-out: a copy, the batch may be fetched again)
+            res[i] = b->recovered[i];
+            res[i].trace = (g2g_skl *) malloc(sizeof(g2g_skl) * (size_t) (res[i].ntrace > 0 ? res[i].ntrace : 1));
+            memcpy(res[i].trace, b->recovered[i].trace, sizeof(g2g_skl) * (size_t) res[i].ntrace);
+            continue;
+        }
         const char *tmp = all.data() + (b->out_off[i] - b->out_lo);
         memcpy(&res[i].score, tmp, sizeof(double));
         int nt, rr0;
@@ -973,6 +1054,7 @@ extern "C" void g2g_batch_free(g2g_batch *b)
     if (b->d_tiles) hipFree(b->d_tiles);
     if (b->d_flags) hipFree(b->d_flags);
     for (int k = 0; k < 20; ++k) if (b->simscr[k]) hipFree(b->simscr[k]);
+    for (size_t i = 0; i < b->recovered.size(); ++i) free(b->recovered[i].trace);
     delete b;
 }
 
@@ -1069,7 +1151,7 @@ static size_t problem_bytes(const g2g_problem *p)
     const g2g_side *sd[2] = {&p->a, &p->b};
     for (int k = 0; k < 2; ++k) {
         const size_t cols = (size_t) sd[k]->len + 2;
-        bytes += cols * sd[k]->many * (kind_of(p->alnmode) == 3 ? 17 : 1) + cols * 24 + cols * 8 * (size_t) (sd[k]->nelm > 0 ? sd[k]->nelm : 0);
+        bytes += cols * sd[k]->many * (kind_of(p->alnmode) == 3 ? 17 : 1) + cols * 24 + cols * 8 * (size_t) ((sd[k]->pseq && sd[k]->nelm > 0) ? sd[k]->nelm : 0);    // (nelm of a side without vectors is not defined)
         if (sd[k]->has_gfq) for (int v = 0; v < 3; ++v) bytes += 12 * (size_t) sd[k]->gfq.off[v][sd[k]->len + 1] + 4 * cols;
     }
     const size_t lists = 8 * (size_t) ((p->a.has_gfq ? p->a.gfq.hetero + 1 : p->a.many) + (p->b.has_gfq ? p->b.gfq.hetero + 1 : p->b.many));
@@ -1100,6 +1182,7 @@ extern "C" int g2g_forward_batch(g2g_ctx *ctx, int n, const g2g_problem *const *
             if (hi > lo && (acc + pb > budget || hi - lo >= G2G_MAX_BATCH)) break;
             acc += pb; ++hi;
         }
+        if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] forward_batch: chunk [%d, %d) of %d, %.3g of %.3g bytes\n", lo, hi, n, (double) acc, (double) budget); fflush(stderr); }
         g2g_batch *b = 0;
         int rc = g2g_batch_prepare(ctx, hi - lo, prob + lo, &b);
         if (!rc) {

@@ -29,13 +29,36 @@ __device__ unsigned long long g2g_stamp_acc[16];
 #define STAMP(k)
 #endif
 #define DL_END 0xFFFFu                       // packed terminator glen (INT_MAX in the reference)
-#ifndef G2G_SPIN_MAX
-#define G2G_SPIN_MAX (1 << 24)       // ~20-30 s of polling: a producer wave may be parked for seconds when several processes
-                                    // share the GPU (4 ranks rehearsed on one device timed out with 1 << 22)
-#endif
-// once ANY wait of the launch has given up the batch is lost: the others stop waiting at their next check instead of
-// each running out its own bound (a dead dependency chain would otherwise drain one time-out after the other)
-#define G2G_SPIN_BAIL(it, dbg) if (((it) & 4095) == 4095 && __hip_atomic_load((dbg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { (it) = G2G_SPIN_MAX - 1; }
+// ---- bounded waits on progress words of other resident workgroups -------------------------------------------------------
+// Persistent workgroups poll flags / progress counters that other workgroups of the SAME launch write.  Dependencies sit
+// earlier in the queue than their dependents, so a wait can only be long, not endless -- unless something outside the design
+// happens (several processes oversubscribing the device were seen to stretch waits past an iteration-count bound).  The
+// bound is therefore WALL CLOCK (s_memrealtime: 100 MHz, keeps running while a wave is descheduled), set per launch by the
+// host (hdr[3], units of 65536 ticks = 0.655 ms), and a time-out costs ONE DP, not the batch: the DP is marked in the
+// batch's fail array, every other wait of that DP gives up at its next check, its remaining strips are skipped, and
+// g2g_batch_run re-runs the marked DPs on the non-polling kernel (g2g_forward_kernel).  hdr = done + 16:
+// [0] time-outs, [1] queue slot of the first, [2] offset of the fail array from `done`, [3] the limit.
+__device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hdr, int *failp, const int slot)
+{
+    int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v >= want) return v;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned it = 1; ; ++it) {
+        __builtin_amdgcn_s_sleep(8);
+        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= want) return v;
+        if ((it & 255) == 0) {
+            if (__hip_atomic_load(failp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 0x7fffffff;      // this DP is lost already
+            const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
+            if ((dt >> 16) > (unsigned long long) (unsigned) __hip_atomic_load(hdr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(failp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (atomicAdd(hdr, 1) == 0) hdr[1] = slot;
+                return 0x7fffffff;
+            }
+        }
+    }
+}
+__device__ __forceinline__ bool g2g_dp_failed(const int *failp) { return __hip_atomic_load(failp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
 #define DL_GUARD 128                         // no list is this long: a corrupted one must not hang the wave
 
 // Everything below lives in LDS and says so in its pointer types (address space 3): generic pointers
@@ -769,7 +792,7 @@ __device__ __forceinline__ const GLBV3 double *simblk_at(const SimBlk &S, const 
 template <int KIND, bool NOLL3>
 __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti, int tj, int nsteps, const int C,
                         const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0, const int pint = 32,
-                        const int *prog_left = 0, double *simscr = 0)
+                        const int *prog_left = 0, double *simscr = 0, int *failp = 0)
 {
     // SWEEP MODE (prog_self != 0), as in g2g_kernels_v3.hip: the tile is a whole strip; the strip above publishes every
     // 32 steps up to which corner column its last row's records are in HBM, this strip waits only before its first
@@ -807,13 +830,7 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
     if (prog_left) {                                       // sweep mode: the left boundary chain runs beside the strips (v2_chain_tile)
         const int rows_ = m0 + R - a.left;
         const int wantl = ((pgen & 0x7FF) << 20) | (rows_ < 0xFFFFF ? rows_ : 0xFFFFF);
-        int it = 0;
-        for (; it < G2G_SPIN_MAX; ++it) {
-            if (__hip_atomic_load(prog_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wantl) break;
-            __builtin_amdgcn_s_sleep(8);
-            G2G_SPIN_BAIL(it, dbg)
-        }
-        if (it == G2G_SPIN_MAX) { atomicAdd(dbg, 1); dbg[1] = ti; dbg[2] = -2; }
+        (void) g2g_wait_ge(prog_left, wantl, dbg, failp, ti);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -884,14 +901,7 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         if (col > hi0 + 1) col = hi0 + 1;
         const int want = penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF);
         if (prog_up && want > avail) {
-            int it = 0;
-            for (; it < G2G_SPIN_MAX; ++it) {
-                avail = __hip_atomic_load(prog_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (avail >= want) break;
-                __builtin_amdgcn_s_sleep(8);
-                G2G_SPIN_BAIL(it, dbg)
-            }
-            if (it == G2G_SPIN_MAX) { atomicAdd(dbg, 1); dbg[1] = ti; dbg[2] = col; avail = 0x7fffffff; }
+            avail = g2g_wait_ge(prog_up, want, dbg, failp, ti);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1252,15 +1262,9 @@ struct V2Tile { int prob, ti, tj, nsteps, self, dep_up, dep_left, dep_diag, dep_
 // Cross-workgroup visibility follows the agent-scope release/acquire recipe of the CDNA guide (G16).
 // Every spin is bounded (a kernel that never ends can take the whole node down): on a time-out the wait
 // gives up, the incident is counted in dbg[0] and the host reports the batch as failed.
-__device__ __forceinline__ void v2_wait_flag(const int *flag, int gen, int *dbg, int tile)
+__device__ __forceinline__ void v2_wait_flag(const int *flag, int gen, int *dbg, int tile, int *failp)
 {
-    for (int it = 0; it < G2G_SPIN_MAX; ++it) {
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gen) return;
-        __builtin_amdgcn_s_sleep(8);
-        G2G_SPIN_BAIL(it, dbg)
-    }
-    atomicAdd(dbg, 1);
-    dbg[1] = tile; dbg[2] = (int) (flag - dbg);
+    (void) g2g_wait_ge(flag, gen, dbg, failp, tile);
 }
 #ifdef G2G_V2_STAMP
 __device__ unsigned long long g2g_wait_acc[4];
@@ -1295,23 +1299,33 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
             __syncthreads();                                                                        \
             continue;                                                                               \
         }                                                                                           \
+        int *failp = done + done[18] + T.prob;                                                      \
+        if (threadIdx.x == 0) s_vals[0] = g2g_dp_failed(failp) ? 1 : 0;      /* (one reader: the branch must be uniform) */ \
+        __syncthreads();                                                                            \
+        const int dp_dead = s_vals[0];                                                              \
+        __syncthreads();                                                                            \
+        if (dp_dead) {                    /* this DP lost a wait: its strips are skipped, dependents released */ \
+            if (threadIdx.x == 0) __hip_atomic_store(done + T.self, sweep ? (((gen & 0x7FF) << 20) | 0xFFFFF) : gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            __syncthreads();                                                                        \
+            continue;                                                                               \
+        }                                                                                           \
         /* one call site of the tile function (see g2g_kernels_v3.hip) */                           \
         const int *pu = (sweep && T.dep_up >= 0) ? done + T.dep_up : (const int *) 0;                \
         const int *pl = (sweep && T.dep_left >= 0) ? done + T.dep_left : (const int *) 0;            \
         int *ps = sweep ? done + T.self : (int *) 0;                                                \
         V2_WAIT_T0                                                                                  \
         if (!sweep) {                                                                               \
-            if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t);                    \
-            if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t);                \
-            if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t);                \
-            if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t);                  \
+            if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t, failp);             \
+            if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t, failp);         \
+            if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t, failp);         \
+            if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t, failp);           \
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                      \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
         }                                                                                           \
         __syncthreads();                                                                            \
         V2_WAIT_T1                                                                                  \
         v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen, sweep, pl, \
-                          (sweep && simscr) ? simscr + (size_t) blockIdx.x * (3 * 4096) : (double *) 0); \
+                          (sweep && simscr) ? simscr + (size_t) blockIdx.x * (3 * 4096) : (double *) 0, failp); \
         V2_WAIT_T2                                                                                  \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \

@@ -598,7 +598,7 @@ __device__ __forceinline__ void v3_rec_store(unsigned *dst, int capa, int capb, 
 template <int KIND, bool NOLL3, int NA>
 __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V3Lds LO, const int ti, const int tj, const int nsteps, const int C,
                         const int *prog_up = 0, int *prog_self = 0, int *dbg = 0, const int pgen = 0, const int pint = 32,
-                        const int *prog_left = 0, double *simscr = 0)
+                        const int *prog_left = 0, double *simscr = 0, int *failp = 0)
 {
     // SWEEP MODE (prog_self != 0): the tile is a whole strip (C covers the row range) and the dependency on the strip
     // above is a progress counter instead of tile-completion flags: the strip above publishes, every pint (16/32) steps, up to
@@ -633,13 +633,7 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
     if (prog_left) {                                       // sweep mode: the left boundary chain runs beside the strips (v2_chain_tile)
         const int rows_ = m0 + 64 - a.left;
         const int wantl = ((pgen & 0x7FF) << 20) | (rows_ < 0xFFFFF ? rows_ : 0xFFFFF);
-        int it = 0;
-        for (; it < G2G_SPIN_MAX; ++it) {
-            if (__hip_atomic_load(prog_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wantl) break;
-            __builtin_amdgcn_s_sleep(8);
-            G2G_SPIN_BAIL(it, dbg)
-        }
-        if (it == G2G_SPIN_MAX) { atomicAdd(dbg, 1); dbg[1] = ti; dbg[2] = -2; }
+        (void) g2g_wait_ge(prog_left, wantl, dbg, failp, ti);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -754,14 +748,7 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
     auto need = [&](const int col) {                       // wave-uniform: every lane polls, nobody branches alone
         const int want = penc | (col < 0xFFFFF ? col : 0xFFFFF);
         if (prog_up && want > avail) {
-            int it = 0;
-            for (; it < G2G_SPIN_MAX; ++it) {
-                avail = __hip_atomic_load(prog_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (avail >= want) break;
-                __builtin_amdgcn_s_sleep(8);
-                G2G_SPIN_BAIL(it, dbg)
-            }
-            if (it == G2G_SPIN_MAX) { atomicAdd(dbg, 1); dbg[1] = ti; dbg[2] = col; avail = 0x7fffffff; }
+            avail = g2g_wait_ge(prog_up, want, dbg, failp, ti);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -951,22 +938,32 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
             __syncthreads();                                                                        \
             continue;                                                                               \
         }                                                                                           \
+        int *failp = done + done[18] + T.prob;                                                      \
+        if (threadIdx.x == 0) s_vals[0] = g2g_dp_failed(failp) ? 1 : 0;      /* (one reader: the branch must be uniform) */ \
+        __syncthreads();                                                                            \
+        const int dp_dead = s_vals[0];                                                              \
+        __syncthreads();                                                                            \
+        if (dp_dead) {                    /* this DP lost a wait: its strips are skipped, dependents released */ \
+            if (threadIdx.x == 0) __hip_atomic_store(done + T.self, sweep ? (((gen & 0x7FF) << 20) | 0xFFFFF) : gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            __syncthreads();                                                                        \
+            continue;                                                                               \
+        }                                                                                           \
         const int *pl = (sweep && T.dep_left >= 0) ? done + T.dep_left : (const int *) 0;            \
         /* sweep: strips as a pipeline on progress counters; else tiles on completion flags.  ONE call site of the   \
            tile function, or it is not inlined and its frame lands in scratch memory */                             \
         const int *pu = (sweep && T.dep_up >= 0) ? done + T.dep_up : (const int *) 0;                \
         int *ps = sweep ? done + T.self : (int *) 0;                                                \
         if (!sweep) {                                                                               \
-            if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t);                    \
-            if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t);                \
-            if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t);                \
-            if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t);                  \
+            if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t, failp);             \
+            if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t, failp);         \
+            if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t, failp);         \
+            if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t, failp);           \
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                      \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
         }                                                                                           \
         __syncthreads();                                                                            \
         v3_tile<KIND, N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen, sweep, pl, \
-                              (sweep && simscr) ? simscr + (size_t) blockIdx.x * (3 * 4096) : (double *) 0); \
+                              (sweep && simscr) ? simscr + (size_t) blockIdx.x * (3 * 4096) : (double *) 0, failp); \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
         if (!sweep) {                                                                               \

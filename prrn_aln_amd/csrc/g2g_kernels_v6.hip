@@ -374,7 +374,7 @@ __device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, cons
 template <bool NOLL3, int NA>
 __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const V6Lds LO, const int ti, const int nsteps,
                                          const int *prog_up, int *prog_self, int *dbg, const int pgen, const int pint, const int *prog_left,
-                                         double *simscr)
+                                         double *simscr, int *failp)
 {
     DevProb P;
     uni_prob(P, Pmem);
@@ -405,13 +405,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
     if (prog_left) {                                       // the left boundary chain runs beside the strips (v2_chain_tile)
         const int rows_ = m0 + 64 - a.left;
         const int wantl = ((pgen & 0x7FF) << 20) | (rows_ < 0xFFFFF ? rows_ : 0xFFFFF);
-        int it = 0;
-        for (; it < G2G_SPIN_MAX; ++it) {
-            if (__hip_atomic_load(prog_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wantl) break;
-            __builtin_amdgcn_s_sleep(8);
-            G2G_SPIN_BAIL(it, dbg)
-        }
-        if (it == G2G_SPIN_MAX) { atomicAdd(dbg, 1); dbg[1] = ti; dbg[2] = -2; }
+        (void) g2g_wait_ge(prog_left, wantl, dbg, failp, ti);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -516,14 +510,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
     auto need = [&](const int col) {                       // wave-uniform: every lane polls, nobody branches alone
         const int want = penc | (col < 0xFFFFF ? col : 0xFFFFF);
         if (prog_up && want > avail) {
-            int it = 0;
-            for (; it < G2G_SPIN_MAX; ++it) {
-                avail = __hip_atomic_load(prog_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (avail >= want) break;
-                __builtin_amdgcn_s_sleep(8);
-                G2G_SPIN_BAIL(it, dbg)
-            }
-            if (it == G2G_SPIN_MAX) { atomicAdd(dbg, 1); dbg[1] = ti; dbg[2] = col; avail = 0x7fffffff; }
+            avail = g2g_wait_ge(prog_up, want, dbg, failp, ti);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -718,11 +705,21 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
             __syncthreads();                                                                        \
             continue;                                                                               \
         }                                                                                           \
+        int *failp = done + done[18] + T.prob;                                                      \
+        if (threadIdx.x == 0) s_vals[0] = g2g_dp_failed(failp) ? 1 : 0;      /* (one reader: the branch must be uniform) */ \
+        __syncthreads();                                                                            \
+        const int dp_dead = s_vals[0];                                                              \
+        __syncthreads();                                                                            \
+        if (dp_dead) {                    /* this DP lost a wait: its strips are skipped, dependents released */ \
+            if (threadIdx.x == 0) __hip_atomic_store(done + T.self, ((gen & 0x7FF) << 20) | 0xFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            __syncthreads();                                                                        \
+            continue;                                                                               \
+        }                                                                                           \
         const int *pl = T.dep_left >= 0 ? done + T.dep_left : (const int *) 0;                      \
         const int *pu = T.dep_up >= 0 ? done + T.dep_up : (const int *) 0;                          \
         __syncthreads();                                                                            \
         v6_strip<N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, T.nsteps, pu, done + T.self, done + 16, gen, pint, pl, \
-                         simscr + (size_t) blockIdx.x * (3 * 4096)); \
+                         simscr + (size_t) blockIdx.x * (3 * 4096), failp); \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
     }                                                                                               \

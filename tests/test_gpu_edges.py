@@ -99,3 +99,29 @@ def test_many_runs_of_one_batch(ctx):
             for d, (scr, cells, tr, st) in zip(ds, batch.fetch()):
                 assert st == 0 and scr == d["scr"][0] and np.array_equal(tr, d["vmf_trace"]), it
     batch.free()
+
+
+def test_injected_stall_costs_one_dp_and_is_recovered(ctx, monkeypatch):
+    """A wait that can never be satisfied (test hook G2G_INJECT_STALL: the victim's first strip depends on a flag nobody
+    writes) must run into the WALL-CLOCK limit, cost only that DP, and g2g_batch_run must re-run the DP on the non-polling
+    kernel in the same call: every result of the batch, the victim's included, still equals the reference golden."""
+    import glob, os, time
+    from prrn_aln_amd import _abi
+    gold = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "syn24x120_k*.npz")))
+    ds = [dict(np.load(f)) for f in gold]
+    ds = [d for d in ds if d["alnmode"][0] in (7, 8, 9)]
+    assert len(ds) >= 4
+    hs = [_abi.problem_from_arrays(d) for d in ds]
+    for victim in (0, 2):
+        monkeypatch.setenv("G2G_INJECT_STALL", str(victim))
+        monkeypatch.setenv("G2G_WAIT_LIMIT_MS", "300")
+        t0 = time.time()
+        res = ctx.forward_batch(hs)
+        dt = time.time() - t0
+        monkeypatch.delenv("G2G_INJECT_STALL")
+        monkeypatch.delenv("G2G_WAIT_LIMIT_MS")
+        assert 0.25 < dt < 20, dt                      # it did wait for the limit, and for not much longer
+        for d, (scr, cells, tr, st) in zip(ds, res):
+            assert st == 0 and scr == d["scr"][0] and np.array_equal(tr, d["vmf_trace"])
+    res = ctx.forward_batch(hs)                        # and the context is fine afterwards
+    assert all(st == 0 and scr == d["scr"][0] for d, (scr, cells, tr, st) in zip(ds, res))
