@@ -37,9 +37,10 @@ class Sweep:
     libg2g.so).  `order` lists division ids by decreasing DP size (longest-processing-time first)."""
 
     def __init__(self, fam: Family, alp: op.AlnParam, weighted: bool = True, limit: Optional[int] = None,
-                 workers: Optional[int] = None):
+                 workers: Optional[int] = None, codes: Optional[np.ndarray] = None):
+        """`codes`: start from this MSA ((columns, members) residue codes of the family's members) instead of fam.msa."""
         self.fam, self.alp = fam, alp
-        self.codes = op.encode(fam.msa, alp.molc)
+        self.codes = op.encode(fam.msa, alp.molc) if codes is None else np.ascontiguousarray(codes, np.uint8)
         n = len(fam.msa)
         self.weights = np.asarray(tree_weights(fam.tree, n)) if weighted else None
         self.branches = tree_branches(fam.tree)
