@@ -264,7 +264,10 @@ static V6Lds v6_layout(int rows_bytes, int ca4max, int rs)
     L.rs = rs;
     return L;
 }
-static const int V6_SMALL_LDS = 48 * 1024;          // launches are split at this footprint
+// v6 launches are split at this LDS footprint; DPs above it stay on v2 (G2G_V6_LARGE: run them on v6 in a launch of their own).
+// 53 KB = three strips per CU.
+static int v6_small_lds() { static const int v = getenv("G2G_V6_SMALL_KB") ? atoi(getenv("G2G_V6_SMALL_KB")) * 1024 : 53 * 1024; return v; }
+#define V6_SMALL_LDS (v6_small_lds())
 static int v6_rows_bytes(const DevProb &d)
 {
     const int lsz = ((d.capa + 3) & ~3) + ((d.capb + 3) & ~3);
