@@ -287,7 +287,7 @@ def main():
     # second workload (not the metric): the same family, sweep started from the REFERENCE's progressive MSA (fixture made by
     # tools/make_progressive_fixture.py) -- shorter, rougher, smaller DPs than the synthetic true alignment
     prog = None
-    ppath = os.path.join(ROOT, "tests", "golden", "prog256x1024.npz")
+    ppath = os.path.join(ROOT, "tests", "golden", "msa", "prog256x1024.npz")
     if world == 1 and not args.shard_of and not args.dna and not args.limit and args.nseq == 256 and args.length == 1024 and args.seed == 1 \
             and os.path.exists(ppath) and not args.no_cpu:
         try:

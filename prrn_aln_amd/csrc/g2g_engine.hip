@@ -249,7 +249,8 @@ static V3Lds v3_layout(int rows_bytes, int ca4max, int apool, int bpool, int C)
 }
 // LDS plan of the v6 kernel (g2g_kernels_v6.hip): ring rows of dynamic lists, black lists, staging scalars, the ring of
 // b's static lists (3 views x rs entries x 16 B), queue scratch, sinks
-static V6Lds v6_layout(int rows_bytes, int ca4max, int rs)
+struct V6Ring { int rs[3]; };
+static V6Lds v6_layout(int rows_bytes, int ca4max, const V6Ring &R)
 {
     V6Lds L;
     int o = 0;
@@ -257,38 +258,42 @@ static V6Lds v6_layout(int rows_bytes, int ca4max, int rs)
     L.rows = take(rows_bytes);
     L.black = take(4 * (ca4max + 8));
     L.stsc = take(4 * 28);
-    L.ring = take(3 * 16 * rs);
+    for (int v = 0; v < 3; ++v) { L.rs[v] = R.rs[v]; L.ringf[v] = take(8 * R.rs[v]); }
+    for (int v = 0; v < 3; ++v) L.ringk[v] = take(4 * R.rs[v]);
     L.svals = take(4 * 64);
     L.sink = take(4 * 64 + 16 * 64);
     L.total = o;
-    L.rs = rs;
     return L;
 }
-// v6 launches are split at this LDS footprint; DPs above it stay on v2 (G2G_V6_LARGE: run them on v6 in a launch of their own).
-// 53 KB = three strips per CU.
+// A launch has ONE LDS plan, the largest of its DPs, and LDS decides how many strips a CU holds: v6 DPs are dealt to two
+// launches by footprint -- up to 40 KB (four strips per CU) and up to 53 KB (three) -- and DPs above that stay on v2, which
+// beats v6 at two strips per CU (measured: 779 ms per bench sweep with the limit at 53 KB, 1015 ms at 64 KB).
 static int v6_small_lds() { static const int v = getenv("G2G_V6_SMALL_KB") ? atoi(getenv("G2G_V6_SMALL_KB")) * 1024 : 53 * 1024; return v; }
 #define V6_SMALL_LDS (v6_small_lds())
+static const int V6_CLASS_A = 40 * 1024;
 static int v6_rows_bytes(const DevProb &d)
 {
     const int lsz = ((d.capa + 3) & ~3) + ((d.capb + 3) & ~3);
     return 65 * v3_pitch(d.noll == 3 ? 9 : 6, lsz) * 4 + 32;
 }
-// ring entries the v6 kernel needs per view for this problem: the most pool entries any window of V6_WINDOW consecutive
-// columns of b holds (the ring is indexed by pool position & (rs - 1))
-static int v6_ring_need(const g2g_problem *p)
+// ring entries the v6 kernel needs per view for this problem: the most list entries (terminators not counted) any window
+// of V6_WINDOW consecutive columns of b holds (a ring is indexed by compact pool position & (rs - 1))
+static V6Ring v6_ring_need(const g2g_problem *p)
 {
-    int need = 1;
+    V6Ring R;
     const int lo = p->b.left, hi = p->b.right;
     for (int v = 0; v < 3; ++v) {
         const int32_t *off = p->b.gfq.off[v];
+        int need = 1;
         for (int c = lo; c < hi; ++c) {
             const int e = std::min(c + V6_WINDOW, hi);
-            need = std::max(need, off[e + 1] - off[c + 1]);
+            need = std::max(need, (off[e + 1] - (e + 1)) - (off[c + 1] - (c + 1)));
         }
+        int rs = 32;
+        while (rs < need) rs <<= 1;
+        R.rs[v] = rs;
     }
-    int rs = 64;
-    while (rs < need) rs <<= 1;
-    return rs;
+    return R;
 }
 struct V3Need { int rows_bytes, ca4, apool, bpool, total; };
 static V3Need v3_need(const DevProb &d, const g2g_problem *p, int C, bool areg = false)
@@ -573,7 +578,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         if ((d.kind == 1 || d.kind == 2) && !force_v1 && !getenv("G2G_FORCE_V1") && p->a.len + p->b.len < 65000) {
             // _pf: one lane per cell with rank-form merges (v6) when the rows' static lists fit the register file
             if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_V6") && !getenv("G2G_V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V6_NA && d.a.r_from_t &&
-                v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(p)).total <= (getenv("G2G_V6_LARGE") ? (int) V2_LDS_MAX : V6_SMALL_LDS)) d.v2_ok = 6;
+                v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(p)).total <= V6_SMALL_LDS) d.v2_ok = 6;
             else if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_AREG") && (d.kind == 1 || getenv("G2G_V3_PF")) && d.a.maxlist <= G2G_V3_NA &&
                 v3_need(d, p, b->v3_cols, true).total <= (int) V2_LDS_MAX) d.v2_ok = 3;
             else {
@@ -679,7 +684,8 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         std::vector<V2Tile> pre[16];                      // boundary chains of sweep-mode DPs: they head their variant's queue
         std::vector<int> ip;                              // the other DPs: chains in the prologue kernel
         const bool chainq = !getenv("G2G_NO_CHAINQ");
-        int v6rows[4] = {0, 0, 0, 0}, v6ca4[4] = {0, 0, 0, 0}, v6rs[4] = {64, 64, 64, 64};
+        int v6rows[4] = {0, 0, 0, 0}, v6ca4[4] = {0, 0, 0, 0};
+        V6Ring v6rs[4] = {{{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}};
         V3Need need[8];
         memset(need, 0, sizeof need);
         for (int i = 0; i < n; ++i) {
@@ -701,11 +707,11 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
             const int nstrip = (ar - al + R - 1) / R, nblk = (br - bl_ + C - 1) / C;
             // (one LDS plan per launch = the largest of its DPs: DPs whose column lists need a big ring get a launch of their own,
             //  or a handful of balanced divisions would cost every strip of the sweep its occupancy)
-            const int var = d.v2_ok == 6 ? 12 + (d.noll == 3 ? 1 : 0) + (v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(prob[i])).total > V6_SMALL_LDS ? 2 : 0) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
+            const int var = d.v2_ok == 6 ? 12 + (d.noll == 3 ? 1 : 0) + (v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(prob[i])).total > V6_CLASS_A ? 2 : 0) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
             if (d.v2_ok == 6) {
                 v6rows[var - 12] = std::max(v6rows[var - 12], v6_rows_bytes(d));
                 v6ca4[var - 12] = std::max(v6ca4[var - 12], (d.capa + 3) & ~3);
-                v6rs[var - 12] = std::max(v6rs[var - 12], v6_ring_need(prob[i]));
+                { const V6Ring rn = v6_ring_need(prob[i]); for (int q = 0; q < 3; ++q) v6rs[var - 12].rs[q] = std::max(v6rs[var - 12].rs[q], rn.rs[q]); }
             } else if (d.v2_ok >= 2) {
                 const V3Need nd = v3_need(d, prob[i], C, d.v2_ok == 3);
                 V3Need &x = need[var - 4];
@@ -927,7 +933,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[v & 3], 0));
         }
         for (int vi = 0; vi < 4; ++vi) {
-            const int v = 3 - vi;                    // (large-footprint launches first: they hold the longest DPs)
+            const int v = 3 - vi;                    // (the larger-footprint launch first)
             const int cnt = b->var_off[v + 13] - b->var_off[v + 12];
             if (!cnt) continue;
             typedef void (*v6k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V6Lds, int, int, double *);
@@ -942,7 +948,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             if (const char *e = getenv("G2G_V6_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc = w; }
             const int grid = std::min(cnt, ncu * wpc);
             const int pint = b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= ncu * wpc ? 4 : cnt < 4 * ncu * wpc ? 16 : 32;   // publish interval (power of 2)
-            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v6 variant %d: %d strips, grid %d, lds %d (ring %d entries), publish every %d, gen %d\n", v, cnt, grid, LO.total, LO.rs, pint, b->gen); fflush(stderr); }
+            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v6 variant %d: %d strips, grid %d, lds %d (rings %d / %d / %d entries), publish every %d, gen %d\n", v, cnt, grid, LO.total, LO.rs[0], LO.rs[1], LO.rs[2], pint, b->gen); fflush(stderr); }
             double *simscr6 = sim_scratch(12 + v, grid);
             if (!simscr6) { g2g_set_error("%s", "hipMalloc(column-score scratch)"); return G2G_ERR_NOMEM; }
             hipLaunchKernelGGL(v6k[v], dim3(grid), dim3(64), (size_t) LO.total, vs,

@@ -40,7 +40,8 @@ __device__ unsigned long long g2g_v6_stamp_acc[16];
 #define V6_STAMP_PASS
 #endif
 
-struct V6Lds { int rows, black, stsc, ring, svals, sink, total, rs; };     // byte offsets; rs: ring entries per view (power of 2)
+// byte offsets; ringk / ringf / rs: per view (s, t, r) the key and freq arrays of the column-list ring and its entries (power of 2)
+struct V6Lds { int rows, black, stsc, svals, sink, total; int ringk[3], ringf[3], rs[3]; };
 
 #define V6_FEED 16                      // columns per ring refill
 #define V6_AHEAD 32                     // a refill reaches this many columns beyond lane 0's
@@ -175,19 +176,23 @@ __device__ __forceinline__ void nd6_fin(const ND6 &s, const bool was_on, lu32 *d
 }
 
 // ---- the ring of b's static lists ------------------------------------------------------------------------
-// entry = 16 bytes {i32 glen, -, f64 freq}; ring v holds pool entries of view v at index (pool position & mask)
+// Per view two arrays: lookup keys (u32, (glen << 16) | 0xFFFF) and freq (f64) -- 12 bytes per entry, terminators left out.
+// An entry's ring index is its COMPACT pool position & mask: pool position minus the terminators in front of it, i.e.
+// off[v][n + 1] - (n + 1) + k for entry k of column n (every position contributes exactly one terminator).  A lane knows its
+// column's lists by (start, length) taken from the offset tables.
 struct SE6 { int g; unsigned key; double f; };
-__device__ __forceinline__ SE6 se6_read(const lchar *ring, const int idx)
+struct Ring6 { const lu32 *k; const lf64 *f; int mask; };
+__device__ __forceinline__ SE6 se6_read(const Ring6 &r, const int idx)
 {
-    const v4u32 v = *(const LDS v4u32 *) (ring + ((unsigned) idx << 4));
-    SE6 e; e.g = (int) v.x; e.key = v.y; e.f = __hiloint2double((int) v.w, (int) v.z); return e;
+    const int i = idx & r.mask;
+    SE6 e; e.key = r.k[i]; e.f = r.f[i]; e.g = (int) (e.key >> 16); return e;
 }
 
 // the row's static lists in registers: glen as lookup key ((g << 16) | 0xFFFF; slots behind the list: key 0xFFFF, freq 0) and freq;
 // ls / lt / lr: the lane's list lengths
 // The r view is not held: r = [head {glen 0, freq rhf}, if present] + the t list with glen + 1 (DevSide::r_from_t).
 template <int N> struct A6 { const unsigned (&sk)[N]; const double (&sf)[N]; const unsigned (&tk)[N]; const double (&tf)[N]; double rhf; int ls, lt; };
-struct B6 { const lchar *rs, *rt, *rr; int os, ot, orr, lens, mask; };      // the lane's column: ring bases, list starts, length of s
+struct B6 { Ring6 rs, rt, rr; int os, ot, orr, lens, lent, lenr; };         // the lane's column: rings, list starts (compact), lengths
 
 // one "X" merge: cf = the column's s list (ring, stretched by dlb of the record), df = a row list in registers (stretched by
 // dla): newgap(b.s, dlb, a.t|a.r, dla).  RV: df is the r view = an optional head entry {glen 0, freq hf} followed by the t
@@ -209,7 +214,7 @@ __device__ __forceinline__ double v6_xmerge(const DH<NE> &ha, const DH<NE> &hb, 
     }
     for (int kk = lmax - 1; kk >= 0; --kk) {
         const bool valid = kk < B.lens;
-        const SE6 e = se6_read(B.rs, (B.os + (valid ? kk : 0)) & B.mask);
+        const SE6 e = se6_read(B.rs, B.os + (valid ? kk : 0));
         const unsigned i = valid ? dh_stretch<NE, SCAN>(e.key, hb) : 0u;
         if (RV) Sh = i >= jh ? e.f : Sh;
         V6_UNROLL
@@ -281,9 +286,9 @@ __device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, cons
         bool l0 = true, l1 = do_vert, l2 = do_vert, l3 = do_vert && NOLL3;
         for (int d = 0; d < DL_GUARD; ++d) {
             if (wave_none(l0 || l1 || l2 || l3)) break;
-            const SE6 et = se6_read(B.rt, (B.ot + d) & B.mask), er = se6_read(B.rr, (B.orr + d) & B.mask);
-            l0 = l0 && et.g >= 0;
-            const bool lv = er.g >= 0;
+            const SE6 et = se6_read(B.rt, B.ot + d), er = se6_read(B.rr, B.orr + d);
+            l0 = l0 && d < B.lent;
+            const bool lv = d < B.lenr;
             l1 = l1 && lv; l2 = l2 && lv; l3 = l3 && lv;
             const unsigned j0 = dh_stretch<NE, SCAN>(et.key, b_hd), j1 = dh_stretch<NE, SCAN>(er.key, b_gu), j2 = dh_stretch<NE, SCAN>(er.key, b_hu);
             const unsigned j3 = NOLL3 ? dh_stretch<NE, SCAN>(er.key, b_g2) : 0u;
@@ -352,10 +357,11 @@ __device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, cons
         lu32 *const f_d2 = win == 3 ? dh + ca4 : nul, *const f2_d2 = win == 4 ? dh + ca4 : nul;
         for (int k = 0; k < DL_GUARD; ++k) {
             if (wave_none(n_f.on || n_h.on || (NOLL3 && n_f2.on))) break;
-            const SE6 e = se6_read(B.rt, (B.ot + k) & B.mask);
-            nd6_step<NE, SCAN>(n_f, h_fs, e.g, e.key, df + ca4, f_d2, sink);
-            nd6_step<NE, SCAN>(n_h, b_hd, e.g, e.key, dh + ca4, nul, sink);
-            if (NOLL3) nd6_step<NE, SCAN>(n_f2, h_fs2, e.g, e.key, df2 + ca4, f2_d2, sink);
+            const SE6 e = se6_read(B.rt, B.ot + k);
+            const int g = k < B.lent ? e.g : -1;
+            nd6_step<NE, SCAN>(n_f, h_fs, g, e.key, df + ca4, f_d2, sink);
+            nd6_step<NE, SCAN>(n_h, b_hd, g, e.key, dh + ca4, nul, sink);
+            if (NOLL3) nd6_step<NE, SCAN>(n_f2, h_fs2, g, e.key, df2 + ca4, f2_d2, sink);
         }
         nd6_fin(n_f, do_hori, df + ca4, f_d2, sink);
         nd6_fin(n_h, win == 0, dh + ca4, nul, sink);
@@ -454,27 +460,26 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
     while (__ballot(ls > TAs)) ++TAs;
     while (__ballot(lt > TAt)) ++TAt;
     // ---- the ring of the columns' static lists
-    const int rmask = LO.rs - 1;
-    lchar *const ringS = lds + LO.ring, *const ringT = ringS + (size_t) LO.rs * 16, *const ringR = ringT + (size_t) LO.rs * 16;
-    int fedcol = cbase - 1;                                // columns <= fedcol are in the ring
-    auto refill = [&](int upto) {                          // wave-uniform
-        if (upto > b.right - 1) upto = b.right - 1;
-        if (upto <= fedcol) return;
+    Ring6 ring[3];
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const GLB int *bo = v == 0 ? boff0 : v == 1 ? boff1 : boff2;
-            const int k0 = bo[fedcol + 2], k1 = bo[upto + 2];
-            lchar *const rg = v == 0 ? ringS : v == 1 ? ringT : ringR;
-            const GLB int *bgl = glb(b.glen[v]);
-            const GLB double *bfr = glb(b.freq[v]);
-            for (int k = k0 + lane; k < k1; k += 64) {
-                const int g = bgl[k];
-                const double f = bfr[k];
-                v4u32 w; w.x = (unsigned) g; w.y = v6_key(g); w.z = (unsigned) __double2loint(f); w.w = (unsigned) __double2hiint(f);
-                *(LDS v4u32 *) (rg + ((unsigned) (k & rmask) << 4)) = w;
+    for (int v = 0; v < 3; ++v) { ring[v].k = (const lu32 *) (lds + LO.ringk[v]); ring[v].f = (const lf64 *) (lds + LO.ringf[v]); ring[v].mask = LO.rs[v] - 1; }
+    int fedcol = cbase - 1;                                // columns <= fedcol are in the ring
+    auto refill = [&](int upto) {                          // wave-uniform; lane <-> (column, view): at most 16 columns x 3 views a time
+        if (upto > b.right - 1) upto = b.right - 1;
+        for (int c0_ = fedcol + 1; c0_ <= upto; c0_ += 21) {
+            const int col = c0_ + lane / 3, v = lane % 3;
+            if (lane < 63 && col <= upto) {
+                const GLB int *bo = v == 0 ? boff0 : v == 1 ? boff1 : boff2;
+                const int k0 = bo[col + 1], len = bo[col + 2] - k0 - 1, c = k0 - (col + 1);
+                const GLB int *bgl = glb(b.glen[v]);
+                const GLB double *bfr = glb(b.freq[v]);
+                lu32 *rk = (lu32 *) (lds + LO.ringk[v]);
+                lf64 *rf = (lf64 *) (lds + LO.ringf[v]);
+                const int mask = LO.rs[v] - 1;
+                for (int e = 0; e < len; ++e) { rk[(c + e) & mask] = v6_key(bgl[k0 + e]); rf[(c + e) & mask] = bfr[k0 + e]; }
             }
         }
-        fedcol = upto;
+        if (upto > fedcol) fedcol = upto;
     };
     // ---- the records this row starts from ------------------------------------------------------------
     RS oH = rs_black(), oG = rs_black(), oG2 = rs_black(), oF = rs_black(), oF2 = rs_black();
@@ -543,7 +548,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
     simblk_fill(P, SB, 0, m0, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     double sim_cur = 0, bc_cur = 0;
-    int os_cur = 0, oe_cur = 0, ot_cur = 0, or_cur = 0;
+    int os_cur = 0, oe_cur = 0, ot_cur = 0, te_cur = 0, or_cur = 0, re_cur = 0;       // starts / ends (pool positions) of the column's three lists
     bool have = false;
     RS hu = rs_black(), gu = rs_black(), g2u = rs_black(), hd;
     const bool do_vert = m > a.left;
@@ -615,15 +620,15 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
         }
         // -- loads for the next step: next column's score / thickness / list offsets; the strip above's records two columns ahead
         double sim_nx = 0, bc_nx = 0;
-        int os_nx = 0, oe_nx = 0, ot_nx = 0, or_nx = 0;
+        int os_nx = 0, oe_nx = 0, ot_nx = 0, te_nx = 0, or_nx = 0, re_nx = 0;
         if (active) {
             if (!have) {
                 sim_cur = *simblk_at(SB, lane, n); bc_cur = bthk[(size_t) (n + 1) * 3];
-                os_cur = boff0[n + 1]; oe_cur = boff0[n + 2]; ot_cur = boff1[n + 1]; or_cur = boff2[n + 1];
+                os_cur = boff0[n + 1]; oe_cur = boff0[n + 2]; ot_cur = boff1[n + 1]; te_cur = boff1[n + 2]; or_cur = boff2[n + 1]; re_cur = boff2[n + 2];
             }
             if (n + 1 < hi) {
                 sim_nx = *simblk_at(SB, lane, n + 1); bc_nx = bthk[(size_t) (n + 2) * 3];
-                os_nx = oe_cur; oe_nx = boff0[n + 3]; ot_nx = boff1[n + 2]; or_nx = boff2[n + 2];
+                os_nx = oe_cur; oe_nx = boff0[n + 3]; ot_nx = te_cur; te_nx = boff1[n + 3]; or_nx = re_cur; re_nx = boff2[n + 3];
             }
         }
         st_prev = n0 + 1 < hi0 && n0 + 2 <= c1;
@@ -633,9 +638,9 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
         if (active) {                                      // (loops inside are uniform over the ACTIVE lanes: ballots see only them)
             const bool do_hori = n > b.left;
             B6 B;
-            B.rs = ringS; B.rt = ringT; B.rr = ringR; B.mask = rmask;
-            B.os = os_cur; B.ot = ot_cur; B.orr = or_cur;
-            B.lens = oe_cur - os_cur - 1;
+            B.rs = ring[0]; B.rt = ring[1]; B.rr = ring[2];
+            B.os = os_cur - (n + 1); B.ot = ot_cur - (n + 1); B.orr = or_cur - (n + 1);          // compact positions (see Ring6)
+            B.lens = oe_cur - os_cur - 1; B.lent = te_cur - ot_cur - 1; B.lenr = re_cur - or_cur - 1;
             const bool up_in = do_vert && (n - (m - 1) <= P.up);          // cell (m-1, n) exists
             const bool left_in = (n - 1 - m >= P.lw);                      // cell (m, n-1) exists
             const RS bk = rs_black();
@@ -671,7 +676,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
             p_tri = (size_t) (d - P.d0) * P.tstride + (m - mlo);
             p_trb = trb;
             sim_cur = sim_nx; bc_cur = bc_nx; have = (n + 1 < hi);
-            os_cur = os_nx; oe_cur = oe_nx; ot_cur = ot_nx; or_cur = or_nx;
+            os_cur = os_nx; oe_cur = oe_nx; ot_cur = ot_nx; te_cur = te_nx; or_cur = or_nx; re_cur = re_nx;
             if (m == a.right - 1 && n == b.right - 1) *P.score = myH.val;
         }
         p_act = active;

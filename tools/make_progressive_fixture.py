@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tests/golden/prog256x1024.npz: the REFERENCE's own progressive alignment of the bench family (256 proteins x 1024 aa,
+"""tests/golden/msa/prog256x1024.npz: the REFERENCE's own progressive alignment of the bench family (256 proteins x 1024 aa,
 prrn_aln_amd/synth.py seed 1) -- `prrn5 -YH0 -S0 seqs.fa`, i.e. guide forest + progressive alignment, no refinement -- as
 the start MSA of bench.py's second workload (refinement starts from the serial progressive MSA,
 which is shorter and rougher than the synthetic true alignment).  Data only: residue codes, members in family order.
@@ -49,7 +49,7 @@ def main():
     for r, t in zip(msa, fam.msa):
         assert r.replace("-", "") == t.replace("-", "")
     codes = op.encode(msa, op.PROTEIN)
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "prog256x1024.npz"), codes=codes)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "msa", "prog256x1024.npz"), codes=codes)
     print("progressive MSA: %d members x %d columns (true alignment: %d columns)" % (codes.shape[1], codes.shape[0], len(fam.msa[0])))
 
 
