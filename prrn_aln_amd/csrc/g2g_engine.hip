@@ -19,6 +19,7 @@
 #include "g2g_kernels_v2.hip"
 #include "g2g_kernels_v3.hip"
 #include "g2g_kernels_v6.hip"
+#include "g2g_kernels_v7.hip"
 
 static thread_local std::string g_err;
 void g2g_set_error(const char *fmt, const char *a)
@@ -194,7 +195,7 @@ struct g2g_batch {
     int v2_maxcols;                 // longest b-range ...
     size_t simtile_lds;             // LDS of the tiled column-score kernel
     V2Tile *d_tiles;                // tiles: per variant (v2: hf2, hf3, pf2, pf3; v3: the same four) a queue ordered by wavefront i + j
-    int var_off[17];                // variant v owns tiles [var_off[v], var_off[v+1])
+    int var_off[25];                // variant v owns tiles [var_off[v], var_off[v+1])
     V3Lds v3lds[8];                 // LDS plan of the v3 variants
     V6Lds v6lds[4];                 // LDS plans of the v6 (_pf, one lane per cell, rank-form merges) launches: Noll 2, 3 x {small, large} footprint
     int v2_cols;
@@ -202,7 +203,7 @@ struct g2g_batch {
     int v2_sweep;                   // v2 (_pf): the same
     int v3_sweep;                   // v3r (_hf): strips as a pipeline with progress counters (one tile per strip)
     int v3_cols;                    // columns per v3 tile
-    int *d_flags;                   // [0..15] queue heads, [16..19] incident report, [20..] tile-completion flags (generation numbers)
+    int *d_flags;                   // [0, G2G_HDR) queue heads, [G2G_HDR, +4) header of the waits, then tile flags / progress counters, then per-DP fail flags
     int nflags, gen;
     std::vector<int> flags0;        // initial contents of d_flags (re-uploaded when the 11-bit generation of the progress counters wraps)
     long long ntiles;
@@ -575,6 +576,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         d.trace = OFF<uint8_t>(take((size_t) (d.d1 - d.d0 + 1) * tmax));
         // v2 kernel (gap-profile engines): packed 16-bit gap lengths and an LDS budget decide eligibility
         d.v2_ok = 0;
+        if (d.kind == 0 && !force_v1 && !getenv("G2G_FORCE_V1") && !getenv("G2G_NO_V7")) d.v2_ok = 7;      // DPunit: strips without gap state
         if ((d.kind == 1 || d.kind == 2) && !force_v1 && !getenv("G2G_FORCE_V1") && p->a.len + p->b.len < 65000) {
             // _pf: one lane per cell with rank-form merges (v6) when the rows' static lists fit the register file
             if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_V6") && !getenv("G2G_V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V6_NA && d.a.r_from_t &&
@@ -612,7 +614,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
             if (d.noll == 3) d.v2_cbF2 = OFF<void>(take(recsz * ((size_t) (ar - al) + 3)));
             d.v2_rowoff = OFF<long long>(take(sizeof(long long) * ((size_t) (ar - al) + 2)));
             // the column-score matrix: only for DPs whose kernel reads one (strips in sweep mode make their own, block by block)
-            const bool own_sim = !getenv("G2G_NO_SIMBLK") && (d.v2_ok == 6 || (d.v2_ok == 1 && b->v2_sweep) || ((d.v2_ok == 2 || d.v2_ok == 3) && d.kind == 1 && b->v3_sweep));
+            const bool own_sim = !getenv("G2G_NO_SIMBLK") && (d.v2_ok == 6 || d.v2_ok == 7 || (d.v2_ok == 1 && b->v2_sweep) || ((d.v2_ok == 2 || d.v2_ok == 3) && d.kind == 1 && b->v3_sweep));
             if (!own_sim) d.v2_sim = OFF<double>(take(sizeof(double) * (size_t) cells + 64));
         }
         b->rr1[i] = (long long) (bl_ - al) + (br - ar);
@@ -679,9 +681,9 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
     // ordered by wavefront i + j; one completion flag per tile slot (empty slots count as done for ever)
     b->d_tiles = 0; b->d_idxp = 0; b->np = 0; b->ntiles = 0; b->lds2p = 0; b->v2_maxrows = 1; b->v2_maxcols = 1; b->simtile_lds = 0; b->d_flags = 0; b->nflags = 0; b->gen = 0;
     {
-        std::vector<std::vector<std::vector<V2Tile> > > q(16);   // [variant][wavefront] -> tiles
-        std::vector<int> flags(20, 0);                    // 0-15 queue heads, 16-19 incident report
-        std::vector<V2Tile> pre[16];                      // boundary chains of sweep-mode DPs: they head their variant's queue
+        std::vector<std::vector<std::vector<V2Tile> > > q(G2G_HDR);   // [variant][wavefront] -> tiles
+        std::vector<int> flags(G2G_HDR + 4, 0);           // queue heads, then the header of the waits (g2g_wait_ge)
+        std::vector<V2Tile> pre[G2G_HDR];                 // boundary chains of sweep-mode DPs: they head their variant's queue
         std::vector<int> ip;                              // the other DPs: chains in the prologue kernel
         const bool chainq = !getenv("G2G_NO_CHAINQ");
         int v6rows[4] = {0, 0, 0, 0}, v6ca4[4] = {0, 0, 0, 0};
@@ -702,23 +704,24 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
             const int al = d.a.left, ar = d.a.right, bl_ = d.b.left, br = d.b.right;
             const int R = d.v2_ok >= 2 ? 64 : b->v2_threads / 8;
             const bool swp3 = (d.v2_ok == 3 || d.v2_ok == 2) && d.kind == 1 && b->v3_sweep;   // one tile per strip, pipelined (kind 1 only: no column pool)
-            const bool swp2 = (d.v2_ok == 1 && b->v2_sweep) || d.v2_ok == 6;     // (v6 knows sweep mode only)
+            const bool swp2 = (d.v2_ok == 1 && b->v2_sweep) || d.v2_ok >= 6;     // (v6 and v7 know sweep mode only)
             const int C = (swp3 || swp2) ? (1 << 20) : d.v2_ok >= 2 ? b->v3_cols : b->v2_cols;
             const int nstrip = (ar - al + R - 1) / R, nblk = (br - bl_ + C - 1) / C;
             // (one LDS plan per launch = the largest of its DPs: DPs whose column lists need a big ring get a launch of their own,
             //  or a handful of balanced divisions would cost every strip of the sweep its occupancy)
-            const int var = d.v2_ok == 6 ? 12 + (d.noll == 3 ? 1 : 0) + (v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(prob[i])).total > V6_CLASS_A ? 2 : 0) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
+            const int var = d.v2_ok == 7 ? 16 + (d.noll == 3 ? 1 : 0) : d.v2_ok == 6 ? 12 + (d.noll == 3 ? 1 : 0) + (v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(prob[i])).total > V6_CLASS_A ? 2 : 0) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
             if (d.v2_ok == 6) {
                 v6rows[var - 12] = std::max(v6rows[var - 12], v6_rows_bytes(d));
                 v6ca4[var - 12] = std::max(v6ca4[var - 12], (d.capa + 3) & ~3);
                 { const V6Ring rn = v6_ring_need(prob[i]); for (int q = 0; q < 3; ++q) v6rs[var - 12].rs[q] = std::max(v6rs[var - 12].rs[q], rn.rs[q]); }
+            } else if (d.v2_ok == 7) {
             } else if (d.v2_ok >= 2) {
                 const V3Need nd = v3_need(d, prob[i], C, d.v2_ok == 3);
                 V3Need &x = need[var - 4];
                 x.rows_bytes = std::max(x.rows_bytes, nd.rows_bytes); x.ca4 = std::max(x.ca4, nd.ca4);
                 x.apool = std::max(x.apool, nd.apool); x.bpool = std::max(x.bpool, nd.bpool);
             }
-            const bool cq = chainq && (swp2 || swp3);
+            const bool cq = (chainq && (swp2 || swp3)) || d.v2_ok == 7;      // (v7's chains always run as queue entries: the prologue kernel knows the gap-profile kinds only)
             int ftop = -1, fleft = -1;
             if (cq) {
                 ftop = (int) flags.size(); fleft = ftop + 1;
@@ -757,12 +760,12 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
             }
         }
         std::vector<V2Tile> all;
-        for (int v = 0; v < 16; ++v) {
+        for (int v = 0; v < G2G_HDR; ++v) {
             b->var_off[v] = (int) all.size();
             all.insert(all.end(), pre[v].begin(), pre[v].end());
             for (size_t k = 0; k < q[v].size(); ++k) all.insert(all.end(), q[v][k].begin(), q[v][k].end());
         }
-        b->var_off[16] = (int) all.size();
+        b->var_off[G2G_HDR] = (int) all.size();
         for (int v = 0; v < 4; ++v) b->v6lds[v] = v6_layout(v6rows[v], v6ca4[v], v6rs[v]);
         for (int v = 0; v < 8; ++v) b->v3lds[v] = v3_layout(need[v].rows_bytes, need[v].ca4, need[v].apool, need[v].bpool, b->v3_cols);
         // test hook: G2G_INJECT_STALL=<i> makes the first strip / tile of problem i depend on a flag nobody ever writes
@@ -853,12 +856,12 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             ++b->gen;
         }
         {   // queue heads; header of the waits (g2g_wait_ge): time-outs, first slot, offset of the fail flags, wall-clock limit
-            int hdr[20];
+            int hdr[G2G_HDR + 4];
             memset(hdr, 0, sizeof hdr);
             double limit_ms = 20000.;
             if (const char *e = getenv("G2G_WAIT_LIMIT_MS")) { const double v = atof(e); if (v > 0) limit_ms = v; }
-            hdr[18] = b->fail_off;
-            hdr[19] = (int) std::min(2.0e9, limit_ms * ctx->rt_ticks_per_ms / 65536.) + 1;
+            hdr[G2G_HDR + 2] = b->fail_off;
+            hdr[G2G_HDR + 3] = (int) std::min(2.0e9, limit_ms * ctx->rt_ticks_per_ms / 65536.) + 1;
             HIPCHK(hipMemcpyAsync(b->d_flags, hdr, sizeof hdr, hipMemcpyHostToDevice, ctx->stream));
             HIPCHK(hipMemsetAsync(b->d_flags + b->fail_off, 0, sizeof(int) * (size_t) (b->n > 0 ? b->n : 1), ctx->stream));
         }
@@ -960,7 +963,26 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipEventRecord(ctx->vev[jev], vs));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[jev], 0));
         }
-    }
+            for (int v = 0; v < 2; ++v) {                        // v7: DPunit strips (no gap state, no LDS to speak of)
+            const int cnt = b->var_off[v + 17] - b->var_off[v + 16];
+            if (!cnt) continue;
+            typedef void (*v7k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int, double *);
+            static const v7k_t v7k[2] = {g2g_v7_ngp2, g2g_v7_ngp3};
+            hipStream_t vs = ctx->vstream[4 + v];
+            HIPCHK(hipStreamWaitEvent(vs, ctx->vev[4], 0));
+            const int grid = std::min(cnt, ncu * 16);
+            const int pint = b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= ncu * 16 ? 4 : cnt < 4 * ncu * 16 ? 16 : 32;
+            double *simscr7 = sim_scratch(16 + v, grid);
+            if (!simscr7) { g2g_set_error("%s", "hipMalloc(column-score scratch)"); return G2G_ERR_NOMEM; }
+            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v7 variant %d: %d strips, grid %d, publish every %d, gen %d\n", v, cnt, grid, pint, b->gen); fflush(stderr); }
+            hipLaunchKernelGGL(v7k[v], dim3(grid), dim3(64), 0, vs, (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v + 16]), cnt,
+                               b->d_flags + 16 + v, b->d_flags, b->gen, pint, simscr7);
+            HIPCHK(hipGetLastError());
+            if (getenv("G2G_DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v7 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
+            HIPCHK(hipEventRecord(ctx->vev[5 + v], vs));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[5 + v], 0));
+        }
+}
     if (b->n1) {
         if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v1 (state in HBM): %d of %d problems\n", b->n1, b->n); fflush(stderr); }
         hipLaunchKernelGGL(g2g_forward_kernel, dim3(b->n1), dim3(G2G_FWD_THREADS), 0, ctx->stream,
@@ -973,16 +995,16 @@ extern "C" int g2g_batch_run(g2g_batch *b)
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (b->d_flags) {
-        int rep[20];
+        int rep[G2G_HDR + 4];
         HIPCHK(hipMemcpy(rep, b->d_flags, sizeof rep, hipMemcpyDeviceToHost));
-        if (rep[16]) {
+        if (rep[G2G_HDR]) {
             // Some wait ran into the wall-clock limit.  Only the DPs marked in the fail array are lost; they are re-run here, in
             // the same call, on the kernel that polls nothing (one workgroup per DP, state in HBM).
             std::vector<int> fail(b->n);
             HIPCHK(hipMemcpy(fail.data(), b->d_flags + b->fail_off, sizeof(int) * (size_t) b->n, hipMemcpyDeviceToHost));
             std::vector<int> lost;
             for (int i = 0; i < b->n; ++i) if (fail[i] && !b->status[i]) lost.push_back(i);
-            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] s_memrealtime: %.0f ticks/ms; ", ctx->rt_ticks_per_ms); fprintf(stderr, "[g2g] %d waits timed out (first: queue slot %d): re-running %zu DP(s) on g2g_forward_kernel\n", rep[16], rep[17], lost.size()); fflush(stderr); }
+            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] s_memrealtime: %.0f ticks/ms; ", ctx->rt_ticks_per_ms); fprintf(stderr, "[g2g] %d waits timed out (first: queue slot %d): re-running %zu DP(s) on g2g_forward_kernel\n", rep[G2G_HDR], rep[G2G_HDR + 1], lost.size()); fflush(stderr); }
             if (b->force_v1 || lost.empty()) { g2g_set_error("%s", "scheduler: a wait timed out and no DP could be singled out"); return G2G_ERR_DEVICE; }
             std::vector<const g2g_problem *> pp;
             for (int i : lost) pp.push_back(b->src[i]);

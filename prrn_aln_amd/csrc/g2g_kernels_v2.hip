@@ -36,8 +36,9 @@ __device__ unsigned long long g2g_stamp_acc[16];
 // bound is therefore WALL CLOCK (s_memrealtime: 100 MHz, keeps running while a wave is descheduled), set per launch by the
 // host (hdr[3], units of 65536 ticks = 0.655 ms), and a time-out costs ONE DP, not the batch: the DP is marked in the
 // batch's fail array, every other wait of that DP gives up at its next check, its remaining strips are skipped, and
-// g2g_batch_run re-runs the marked DPs on the non-polling kernel (g2g_forward_kernel).  hdr = done + 16:
+// g2g_batch_run re-runs the marked DPs on the non-polling kernel (g2g_forward_kernel).  hdr = done + G2G_HDR:
 // [0] time-outs, [1] queue slot of the first, [2] offset of the fail array from `done`, [3] the limit.
+#define G2G_HDR 24                   // d_flags: [0, 24) queue heads of the kernel variants, [24, 28) this header, tile flags behind
 __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hdr, int *failp, const int slot)
 {
     int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1299,7 +1300,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
             __syncthreads();                                                                        \
             continue;                                                                               \
         }                                                                                           \
-        int *failp = done + done[18] + T.prob;                                                      \
+        int *failp = done + done[G2G_HDR + 2] + T.prob;                                                      \
         if (threadIdx.x == 0) s_vals[0] = g2g_dp_failed(failp) ? 1 : 0;      /* (one reader: the branch must be uniform) */ \
         __syncthreads();                                                                            \
         const int dp_dead = s_vals[0];                                                              \
@@ -1315,16 +1316,16 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         int *ps = sweep ? done + T.self : (int *) 0;                                                \
         V2_WAIT_T0                                                                                  \
         if (!sweep) {                                                                               \
-            if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t, failp);             \
-            if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t, failp);         \
-            if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t, failp);         \
-            if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t, failp);           \
+            if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + G2G_HDR, t, failp);             \
+            if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + G2G_HDR, t, failp);         \
+            if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + G2G_HDR, t, failp);         \
+            if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + G2G_HDR, t, failp);           \
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                      \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
         }                                                                                           \
         __syncthreads();                                                                            \
         V2_WAIT_T1                                                                                  \
-        v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen, sweep, pl, \
+        v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + G2G_HDR, gen, sweep, pl, \
                           (sweep && simscr) ? simscr + (size_t) blockIdx.x * (3 * 4096) : (double *) 0, failp); \
         V2_WAIT_T2                                                                                  \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \

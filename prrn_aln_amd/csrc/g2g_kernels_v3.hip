@@ -938,7 +938,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
             __syncthreads();                                                                        \
             continue;                                                                               \
         }                                                                                           \
-        int *failp = done + done[18] + T.prob;                                                      \
+        int *failp = done + done[G2G_HDR + 2] + T.prob;                                                      \
         if (threadIdx.x == 0) s_vals[0] = g2g_dp_failed(failp) ? 1 : 0;      /* (one reader: the branch must be uniform) */ \
         __syncthreads();                                                                            \
         const int dp_dead = s_vals[0];                                                              \
@@ -954,15 +954,15 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         const int *pu = (sweep && T.dep_up >= 0) ? done + T.dep_up : (const int *) 0;                \
         int *ps = sweep ? done + T.self : (int *) 0;                                                \
         if (!sweep) {                                                                               \
-            if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + 16, t, failp);             \
-            if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + 16, t, failp);         \
-            if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + 16, t, failp);         \
-            if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + 16, t, failp);           \
+            if (T.dep_up >= 0) v2_wait_flag(done + T.dep_up, gen, done + G2G_HDR, t, failp);             \
+            if (T.dep_left >= 0) v2_wait_flag(done + T.dep_left, gen, done + G2G_HDR, t, failp);         \
+            if (T.dep_diag >= 0) v2_wait_flag(done + T.dep_diag, gen, done + G2G_HDR, t, failp);         \
+            if (T.dep_war >= 0) v2_wait_flag(done + T.dep_war, gen, done + G2G_HDR, t, failp);           \
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                      \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
         }                                                                                           \
         __syncthreads();                                                                            \
-        v3_tile<KIND, N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + 16, gen, sweep, pl, \
+        v3_tile<KIND, N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + G2G_HDR, gen, sweep, pl, \
                               (sweep && simscr) ? simscr + (size_t) blockIdx.x * (3 * 4096) : (double *) 0, failp); \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \

@@ -710,7 +710,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
             __syncthreads();                                                                        \
             continue;                                                                               \
         }                                                                                           \
-        int *failp = done + done[18] + T.prob;                                                      \
+        int *failp = done + done[G2G_HDR + 2] + T.prob;                                                      \
         if (threadIdx.x == 0) s_vals[0] = g2g_dp_failed(failp) ? 1 : 0;      /* (one reader: the branch must be uniform) */ \
         __syncthreads();                                                                            \
         const int dp_dead = s_vals[0];                                                              \
@@ -723,7 +723,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         const int *pl = T.dep_left >= 0 ? done + T.dep_left : (const int *) 0;                      \
         const int *pu = T.dep_up >= 0 ? done + T.dep_up : (const int *) 0;                          \
         __syncthreads();                                                                            \
-        v6_strip<N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, T.nsteps, pu, done + T.self, done + 16, gen, pint, pl, \
+        v6_strip<N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, T.nsteps, pu, done + T.self, done + G2G_HDR, gen, pint, pl, \
                          simscr + (size_t) blockIdx.x * (3 * 4096), failp); \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \

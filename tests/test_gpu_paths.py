@@ -29,6 +29,7 @@ CONFIGS = {
     "v3lds_all": {"G2G_NO_AREG": "1", "G2G_V3_PF": "1"},
     "v3lds_all_cols32": {"G2G_NO_AREG": "1", "G2G_V3_PF": "1", "G2G_V3_COLS": "32", "G2G_V3_SWEEP": "0"},   # tile mode
     "v3_pf": {"G2G_V3_PF": "1", "G2G_V3_COLS": "64"},
+    "no_v7": {"G2G_NO_V7": "1"},                                     # DPunit on v1 instead of the strip kernel
     "no_v6": {"G2G_NO_V6": "1"},                                     # _pf on the 8-lanes-per-cell kernel instead of v6
     "v6_publish4": {"G2G_V2_SWEEP": "4"},                            # progress counters published every 4 steps
     "v2": {"G2G_FORCE_V2": "1"},
