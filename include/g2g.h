@@ -141,6 +141,15 @@ const char *g2g_last_error(void);
 int      g2g_abi_version(void);
 /* 1 if a HIP device + gfx950 code object are usable, else 0 (never falls back to the host). */
 int      g2g_device_ok(g2g_ctx *ctx);
+/* Tuning and diagnostic switches of ONE context (kernel-variant selection, strip widths, the waits' time limit, arena
+   limits, debug output: DESIGN.md section 4 lists the names).  `name` is given with or without the "G2G_" prefix.
+   A switch the context has not set reads the environment variable G2G_<NAME> (the environment only supplies
+   defaults); value == NULL turns a switch off for this context whatever the environment says.  Takes effect at the
+   next g2g_batch_prepare / g2g_forward_batch.  g2g_get_option returns the effective value or NULL (valid until the
+   next g2g_set_option on the context). */
+int         g2g_set_option(g2g_ctx *ctx, const char *name, const char *value);
+const char *g2g_get_option(const g2g_ctx *ctx, const char *name);
+void        g2g_reset_options(g2g_ctx *ctx);     /* forget every g2g_set_option: back to the environment's defaults */
 
 /* Fwd2c<recd_t>(seqs, pwd, trb=true).forwardB() + traceback() for a batch of independent problems
    (alignC<recd_t>, reference src/fwd2c.h:671-677).  res[i].trace is malloc'ed by the library. */

@@ -29,6 +29,10 @@ def lib():
     L.g2g_destroy.argtypes = [C.c_void_p]
     L.g2g_last_error.restype = C.c_char_p
     L.g2g_device_ok.argtypes = [C.c_void_p]
+    L.g2g_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    L.g2g_reset_options.argtypes = [C.c_void_p]
+    L.g2g_get_option.restype = C.c_char_p
+    L.g2g_get_option.argtypes = [C.c_void_p, C.c_char_p]
     PP = C.POINTER(C.POINTER(_abi.Problem))
     L.g2g_forward_batch.argtypes = [C.c_void_p, C.c_int, PP, C.POINTER(_abi.Result)]
     L.g2g_batch_prepare.argtypes = [C.c_void_p, C.c_int, PP, C.POINTER(C.c_void_p)]

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <map>
 #include <vector>
 #include <thread>
 #include <atomic>
@@ -43,9 +44,38 @@ struct g2g_ctx {
     hipEvent_t vev[7];              // 0-3, 5-6: join events of the variant streams; 4: fork event
     char *stage; size_t stage_cap;  // pinned host staging buffer of g2g_batch_prepare, kept between calls
     double rt_ticks_per_ms;         // rate of s_memrealtime on this device, measured at g2g_create (the waits' time limit is wall clock)
+    std::map<std::string, std::pair<bool, std::string>> opt;   // g2g_set_option: name -> (present, value); see g2g_opt
     char *spare; size_t spare_bytes; // one device arena kept from the last freed batch (hipMalloc/hipFree of tens of GB per
                                     // call cost up to a second); contents are as undefined as a fresh allocation's
 };
+
+// Tuning and diagnostic switches belong to a context (g2g_set_option / g2g_get_option); a name a context has not set
+// reads the process environment variable G2G_<NAME>, so the environment only supplies defaults.  A switch is "on" when it
+// has a value (any, also the empty string) and "off" when g2g_set_option was given NULL for it.
+static const char *g2g_opt(const g2g_ctx *c, const char *name)
+{
+    if (c) {
+        auto it = c->opt.find(name);
+        if (it != c->opt.end()) return it->second.first ? it->second.second.c_str() : 0;
+    }
+    char env[96];
+    snprintf(env, sizeof env, "G2G_%s", name);
+    return getenv(env);
+}
+extern "C" int g2g_set_option(g2g_ctx *c, const char *name, const char *value)
+{
+    if (!c || !name || !*name || strlen(name) > 64) { g2g_set_error("g2g_set_option: %s", "bad argument"); return G2G_ERR_ARG; }
+    if (!strncmp(name, "G2G_", 4)) name += 4;
+    c->opt[name] = std::make_pair(value != 0, std::string(value ? value : ""));
+    return G2G_OK;
+}
+extern "C" void g2g_reset_options(g2g_ctx *c) { if (c) c->opt.clear(); }
+extern "C" const char *g2g_get_option(const g2g_ctx *c, const char *name)
+{
+    if (!name) return 0;
+    if (!strncmp(name, "G2G_", 4)) name += 4;
+    return g2g_opt(c, name);
+}
 
 extern "C" __global__ void g2g_clock_kernel(unsigned long long *out) { *out = __builtin_amdgcn_s_memrealtime(); }
 
@@ -122,7 +152,8 @@ struct Blob {                       // host image of the input part of the arena
     std::vector<Copy> later;        // big copies are deferred and done by a few host threads at once (flush)
     g2g_ctx *owner;                 // the buffer is the context's pinned staging area: it outlives the Blob (no page
                                     // faults and a DMA-able source on every call after the first)
-    explicit Blob(g2g_ctx *c) : p(c->stage), sz(0), cap(c->stage_cap), owner(c), oom(false) {}
+    int pack_threads;               // option PACK_THREADS (0: one per core, at most 16)
+    explicit Blob(g2g_ctx *c) : p(c->stage), sz(0), cap(c->stage_cap), owner(c), pack_threads(0), oom(false) {}
     ~Blob() { owner->stage = p; owner->stage_cap = cap; }
     Blob(const Blob &) = delete;
     Blob &operator=(const Blob &) = delete;
@@ -155,7 +186,7 @@ struct Blob {                       // host image of the input part of the arena
         unsigned nthr = std::thread::hardware_concurrency();
         if (nthr > 16) nthr = 16;
         if (nthr < 1) nthr = 1;
-        if (const char *e = getenv("G2G_PACK_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) nthr = (unsigned) v; }
+        if (pack_threads >= 1 && pack_threads <= 64) nthr = (unsigned) pack_threads;
         if (nthr > later.size()) nthr = (unsigned) later.size();
         std::atomic<size_t> next(0);
         auto work = [&]() { for (size_t k; (k = next.fetch_add(1)) < later.size(); ) memcpy(p + later[k].off, later[k].src, later[k].bytes); };
@@ -269,8 +300,8 @@ static V6Lds v6_layout(int rows_bytes, int ca4max, const V6Ring &R)
 // A launch has ONE LDS plan, the largest of its DPs, and LDS decides how many strips a CU holds: v6 DPs are dealt to two
 // launches by footprint -- up to 40 KB (four strips per CU) and up to 53 KB (three) -- and DPs above that stay on v2, which
 // beats v6 at two strips per CU (measured: 779 ms per bench sweep with the limit at 53 KB, 1015 ms at 64 KB).
-static int v6_small_lds() { static const int v = getenv("G2G_V6_SMALL_KB") ? atoi(getenv("G2G_V6_SMALL_KB")) * 1024 : 53 * 1024; return v; }
-#define V6_SMALL_LDS (v6_small_lds())
+static int v6_small_lds(const g2g_ctx *c) { const char *e = g2g_opt(c, "V6_SMALL_KB"); return e ? atoi(e) * 1024 : 53 * 1024; }
+#define V6_SMALL_LDS (v6_small_lds(ctx))
 static const int V6_CLASS_A = 40 * 1024;
 static int v6_rows_bytes(const DevProb &d)
 {
@@ -428,7 +459,7 @@ static void release_arena(g2g_batch *b)
 {
     if (!b->d_arena) return;
     g2g_ctx *c = b->ctx;
-    if (getenv("G2G_NO_ARENA_CACHE")) hipFree(b->d_arena);
+    if (g2g_opt(c, "NO_ARENA_CACHE")) hipFree(b->d_arena);
     else if (!c->spare) { c->spare = b->d_arena; c->spare_bytes = b->arena_cap; }
     else if (c->spare_bytes < b->arena_cap) { hipFree(c->spare); c->spare = b->d_arena; c->spare_bytes = b->arena_cap; }
     else hipFree(b->d_arena);
@@ -446,7 +477,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
     if (n > G2G_MAX_BATCH) { g2g_set_error("%s", "g2g_batch_prepare: more than 32768 problems in one batch (use g2g_forward_batch, which cuts chunks)"); return G2G_ERR_ARG; }
     if (!ctx->ok) return G2G_ERR_NODEVICE;
     HIPCHK(hipSetDevice(ctx->device));
-    const bool prep_dbg = getenv("G2G_DEBUG_PREP") != 0;
+    const bool prep_dbg = g2g_opt(ctx, "DEBUG_PREP") != 0;
     auto prep_t0 = std::chrono::steady_clock::now();
     auto prep_lap = [&](const char *what) {
         if (!prep_dbg) return;
@@ -463,6 +494,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
 
     b->dp.resize(n); b->status.assign(n, G2G_OK); b->cells.assign(n, 0); b->out_off.assign(n, 0); b->tcap.assign(n, 0); b->rr1.assign(n, 0);
     Blob bl(ctx);
+    if (const char *e = g2g_opt(ctx, "PACK_THREADS")) bl.pack_threads = atoi(e);
     {   // size the staging buffer once (growing a pinned buffer means allocating and copying it again)
         auto side_bytes = [](const g2g_side &s) {
             const size_t cols = (size_t) s.len + 2;
@@ -525,12 +557,12 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         // on a full sweep), 32-row strips otherwise (half as many strips on a DP's critical path)
         b->v2_threads = 128;
         if (pick(2, 16, 128, 64, ncu * 6) != 128) b->v2_threads = 256;      // (measured crossover: between 1/4 and 1/8 of the bench sweep)
-        if (const char *e = getenv("G2G_V2_THREADS")) { const int t = atoi(e); if (t == 128 || t == 256) b->v2_threads = t; }
+        if (const char *e = g2g_opt(ctx, "V2_THREADS")) { const int t = atoi(e); if (t == 128 || t == 256) b->v2_threads = t; }
         b->v2_cols = pick(2, b->v2_threads / 8, G2G_V2_TILE_COLS, 64, ncu * (768 / b->v2_threads));
-        if (const char *e = getenv("G2G_V2_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v2_cols = c; }
-        if (const char *e = getenv("G2G_V3_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v3_cols = c; }
-        b->v3_sweep = getenv("G2G_V3_SWEEP") ? atoi(getenv("G2G_V3_SWEEP")) : 1;
-        b->v2_sweep = getenv("G2G_V2_SWEEP") ? atoi(getenv("G2G_V2_SWEEP")) : 1;
+        if (const char *e = g2g_opt(ctx, "V2_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v2_cols = c; }
+        if (const char *e = g2g_opt(ctx, "V3_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v3_cols = c; }
+        b->v3_sweep = g2g_opt(ctx, "V3_SWEEP") ? atoi(g2g_opt(ctx, "V3_SWEEP")) : 1;
+        b->v2_sweep = g2g_opt(ctx, "V2_SWEEP") ? atoi(g2g_opt(ctx, "V2_SWEEP")) : 1;
     }
     // index lists for the two forward kernels (filled below, once eligibility is known)
     const size_t idx_off = bl.put(0, 0);
@@ -576,12 +608,12 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         d.trace = OFF<uint8_t>(take((size_t) (d.d1 - d.d0 + 1) * tmax));
         // v2 kernel (gap-profile engines): packed 16-bit gap lengths and an LDS budget decide eligibility
         d.v2_ok = 0;
-        if (d.kind == 0 && !force_v1 && !getenv("G2G_FORCE_V1") && !getenv("G2G_NO_V7")) d.v2_ok = 7;      // DPunit: strips without gap state
-        if ((d.kind == 1 || d.kind == 2) && !force_v1 && !getenv("G2G_FORCE_V1") && p->a.len + p->b.len < 65000) {
+        if (d.kind == 0 && !force_v1 && !g2g_opt(ctx, "FORCE_V1") && !g2g_opt(ctx, "NO_V7")) d.v2_ok = 7;      // DPunit: strips without gap state
+        if ((d.kind == 1 || d.kind == 2) && !force_v1 && !g2g_opt(ctx, "FORCE_V1") && p->a.len + p->b.len < 65000) {
             // _pf: one lane per cell with rank-form merges (v6) when the rows' static lists fit the register file
-            if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_V6") && !getenv("G2G_V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V6_NA && d.a.r_from_t &&
+            if (!g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_V6") && !g2g_opt(ctx, "V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V6_NA && d.a.r_from_t &&
                 v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(p)).total <= V6_SMALL_LDS) d.v2_ok = 6;
-            else if (!getenv("G2G_FORCE_V2") && !getenv("G2G_NO_AREG") && (d.kind == 1 || getenv("G2G_V3_PF")) && d.a.maxlist <= G2G_V3_NA &&
+            else if (!g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_AREG") && (d.kind == 1 || g2g_opt(ctx, "V3_PF")) && d.a.maxlist <= G2G_V3_NA &&
                 v3_need(d, p, b->v3_cols, true).total <= (int) V2_LDS_MAX) d.v2_ok = 3;
             else {
                 // lists too long for registers: the LDS-list one-lane-per-cell kernel, unless its LDS footprint leaves fewer than
@@ -591,8 +623,8 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
                 // group has columns, so sides of 32768 columns or more are not eligible -- they stay on v3 / v1, which keep 32 bits)
                 const bool v2fit = std::max(p->a.len, p->b.len) < 32768 &&
                     v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist, b->v2_threads) + 4 * b->v2_threads <= V2_LDS_MAX;
-                const int v3tot = (!getenv("G2G_FORCE_V2") && (d.kind == 1 || getenv("G2G_V3_PF"))) ? v3_need(d, p, b->v3_cols).total : (int) V2_LDS_MAX + 1;
-                if (v3tot <= (int) V2_LDS_MAX && (v3tot <= (int) V2_LDS_MAX / 3 || !v2fit || getenv("G2G_NO_AREG"))) d.v2_ok = 2;
+                const int v3tot = (!g2g_opt(ctx, "FORCE_V2") && (d.kind == 1 || g2g_opt(ctx, "V3_PF"))) ? v3_need(d, p, b->v3_cols).total : (int) V2_LDS_MAX + 1;
+                if (v3tot <= (int) V2_LDS_MAX && (v3tot <= (int) V2_LDS_MAX / 3 || !v2fit || g2g_opt(ctx, "NO_AREG"))) d.v2_ok = 2;
                 else if (v2fit) d.v2_ok = 1;
             }
         }
@@ -614,7 +646,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
             if (d.noll == 3) d.v2_cbF2 = OFF<void>(take(recsz * ((size_t) (ar - al) + 3)));
             d.v2_rowoff = OFF<long long>(take(sizeof(long long) * ((size_t) (ar - al) + 2)));
             // the column-score matrix: only for DPs whose kernel reads one (strips in sweep mode make their own, block by block)
-            const bool own_sim = !getenv("G2G_NO_SIMBLK") && (d.v2_ok == 6 || d.v2_ok == 7 || (d.v2_ok == 1 && b->v2_sweep) || ((d.v2_ok == 2 || d.v2_ok == 3) && d.kind == 1 && b->v3_sweep));
+            const bool own_sim = !g2g_opt(ctx, "NO_SIMBLK") && (d.v2_ok == 6 || d.v2_ok == 7 || (d.v2_ok == 1 && b->v2_sweep) || ((d.v2_ok == 2 || d.v2_ok == 3) && d.kind == 1 && b->v3_sweep));
             if (!own_sim) d.v2_sim = OFF<double>(take(sizeof(double) * (size_t) cells + 64));
         }
         b->rr1[i] = (long long) (bl_ - al) + (br - ar);
@@ -637,7 +669,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
     if (bl.oom) { g2g_set_error("%s", "host staging buffer: out of (pinned) memory"); delete b; return G2G_ERR_NOMEM; }
     prep_lap("host image of the inputs");
     hipError_t e = hipSuccess;
-    if (ctx->spare && !getenv("G2G_NO_ARENA_CACHE") && ctx->spare_bytes >= b->arena_bytes) {   // (any size that fits: batch sizes of a refinement loop vary call by call)
+    if (ctx->spare && !g2g_opt(ctx, "NO_ARENA_CACHE") && ctx->spare_bytes >= b->arena_bytes) {   // (any size that fits: batch sizes of a refinement loop vary call by call)
         b->d_arena = ctx->spare; b->arena_cap = ctx->spare_bytes;
         ctx->spare = 0; ctx->spare_bytes = 0;
     } else {
@@ -685,7 +717,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         std::vector<int> flags(G2G_HDR + 4, 0);           // queue heads, then the header of the waits (g2g_wait_ge)
         std::vector<V2Tile> pre[G2G_HDR];                 // boundary chains of sweep-mode DPs: they head their variant's queue
         std::vector<int> ip;                              // the other DPs: chains in the prologue kernel
-        const bool chainq = !getenv("G2G_NO_CHAINQ");
+        const bool chainq = !g2g_opt(ctx, "NO_CHAINQ");
         int v6rows[4] = {0, 0, 0, 0}, v6ca4[4] = {0, 0, 0, 0};
         V6Ring v6rs[4] = {{{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}};
         V3Need need[8];
@@ -769,7 +801,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         for (int v = 0; v < 4; ++v) b->v6lds[v] = v6_layout(v6rows[v], v6ca4[v], v6rs[v]);
         for (int v = 0; v < 8; ++v) b->v3lds[v] = v3_layout(need[v].rows_bytes, need[v].ca4, need[v].apool, need[v].bpool, b->v3_cols);
         // test hook: G2G_INJECT_STALL=<i> makes the first strip / tile of problem i depend on a flag nobody ever writes
-        if (const char *e = getenv("G2G_INJECT_STALL")) {
+        if (const char *e = g2g_opt(ctx, "INJECT_STALL")) {
             const int victim = atoi(e);
             const int never = (int) flags.size();
             flags.push_back(0);
@@ -826,14 +858,14 @@ extern "C" int g2g_batch_run(g2g_batch *b)
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->vev[4], ctx->stream));
         HIPCHK(hipStreamWaitEvent(ctx->vstream[3], ctx->vev[4], 0));
-        const int pro_off = getenv("G2G_NO_PROSTAGE") ? 0 : (int) ((b->lds2p + 15) & ~(size_t) 15);
+        const int pro_off = g2g_opt(ctx, "NO_PROSTAGE") ? 0 : (int) ((b->lds2p + 15) & ~(size_t) 15);
         if (b->np) {
             hipLaunchKernelGGL(g2g_v2_prologue_kernel, dim3(b->np), dim3(128), pro_off ? pro_off + 2 * PRO_LDS_BYTES : b->lds2p, ctx->vstream[3],
                                (const DevProb *) b->d_probs, (const int *) b->d_idxp, pro_off);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(ctx->vev[3], ctx->vstream[3]));
-        const int simtiled = (!getenv("G2G_NO_SIMTILE") && b->simtile_lds && b->simtile_lds <= 64 * 1024) ? 1 : 0;
+        const int simtiled = (!g2g_opt(ctx, "NO_SIMTILE") && b->simtile_lds && b->simtile_lds <= 64 * 1024) ? 1 : 0;
         if (simtiled) {
             hipLaunchKernelGGL(g2g_v2_sim_tile_kernel, dim3((b->v2_maxcols + SIM_TC - 1) / SIM_TC, (b->v2_maxrows + SIM_TR - 1) / SIM_TR, b->n2), dim3(256),
                                b->simtile_lds, ctx->stream, (const DevProb *) b->d_probs, (const int *) b->d_idx2);
@@ -843,7 +875,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                            (const DevProb *) b->d_probs, (const int *) b->d_idx2, simtiled);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[3], 0));
-        if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[g2g] prologue+sim done: %s\n", hipGetErrorString(e3)); fflush(stderr); }
+        if (g2g_opt(ctx, "DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[g2g] prologue+sim done: %s\n", hipGetErrorString(e3)); fflush(stderr); }
         // persistent tile / strip kernels: one launch per kernel variant, each on its own stream (they are independent)
         typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int, int, int, int, double *);
         static const v2k_t v2k[4] = {g2g_v2_hf2, g2g_v2_hf3, g2g_v2_pf2, g2g_v2_pf3};
@@ -859,7 +891,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             int hdr[G2G_HDR + 4];
             memset(hdr, 0, sizeof hdr);
             double limit_ms = 20000.;
-            if (const char *e = getenv("G2G_WAIT_LIMIT_MS")) { const double v = atof(e); if (v > 0) limit_ms = v; }
+            if (const char *e = g2g_opt(ctx, "WAIT_LIMIT_MS")) { const double v = atof(e); if (v > 0) limit_ms = v; }
             hdr[G2G_HDR + 2] = b->fail_off;
             hdr[G2G_HDR + 3] = (int) std::min(2.0e9, limit_ms * ctx->rt_ticks_per_ms / 65536.) + 1;
             HIPCHK(hipMemcpyAsync(b->d_flags, hdr, sizeof hdr, hipMemcpyHostToDevice, ctx->stream));
@@ -883,7 +915,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             if (!cnt) continue;
             HIPCHK(hipStreamWaitEvent(ctx->vstream[v], ctx->vev[4], 0));
             int wpc2 = 2048 / T2;              // workgroups per CU the grid provides (LDS decides how many are resident)
-            if (const char *e = getenv("G2G_V2_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc2 = w; }
+            if (const char *e = g2g_opt(ctx, "V2_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc2 = w; }
             const int grid = std::min(cnt, ncu * wpc2);
             // sweep mode: the kernel argument is the publish interval.  A DP's critical path is columns + strips x
             // interval: 32 steps when the strips outnumber the resident workgroups several times over (throughput
@@ -891,9 +923,9 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             // strips fill less than a quarter of the chip (a handful of DPs: latency is all that counts, -10 %).
             const int res2 = ncu * std::max(1, std::min(wpc2, (int) (V2_LDS_MAX / (b->lds2 + 4 * (size_t) T2))));
             const int pint2 = !b->v2_sweep ? 0 : b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= res2 ? 4 : cnt < 4 * res2 ? 16 : 32;
-            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] variant %d: %d tiles, grid %d x %d threads, lds %zu, cols %d, gen %d\n", v, cnt, grid, T2, b->lds2, b->v2_cols, b->gen); fflush(stderr); }
+            if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] variant %d: %d tiles, grid %d x %d threads, lds %zu, cols %d, gen %d\n", v, cnt, grid, T2, b->lds2, b->v2_cols, b->gen); fflush(stderr); }
             double *simscr2 = 0;
-            if (b->v2_sweep && !getenv("G2G_NO_SIMBLK")) {
+            if (b->v2_sweep && !g2g_opt(ctx, "NO_SIMBLK")) {
                 simscr2 = sim_scratch(v, grid);
                 if (!simscr2) { g2g_set_error("%s", "hipMalloc(column-score scratch)"); return G2G_ERR_NOMEM; }
             }
@@ -902,14 +934,14 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                                b->d_flags + v, b->d_flags, b->gen, (int) b->lds2, b->v2_sweep ? (1 << 20) : b->v2_cols, pint2,
                                (pro_off && pro_off + PRO_LDS_BYTES <= b->lds2) ? pro_off : 0, simscr2);
             HIPCHK(hipGetLastError());
-            if (getenv("G2G_DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->vstream[v]); fprintf(stderr, "[g2g] variant %d done: %s\n", v, hipGetErrorString(e3)); fflush(stderr); }
+            if (g2g_opt(ctx, "DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->vstream[v]); fprintf(stderr, "[g2g] variant %d done: %s\n", v, hipGetErrorString(e3)); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[v], ctx->vstream[v]));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[v], 0));
         }
         for (int v = 0; v < 8; ++v) {
             const int cnt = b->var_off[v + 5] - b->var_off[v + 4];
             if (!cnt || !v3k[v]) continue;
-            if (const char *e = getenv("G2G_ONLY_VAR")) if (atoi(e) != v) continue;       // profiling aid
+            if (const char *e = g2g_opt(ctx, "ONLY_VAR")) if (atoi(e) != v) continue;       // profiling aid
             hipStream_t vs = ctx->vstream[v & 3];
             const V3Lds &LO = b->v3lds[v];
             const bool swpv = (v & 3) < 2;                   // the _hf variants (LDS lists 0,1; register lists 4,5) run in sweep mode
@@ -917,11 +949,11 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipStreamWaitEvent(vs, ctx->vev[4], 0));
             int wpc = (int) (V2_LDS_MAX / (size_t) LO.total);              // resident tiles per CU (LDS-bound)
             if (wpc < 1) wpc = 1; if (wpc > 16) wpc = 16;
-            if (const char *e = getenv("G2G_V3_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc = w; }
+            if (const char *e = g2g_opt(ctx, "V3_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc = w; }
             const int grid = std::min(cnt, ncu * wpc);
-            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v3 variant %d: %d tiles, grid %d, lds %d (rows %d, apool@%d, bpool@%d), cols %d, gen %d\n", v, cnt, grid, LO.total, LO.black, LO.aglen, LO.bglen, b->v3_cols, b->gen); fflush(stderr); }
+            if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] v3 variant %d: %d tiles, grid %d, lds %d (rows %d, apool@%d, bpool@%d), cols %d, gen %d\n", v, cnt, grid, LO.total, LO.black, LO.aglen, LO.bglen, b->v3_cols, b->gen); fflush(stderr); }
             double *simscr3 = 0;
-            if (swpv && b->v3_sweep && !getenv("G2G_NO_SIMBLK")) {
+            if (swpv && b->v3_sweep && !g2g_opt(ctx, "NO_SIMBLK")) {
                 simscr3 = sim_scratch(4 + v, grid);
                 if (!simscr3) { g2g_set_error("%s", "hipMalloc(column-score scratch)"); return G2G_ERR_NOMEM; }
             }
@@ -931,7 +963,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                                !(swpv && b->v3_sweep) ? 0 : b->v3_sweep >= 2 ? b->v3_sweep : 4 * cnt <= ncu * std::min(wpc, 8) ? 4 : cnt < 4 * ncu * std::min(wpc, 8) ? 16 : 32,
                                (pro_off && pro_off + (int) PRO_LDS_BYTES <= LO.svals) ? pro_off : 0, simscr3);
             HIPCHK(hipGetLastError());
-            if (getenv("G2G_DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v3 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
+            if (g2g_opt(ctx, "DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v3 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[v & 3], vs));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[v & 3], 0));
         }
@@ -948,10 +980,10 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipStreamWaitEvent(vs, ctx->vev[4], 0));
             int wpc = (int) (V2_LDS_MAX / (size_t) LO.total);              // resident strips per CU (LDS-bound)
             if (wpc < 1) wpc = 1; if (wpc > 8) wpc = 8;
-            if (const char *e = getenv("G2G_V6_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc = w; }
+            if (const char *e = g2g_opt(ctx, "V6_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc = w; }
             const int grid = std::min(cnt, ncu * wpc);
             const int pint = b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= ncu * wpc ? 4 : cnt < 4 * ncu * wpc ? 16 : 32;   // publish interval (power of 2)
-            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v6 variant %d: %d strips, grid %d, lds %d (rings %d / %d / %d entries), publish every %d, gen %d\n", v, cnt, grid, LO.total, LO.rs[0], LO.rs[1], LO.rs[2], pint, b->gen); fflush(stderr); }
+            if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] v6 variant %d: %d strips, grid %d, lds %d (rings %d / %d / %d entries), publish every %d, gen %d\n", v, cnt, grid, LO.total, LO.rs[0], LO.rs[1], LO.rs[2], pint, b->gen); fflush(stderr); }
             double *simscr6 = sim_scratch(12 + v, grid);
             if (!simscr6) { g2g_set_error("%s", "hipMalloc(column-score scratch)"); return G2G_ERR_NOMEM; }
             hipLaunchKernelGGL(v6k[v], dim3(grid), dim3(64), (size_t) LO.total, vs,
@@ -959,7 +991,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                                b->d_flags + 12 + v, b->d_flags, b->gen, LO, pint,
                                (pro_off && pro_off + (int) PRO_LDS_BYTES <= LO.svals) ? pro_off : 0, simscr6);
             HIPCHK(hipGetLastError());
-            if (getenv("G2G_DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v6 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
+            if (g2g_opt(ctx, "DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v6 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[jev], vs));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[jev], 0));
         }
@@ -974,17 +1006,17 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             const int pint = b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= ncu * 16 ? 4 : cnt < 4 * ncu * 16 ? 16 : 32;
             double *simscr7 = sim_scratch(16 + v, grid);
             if (!simscr7) { g2g_set_error("%s", "hipMalloc(column-score scratch)"); return G2G_ERR_NOMEM; }
-            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v7 variant %d: %d strips, grid %d, publish every %d, gen %d\n", v, cnt, grid, pint, b->gen); fflush(stderr); }
+            if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] v7 variant %d: %d strips, grid %d, publish every %d, gen %d\n", v, cnt, grid, pint, b->gen); fflush(stderr); }
             hipLaunchKernelGGL(v7k[v], dim3(grid), dim3(64), 0, vs, (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v + 16]), cnt,
                                b->d_flags + 16 + v, b->d_flags, b->gen, pint, simscr7);
             HIPCHK(hipGetLastError());
-            if (getenv("G2G_DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v7 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
+            if (g2g_opt(ctx, "DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v7 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[5 + v], vs));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[5 + v], 0));
         }
 }
     if (b->n1) {
-        if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] v1 (state in HBM): %d of %d problems\n", b->n1, b->n); fflush(stderr); }
+        if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] v1 (state in HBM): %d of %d problems\n", b->n1, b->n); fflush(stderr); }
         hipLaunchKernelGGL(g2g_forward_kernel, dim3(b->n1), dim3(G2G_FWD_THREADS), 0, ctx->stream,
                            (const DevProb *) b->d_probs, (const int *) b->d_idx1);
         HIPCHK(hipGetLastError());
@@ -1004,7 +1036,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipMemcpy(fail.data(), b->d_flags + b->fail_off, sizeof(int) * (size_t) b->n, hipMemcpyDeviceToHost));
             std::vector<int> lost;
             for (int i = 0; i < b->n; ++i) if (fail[i] && !b->status[i]) lost.push_back(i);
-            if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] s_memrealtime: %.0f ticks/ms; ", ctx->rt_ticks_per_ms); fprintf(stderr, "[g2g] %d waits timed out (first: queue slot %d): re-running %zu DP(s) on g2g_forward_kernel\n", rep[G2G_HDR], rep[G2G_HDR + 1], lost.size()); fflush(stderr); }
+            if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] s_memrealtime: %.0f ticks/ms; ", ctx->rt_ticks_per_ms); fprintf(stderr, "[g2g] %d waits timed out (first: queue slot %d): re-running %zu DP(s) on g2g_forward_kernel\n", rep[G2G_HDR], rep[G2G_HDR + 1], lost.size()); fflush(stderr); }
             if (b->force_v1 || lost.empty()) { g2g_set_error("%s", "scheduler: a wait timed out and no DP could be singled out"); return G2G_ERR_DEVICE; }
             std::vector<const g2g_problem *> pp;
             for (int i : lost) pp.push_back(b->src[i]);
@@ -1162,7 +1194,7 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
 }
 
 // upper estimate of the arena bytes one problem takes in a batch (inputs + state + trace + column scores)
-static size_t problem_bytes(const g2g_problem *p)
+static size_t problem_bytes(const g2g_ctx *ctx, const g2g_problem *p)
 {
     if (check_problem(p)) return 4096;
     const int al = p->a.left, ar = p->a.right, bl = p->b.left, br = p->b.right;
@@ -1177,7 +1209,7 @@ static size_t problem_bytes(const g2g_problem *p)
     }
     // trace (1 B per cell) + the column-score matrix (8 B per cell) where a kernel reads one: strips in sweep mode (the
     // default of every tiled kernel) make their own scores
-    const bool matrix = getenv("G2G_NO_SIMBLK") || getenv("G2G_V2_SWEEP") || getenv("G2G_V3_SWEEP") || getenv("G2G_V3_PF");   // (tile-mode test configurations)
+    const bool matrix = g2g_opt(ctx, "NO_SIMBLK") || g2g_opt(ctx, "V2_SWEEP") || g2g_opt(ctx, "V3_SWEEP") || g2g_opt(ctx, "V3_PF");   // (tile-mode test configurations)
     size_t bytes = (size_t) (ar - al + br - bl + 2) * tmax + (matrix ? 8 * (size_t) cells : 0);
     const g2g_side *sd[2] = {&p->a, &p->b};
     for (int k = 0; k < 2; ++k) {
@@ -1202,18 +1234,18 @@ extern "C" int g2g_forward_batch(g2g_ctx *ctx, int n, const g2g_problem *const *
     HIPCHK(hipSetDevice(ctx->device));
     size_t budget = (size_t) 64 << 30;              // per chunk (128 GB chunks were no faster on a 3.3e10-cell DNA sweep)
     { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr) budget = std::min(budget, (size_t) (0.7 * (double) fr)); }
-    if (const char *e = getenv("G2G_ARENA_LIMIT_GB")) { const double g = atof(e); if (g > 0) budget = (size_t) (g * (double) ((size_t) 1 << 30)); }
+    if (const char *e = g2g_opt(ctx, "ARENA_LIMIT_GB")) { const double g = atof(e); if (g > 0) budget = (size_t) (g * (double) ((size_t) 1 << 30)); }
     for (int i = 0; i < n; ++i) { res[i].trace = 0; res[i].ntrace = 0; }
     int lo = 0;
     while (lo < n) {
         size_t acc = 0;
         int hi = lo;
         while (hi < n) {
-            const size_t pb = problem_bytes(prob[hi]);
+            const size_t pb = problem_bytes(ctx, prob[hi]);
             if (hi > lo && (acc + pb > budget || hi - lo >= G2G_MAX_BATCH)) break;
             acc += pb; ++hi;
         }
-        if (getenv("G2G_DEBUG")) { fprintf(stderr, "[g2g] forward_batch: chunk [%d, %d) of %d, %.3g of %.3g bytes\n", lo, hi, n, (double) acc, (double) budget); fflush(stderr); }
+        if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] forward_batch: chunk [%d, %d) of %d, %.3g of %.3g bytes\n", lo, hi, n, (double) acc, (double) budget); fflush(stderr); }
         g2g_batch *b = 0;
         int rc = g2g_batch_prepare(ctx, hi - lo, prob + lo, &b);
         if (!rc) {

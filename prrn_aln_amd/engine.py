@@ -12,7 +12,7 @@ from ._lib import G2GError, last_error, lib
 
 
 class Context:
-    def __init__(self, device: int = -1):
+    def __init__(self, device: int = -1, options=None):
         L = lib()
         self._h = L.g2g_create(device)
         if not self._h:
@@ -22,6 +22,21 @@ class Context:
             L.g2g_destroy(self._h)
             self._h = None
             raise G2GError("no usable MI355X / gfx950 kernel image: " + msg)
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def set_option(self, name: str, value=None):
+        """g2g_set_option: a tuning / diagnostic switch of this context (None: off, whatever the environment says)"""
+        v = None if value is None else str(value).encode()
+        if lib().g2g_set_option(self._h, name.encode(), v) != 0:
+            raise G2GError(last_error())
+
+    def reset_options(self):
+        lib().g2g_reset_options(self._h)
+
+    def get_option(self, name: str):
+        v = lib().g2g_get_option(self._h, name.encode())
+        return None if v is None else v.decode()
 
     def close(self):
         if self._h:

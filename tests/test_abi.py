@@ -60,3 +60,34 @@ def test_no_device_fails_loudly(built):
     from prrn_aln_amd._lib import G2GError
     with pytest.raises(G2GError):
         engine.Context()
+
+
+def test_context_options_override_the_environment(built, monkeypatch):
+    """g2g_set_option / g2g_get_option / g2g_reset_options: per-context switches, the environment supplies defaults only
+    (no GPU needed: a context without a device still holds options)."""
+    L = C.CDLL(built)
+    L.g2g_create.restype = C.c_void_p
+    L.g2g_get_option.restype = C.c_char_p
+    L.g2g_get_option.argtypes = [C.c_void_p, C.c_char_p]
+    L.g2g_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    L.g2g_reset_options.argtypes = [C.c_void_p]
+    L.g2g_destroy.argtypes = [C.c_void_p]
+    monkeypatch.setenv("G2G_V3_COLS", "48")
+    assert L.g2g_get_option(None, b"V3_COLS") == b"48"                 # no context: the environment's default
+    h = L.g2g_create(-1)
+    if not h:
+        pytest.skip("g2g_create gives no context without a device (the same test runs in tests/test_gpu_edges.py)")
+    try:
+        monkeypatch.delenv("G2G_V3_COLS", raising=False)
+        assert L.g2g_get_option(h, b"V3_COLS") is None
+        monkeypatch.setenv("G2G_V3_COLS", "32")
+        assert L.g2g_get_option(h, b"V3_COLS") == b"32" and L.g2g_get_option(h, b"G2G_V3_COLS") == b"32"
+        assert L.g2g_set_option(h, b"V3_COLS", b"64") == 0
+        assert L.g2g_get_option(h, b"V3_COLS") == b"64"
+        assert L.g2g_set_option(h, b"G2G_V3_COLS", None) == 0          # off for this context, whatever the environment says
+        assert L.g2g_get_option(h, b"V3_COLS") is None
+        L.g2g_reset_options(h)
+        assert L.g2g_get_option(h, b"V3_COLS") == b"32"
+        assert L.g2g_set_option(h, b"", b"1") != 0 and L.g2g_set_option(None, b"X", b"1") != 0
+    finally:
+        L.g2g_destroy(h)

@@ -113,15 +113,30 @@ def test_injected_stall_costs_one_dp_and_is_recovered(ctx, monkeypatch):
     assert len(ds) >= 4
     hs = [_abi.problem_from_arrays(d) for d in ds]
     for victim in (0, 2):
-        monkeypatch.setenv("G2G_INJECT_STALL", str(victim))
-        monkeypatch.setenv("G2G_WAIT_LIMIT_MS", "300")
+        ctx.set_option("INJECT_STALL", victim)
+        ctx.set_option("WAIT_LIMIT_MS", 300)
         t0 = time.time()
         res = ctx.forward_batch(hs)
         dt = time.time() - t0
-        monkeypatch.delenv("G2G_INJECT_STALL")
-        monkeypatch.delenv("G2G_WAIT_LIMIT_MS")
+        ctx.set_option("INJECT_STALL", None)
+        ctx.set_option("WAIT_LIMIT_MS", None)
         assert 0.25 < dt < 20, dt                      # it did wait for the limit, and for not much longer
         for d, (scr, cells, tr, st) in zip(ds, res):
             assert st == 0 and scr == d["scr"][0] and np.array_equal(tr, d["vmf_trace"])
     res = ctx.forward_batch(hs)                        # and the context is fine afterwards
     assert all(st == 0 and scr == d["scr"][0] for d, (scr, cells, tr, st) in zip(ds, res))
+
+
+def test_context_options(ctx, monkeypatch):
+    """g2g_set_option is per context and beats the environment; NULL turns a switch off; reset goes back to the defaults"""
+    monkeypatch.setenv("G2G_V3_COLS", "32")
+    other = engine.Context(options={"V3_COLS": 128})
+    try:
+        assert ctx.get_option("V3_COLS") == "32" and other.get_option("G2G_V3_COLS") == "128"
+        ctx.set_option("V3_COLS", None)
+        assert ctx.get_option("V3_COLS") is None and other.get_option("V3_COLS") == "128"
+        ctx.reset_options()
+        assert ctx.get_option("V3_COLS") == "32"
+    finally:
+        other.close()
+        ctx.reset_options()

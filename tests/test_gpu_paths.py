@@ -2,7 +2,7 @@
 
 The engine picks a kernel per problem (g2g_engine.hip: v3r = one lane per cell with the rows' static lists in
 registers, v3 = the same with the lists in LDS, v6 = one lane per cell with rank-form merges (_pf), v2 = 8-lane teams
-in 4-wave workgroups, v1 = anti-diagonal sweep with the state in HBM).  The selection can be forced through environment variables that are read at batch-prepare time; each
+in 4-wave workgroups, v1 = anti-diagonal sweep with the state in HBM).  The selection can be forced per context (g2g_set_option; the environment G2G_* supplies the defaults), read at batch-prepare time; each
 forced configuration must reproduce the reference bit for bit.  Narrow tiles (G2G_V3_COLS) make even the small
 golden DPs span several column blocks and strips."""
 import glob
@@ -53,16 +53,28 @@ def L():
     return oraclelib.load()
 
 
-def _setenv(monkeypatch, cfg):
+@pytest.fixture(autouse=True)
+def _fresh_options(ctx):
+    ctx.reset_options()
+    yield
+    ctx.reset_options()
+
+
+def _setenv(monkeypatch, cfg, ctx=None):
+    """Force a configuration: through the context's own options (g2g_set_option) when a context is given -- the
+    environment's G2G_* are cleared either way -- else through the environment defaults."""
     for k in ALLVARS:
         monkeypatch.delenv(k, raising=False)
     for k, v in cfg.items():
-        monkeypatch.setenv(k, v)
+        if ctx is not None:
+            ctx.set_option(k, v)
+        else:
+            monkeypatch.setenv(k, v)
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_goldens_every_path(ctx, monkeypatch, name):
-    _setenv(monkeypatch, CONFIGS[name])
+    _setenv(monkeypatch, CONFIGS[name], ctx)
     ds = [dict(np.load(f)) for f in GOLD]
     hs = [_abi.problem_from_arrays(d) for d in ds]
     res = ctx.forward_batch(hs)
