@@ -21,6 +21,7 @@
 #include "g2g_kernels_v3.hip"
 #include "g2g_kernels_v6.hip"
 #include "g2g_kernels_v7.hip"
+#include "g2g_kernels_v8.hip"
 
 static thread_local std::string g_err;
 void g2g_set_error(const char *fmt, const char *a)
@@ -609,6 +610,13 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         // v2 kernel (gap-profile engines): packed 16-bit gap lengths and an LDS budget decide eligibility
         d.v2_ok = 0;
         if (d.kind == 0 && !force_v1 && !g2g_opt(ctx, "FORCE_V1") && !g2g_opt(ctx, "NO_V7")) d.v2_ok = 7;      // DPunit: strips without gap state
+        if (d.kind == 3 && !force_v1 && !g2g_opt(ctx, "FORCE_V1") && !g2g_opt(ctx, "NO_V8")) {
+            // DPunit_nv: strips with the members' gap lengths in registers, for the member counts selAlnMode sends this way
+            const int an = p->a.many, bn = p->b.many, ck = p->crg2_kind;
+            const bool fits = ck == 11 ? (an == 1 && bn == 1) : (ck == 120 || ck == 121) ? (an == 1 && bn <= 5) :
+                              (ck == 210 || ck == 211) ? (an <= 5 && bn == 1) : (ck == 220 || ck == 221) ? (an <= 3 && bn <= 3) : false;
+            if (fits && p->a.gapdens && p->b.gapdens && p->a.postgapdens && p->b.postgapdens && (!(ck & 1) || ck == 11 || (p->a.weight && p->b.weight))) d.v2_ok = 8;
+        }
         if ((d.kind == 1 || d.kind == 2) && !force_v1 && !g2g_opt(ctx, "FORCE_V1") && p->a.len + p->b.len < 65000) {
             // _pf: one lane per cell with rank-form merges (v6) when the rows' static lists fit the register file
             if (!g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_V6") && !g2g_opt(ctx, "V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V6_NA && d.a.r_from_t &&
@@ -635,7 +643,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
             if (d.kind == 2) d.dlb[XH] = OFF<int2>(take(sizeof(int2) * (size_t) (d.capb + 1)));
         }
         if (d.v2_ok) {
-            const size_t recsz = (16 + 4 * (size_t) (d.capa + (d.kind == 2 ? d.capb : 0)) + 15) & ~(size_t) 15;
+            const size_t recsz = d.v2_ok == 8 ? 4 * V8_REC : (16 + 4 * (size_t) (d.capa + (d.kind == 2 ? d.capb : 0)) + 15) & ~(size_t) 15;
             d.v2_rowstride = p->b.len + 3;
             d.v2_rowH = OFF<void>(take(3 * recsz * (size_t) d.v2_rowstride));
             d.v2_rowG = OFF<void>(take(3 * recsz * (size_t) d.v2_rowstride));
@@ -646,7 +654,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
             if (d.noll == 3) d.v2_cbF2 = OFF<void>(take(recsz * ((size_t) (ar - al) + 3)));
             d.v2_rowoff = OFF<long long>(take(sizeof(long long) * ((size_t) (ar - al) + 2)));
             // the column-score matrix: only for DPs whose kernel reads one (strips in sweep mode make their own, block by block)
-            const bool own_sim = !g2g_opt(ctx, "NO_SIMBLK") && (d.v2_ok == 6 || d.v2_ok == 7 || (d.v2_ok == 1 && b->v2_sweep) || ((d.v2_ok == 2 || d.v2_ok == 3) && d.kind == 1 && b->v3_sweep));
+            const bool own_sim = !g2g_opt(ctx, "NO_SIMBLK") && (d.v2_ok >= 6 || (d.v2_ok == 1 && b->v2_sweep) || ((d.v2_ok == 2 || d.v2_ok == 3) && d.kind == 1 && b->v3_sweep));
             if (!own_sim) d.v2_sim = OFF<double>(take(sizeof(double) * (size_t) cells + 64));
         }
         b->rr1[i] = (long long) (bl_ - al) + (br - ar);
@@ -725,7 +733,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         for (int i = 0; i < n; ++i) {
             const DevProb &d = b->dp[i];
             if (d.kind < 0 || !d.v2_ok) continue;
-            const size_t recsz = (16 + 4 * (size_t) (d.capa + (d.kind == 2 ? d.capb : 0)) + 15) & ~(size_t) 15;
+            const size_t recsz = d.v2_ok == 8 ? 4 * V8_REC : (16 + 4 * (size_t) (d.capa + (d.kind == 2 ? d.capb : 0)) + 15) & ~(size_t) 15;
             b->lds2p = std::max(b->lds2p, 5 * recsz + 64);
             b->v2_maxrows = std::max(b->v2_maxrows, d.a.right - d.a.left);
             b->v2_maxcols = std::max(b->v2_maxcols, d.b.right - d.b.left);
@@ -741,19 +749,19 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
             const int nstrip = (ar - al + R - 1) / R, nblk = (br - bl_ + C - 1) / C;
             // (one LDS plan per launch = the largest of its DPs: DPs whose column lists need a big ring get a launch of their own,
             //  or a handful of balanced divisions would cost every strip of the sweep its occupancy)
-            const int var = d.v2_ok == 7 ? 16 + (d.noll == 3 ? 1 : 0) : d.v2_ok == 6 ? 12 + (d.noll == 3 ? 1 : 0) + (v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(prob[i])).total > V6_CLASS_A ? 2 : 0) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
+            const int var = d.v2_ok == 8 ? 18 + (d.noll == 3 ? 1 : 0) : d.v2_ok == 7 ? 16 + (d.noll == 3 ? 1 : 0) : d.v2_ok == 6 ? 12 + (d.noll == 3 ? 1 : 0) + (v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(prob[i])).total > V6_CLASS_A ? 2 : 0) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
             if (d.v2_ok == 6) {
                 v6rows[var - 12] = std::max(v6rows[var - 12], v6_rows_bytes(d));
                 v6ca4[var - 12] = std::max(v6ca4[var - 12], (d.capa + 3) & ~3);
                 { const V6Ring rn = v6_ring_need(prob[i]); for (int q = 0; q < 3; ++q) v6rs[var - 12].rs[q] = std::max(v6rs[var - 12].rs[q], rn.rs[q]); }
-            } else if (d.v2_ok == 7) {
+            } else if (d.v2_ok >= 7) {
             } else if (d.v2_ok >= 2) {
                 const V3Need nd = v3_need(d, prob[i], C, d.v2_ok == 3);
                 V3Need &x = need[var - 4];
                 x.rows_bytes = std::max(x.rows_bytes, nd.rows_bytes); x.ca4 = std::max(x.ca4, nd.ca4);
                 x.apool = std::max(x.apool, nd.apool); x.bpool = std::max(x.bpool, nd.bpool);
             }
-            const bool cq = (chainq && (swp2 || swp3)) || d.v2_ok == 7;      // (v7's chains always run as queue entries: the prologue kernel knows the gap-profile kinds only)
+            const bool cq = (chainq && (swp2 || swp3)) || d.v2_ok >= 7;      // (v7's and v8's chains always run as queue entries: the prologue kernel knows the gap-profile kinds only)
             int ftop = -1, fleft = -1;
             if (cq) {
                 ftop = (int) flags.size(); fleft = ftop + 1;
@@ -995,24 +1003,25 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipEventRecord(ctx->vev[jev], vs));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[jev], 0));
         }
-            for (int v = 0; v < 2; ++v) {                        // v7: DPunit strips (no gap state, no LDS to speak of)
+        for (int v = 0; v < 4; ++v) {                        // v7: DPunit strips (no gap state, no LDS to speak of); v8: DPunit_nv strips
             const int cnt = b->var_off[v + 17] - b->var_off[v + 16];
             if (!cnt) continue;
             typedef void (*v7k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int, double *);
-            static const v7k_t v7k[2] = {g2g_v7_ngp2, g2g_v7_ngp3};
-            hipStream_t vs = ctx->vstream[4 + v];
+            static const v7k_t v7k[4] = {g2g_v7_ngp2, g2g_v7_ngp3, g2g_v8_ntv2, g2g_v8_ntv3};
+            hipStream_t vs = ctx->vstream[4 + (v & 1)];
             HIPCHK(hipStreamWaitEvent(vs, ctx->vev[4], 0));
-            const int grid = std::min(cnt, ncu * 16);
-            const int pint = b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= ncu * 16 ? 4 : cnt < 4 * ncu * 16 ? 16 : 32;
+            const int wpc = v < 2 ? 16 : 4;                  // (v8 holds its records' lengths in registers: one wave per SIMD)
+            const int grid = std::min(cnt, ncu * wpc);
+            const int pint = b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= ncu * wpc ? 4 : cnt < 4 * ncu * wpc ? 16 : 32;
             double *simscr7 = sim_scratch(16 + v, grid);
             if (!simscr7) { g2g_set_error("%s", "hipMalloc(column-score scratch)"); return G2G_ERR_NOMEM; }
-            if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] v7 variant %d: %d strips, grid %d, publish every %d, gen %d\n", v, cnt, grid, pint, b->gen); fflush(stderr); }
+            if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] %s variant %d: %d strips, grid %d, publish every %d, gen %d\n", v < 2 ? "v7" : "v8", v & 1, cnt, grid, pint, b->gen); fflush(stderr); }
             hipLaunchKernelGGL(v7k[v], dim3(grid), dim3(64), 0, vs, (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v + 16]), cnt,
                                b->d_flags + 16 + v, b->d_flags, b->gen, pint, simscr7);
             HIPCHK(hipGetLastError());
-            if (g2g_opt(ctx, "DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v7 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
-            HIPCHK(hipEventRecord(ctx->vev[5 + v], vs));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[5 + v], 0));
+            if (g2g_opt(ctx, "DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] %s variant %d done: %s, %.1f ms\n", v < 2 ? "v7" : "v8", v & 1, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
+            HIPCHK(hipEventRecord(ctx->vev[5 + (v & 1)], vs));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[5 + (v & 1)], 0));
         }
 }
     if (b->n1) {

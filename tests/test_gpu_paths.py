@@ -2,7 +2,7 @@
 
 The engine picks a kernel per problem (g2g_engine.hip: v3r = one lane per cell with the rows' static lists in
 registers, v3 = the same with the lists in LDS, v6 = one lane per cell with rank-form merges (_pf), v2 = 8-lane teams
-in 4-wave workgroups, v1 = anti-diagonal sweep with the state in HBM).  The selection can be forced per context (g2g_set_option; the environment G2G_* supplies the defaults), read at batch-prepare time; each
+in 4-wave workgroups, v7 / v8 = one lane per cell for the records without gap profiles (DPunit, DPunit_nv), v1 = anti-diagonal sweep with the state in HBM).  The selection can be forced per context (g2g_set_option; the environment G2G_* supplies the defaults), read at batch-prepare time; each
 forced configuration must reproduce the reference bit for bit.  Narrow tiles (G2G_V3_COLS) make even the small
 golden DPs span several column blocks and strips."""
 import glob
@@ -30,6 +30,7 @@ CONFIGS = {
     "v3lds_all_cols32": {"G2G_NO_AREG": "1", "G2G_V3_PF": "1", "G2G_V3_COLS": "32", "G2G_V3_SWEEP": "0"},   # tile mode
     "v3_pf": {"G2G_V3_PF": "1", "G2G_V3_COLS": "64"},
     "no_v7": {"G2G_NO_V7": "1"},                                     # DPunit on v1 instead of the strip kernel
+    "no_v8": {"G2G_NO_V8": "1"},                                     # DPunit_nv on v1 instead of the strip kernel
     "no_v6": {"G2G_NO_V6": "1"},                                     # _pf on the 8-lanes-per-cell kernel instead of v6
     "v6_publish4": {"G2G_V2_SWEEP": "4"},                            # progress counters published every 4 steps
     "v2": {"G2G_FORCE_V2": "1"},
@@ -107,3 +108,29 @@ def test_large_divisions_every_path(ctx, L, monkeypatch, name, fam):
         oscr, ocells, otr = oraclelib.forward(L, H)
         assert scr == oscr, (name, pw.alnmode, scr, oscr)
         assert np.array_equal(skl, oraclelib.stdskl(L, otr))
+
+
+@pytest.mark.parametrize("name", ["default", "no_v8", "v6_publish4"])
+def test_naive_mode_strips_vs_oracle(ctx, L, monkeypatch, name):
+    """NTV_ALB (DPunit_nv: one gap length per member, PwdM::crg11 ... crg22w) on families of 3-6 sequences over several
+    64-row strips, weighted and not, Noll 2 and 3: every division and every pairwise member count the mode is chosen for."""
+    _setenv(monkeypatch, CONFIGS[name], ctx)
+    seen = set()
+    for n in (3, 4, 5, 6):
+        for weighted in (True, False):
+            for ls in (1, 3):
+                fam = make_family(n, 260, 70 + n + ls, indel=0.05, max_indel=14)
+                sw = sweep.Sweep(fam, op.AlnParam(ls=ls), weighted=weighted)
+                res = op.align2_batch(ctx, sw.pwds)
+                for pw, (scr, skl, st) in zip(sw.pwds, res):
+                    assert st == 0, (n, weighted, ls, pw.alnmode)
+
+                    class H:
+                        c = pw.problem
+                    oscr, ocells, otr = oraclelib.forward(L, H)
+                    assert scr == oscr, (name, n, weighted, ls, pw.alnmode, pw.problem.crg2_kind, scr, oscr)
+                    assert np.array_equal(skl, oraclelib.stdskl(L, otr))
+                    if pw.alnmode == 10:
+                        seen.add((pw.problem.crg2_kind, pw.problem.a.many, pw.problem.b.many, pw.problem.noll))
+    kinds = {k for (k, _, _, _) in seen}
+    assert kinds >= {121, 211, 221, 120, 210, 220} or len(kinds) >= 4, seen
