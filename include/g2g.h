@@ -240,6 +240,21 @@ int        g2g_homscore(g2g_ctx *ctx, g2g_pwdm *p, double *scr, int64_t rr[2]);
 int        g2g_align2_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *p, double *scr,
                             g2g_skl **skl, int *nskl, int *status);
 
+/* ---- f3: the guide-tree stage -- score-only pairwise DPs between single sequences ----------------------
+ * <-> VTYPE alnScoreD(const Seq* seqs[], const Simmtx* sm, int* ends = 0) (reference src/fwd2d1.cc:324-338), global branch:
+ * Fwd2d::Fwd2d (the boundary values, :58-93), Fwd2d::forwardD (:136-158, anti-diagonal order, affine gaps -(v + k u),
+ * band = stripe(seqs, alprm.sh), src/aln2.cc:156-174) and Fwd2d::lastD (:100-134, terminal-gap discount tgapf).  This is what
+ * dpscore() (src/phyl.cc:222-252) runs for every pair of members when the distance matrix comes from alignment scores.
+ * Sequences are uploaded once, pairs are index pairs; scores are bit-equal to the reference's doubles.
+ * prm: u, v, scale (floats in the reference: the library forms (float) u * (float) scale as the reference does), tgapf, sh,
+ * simmtx / simdim / simrows (Simmtx::mtx as doubles).  Not on this path: the local (algmode.lcl) and `ends` variants.  */
+typedef struct g2g_dseq {
+    const uint8_t *res;             /* Seq::at(0): len residue codes (one member)                 */
+    int32_t len, left, right;       /* Seq::len, ::left, ::right                                  */
+} g2g_dseq;
+int        g2g_alnscored_batch(g2g_ctx *ctx, const g2g_params *prm, int nseq, const g2g_dseq *seqs,
+                               int npairs, const int32_t *ia, const int32_t *ib, double *score, int32_t *status);
+
 #ifdef __cplusplus
 }
 #endif

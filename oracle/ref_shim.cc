@@ -172,7 +172,7 @@ void dump_skl(Dump& d, const char* name, const SKL* skl)
 
 extern "C" {
 
-int ref_shim_version() {return 2;}
+int ref_shim_version() {return 3;}
 
 // prrn5's defaults: static setdefparam() (prrn5.cc:1262-1278) + the per-molecule part of
 // main() (prrn5.cc:1813-1822).  molc: PROTEIN=1, DNA=2 (cmn.h:107).  ls: 1/2 affine, 3 double affine.
@@ -419,6 +419,64 @@ double ref_align_fstat(void* ga, void* gb, double* val, double* gap)
 	if (val) *val = gsi.fstat.val;
 	if (gap) *gap = gsi.fstat.gap;
 	return scr;
+}
+
+
+// ---- f3: single sequences, the guide-tree DPs --------------------------------------------------------------------
+void* ref_seq_read(const char* fname)
+{
+	Seq*	sd = new Seq(fname);
+	if (!sd->many || !sd->len) {delete sd; return 0;}
+	return sd;
+}
+void ref_seq_free(void* s) {delete (Seq*) s;}
+int ref_seq_len(void* s) {return ((Seq*) s)->len;}
+int ref_seq_range(void* s, int* left, int* right) {*left = ((Seq*) s)->left; *right = ((Seq*) s)->right; return ((Seq*) s)->many;}
+void ref_seq_codes(void* s, unsigned char* out)
+{
+	Seq*	sd = (Seq*) s;
+	for (int i = 0; i < sd->len; ++i) out[i] = *sd->at(i);
+}
+// the parameters Fwd2d / Aln2b1 read: alprm and the default similarity matrix
+int ref_dist_params(double* uvst, int* sh, double* mtx, int cap, int* dim, int* rows)
+{
+	const Simmtx*	sm = getSimmtx(0);
+	uvst[0] = alprm.u; uvst[1] = alprm.v; uvst[2] = alprm.scale; uvst[3] = alprm.tgapf;
+	*sh = alprm.sh; *dim = sm->dim; *rows = sm->rows;
+	if (sm->rows * sm->dim > cap) return -1;
+	for (int i = 0; i < sm->rows; ++i)
+	    for (int j = 0; j < sm->dim; ++j) mtx[i * sm->dim + j] = sm->mtx[i][j];
+	return 0;
+}
+// alnScoreD(seqs, simmtx) global branch (fwd2d1.cc:324-338)
+double ref_alnscored(void* sa, void* sb)
+{
+	const Seq*	sqs[2] = {(Seq*) sa, (Seq*) sb};
+	return (double) alnScoreD(sqs, getSimmtx(0), 0);
+}
+double ref_selfalnscr(void* sa) {return (double) selfAlnScr((Seq*) sa, getSimmtx(0));}
+// alnscore2dist (aln2.cc:289-333) as dpscore calls it for two single sequences (phyl.cc:222-252)
+double ref_alnscore2dist(void* sa, void* sb, double denome)
+{
+	Seq*	sqs[2] = {(Seq*) sa, (Seq*) sb};
+	PwdB	pwd((const Seq**) sqs);
+	return (double) alnscore2dist(sqs, &pwd, 0, (FTYPE) denome);
+}
+// alignB_ng (fwd2b1.cc:1347-1353): skeleton corners into out[2 * k] (m, n); returns the number of corners, <0 on failure
+int ref_alignb_ng(void* sa, void* sb, double* scr, int* out, int cap, double* pwdc)
+{
+	const Seq*	sqs[2] = {(Seq*) sa, (Seq*) sb};
+	PwdB	pwd(sqs);
+	VTYPE	s = 0;
+	if (pwdc) {pwdc[0] = pwd.BasicGOP; pwdc[1] = pwd.BasicGEP; pwdc[2] = pwd.LongGOP; pwdc[3] = pwd.LongGEP; pwdc[4] = pwd.Noll; pwdc[5] = pwd.codonk1;}
+	SKL*	skl = alignB_ng(sqs, &pwd, &s);
+	*scr = (double) s;
+	if (!skl) return -1;
+	int	n = skl->n;
+	if (n > cap) {delete[] skl; return -2;}
+	for (int k = 0; k < n; ++k) {out[2 * k] = skl[k + 1].m; out[2 * k + 1] = skl[k + 1].n;}
+	delete[] skl;
+	return n;
 }
 
 }	// extern "C"

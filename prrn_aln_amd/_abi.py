@@ -54,6 +54,20 @@ class Params(C.Structure):
                 ("max_code", C.c_int32)]
 
 
+class DSeq(C.Structure):
+    """g2g_dseq: one single sequence of the guide-tree DPs (f3)"""
+    _fields_ = [("res", c_u8p), ("len", C.c_int32), ("left", C.c_int32), ("right", C.c_int32)]
+
+
+def dseq(codes: np.ndarray) -> "DSeq":
+    x = np.ascontiguousarray(codes, np.uint8)
+    d = DSeq()
+    d.res = x.ctypes.data_as(c_u8p)
+    d.len, d.left, d.right = len(x), 0, len(x)
+    d._keep = x
+    return d
+
+
 def _ptr(arr: np.ndarray, typ):
     return arr.ctypes.data_as(typ)
 

@@ -1270,3 +1270,5 @@ extern "C" int g2g_forward_batch(g2g_ctx *ctx, int n, const g2g_problem *const *
     }
     return G2G_OK;
 }
+
+#include "g2g_dist.hip"                // f3: the guide-tree DPs (own kernels, own entry point; shares the context)

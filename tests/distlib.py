@@ -1,0 +1,38 @@
+"""helpers of the f3 tests: fixtures -> ctypes structures, the oracle's alnScoreD"""
+import ctypes as C
+
+import numpy as np
+
+import oraclelib
+from prrn_aln_amd import _abi
+
+
+def split(d):
+    off = np.concatenate([[0], np.cumsum(d["lens"])])
+    return [np.ascontiguousarray(d["codes"][off[k]:off[k + 1]]) for k in range(len(d["lens"]))]
+
+
+def params(d):
+    p = _abi.Params()
+    p.u, p.v, p.scale, p.tgapf = float(d["u"][0]), float(d["v"][0]), float(d["scale"][0]), float(d["tgapf"][0])
+    p.sh = int(d["sh"][0])
+    p.ls = int(d["ls"][0])
+    m = np.ascontiguousarray(d["simmtx"], np.float64)
+    p.simmtx = m.ctypes.data_as(_abi.c_f64p)
+    p.simrows, p.simdim = m.shape
+    p._keep = m
+    return p
+
+
+def oracle_scores(d, seqs):
+    L = oraclelib.load()
+    L.g2g_oracle_alnscored.argtypes = [C.POINTER(_abi.Params), C.POINTER(_abi.DSeq), C.POINTER(_abi.DSeq), C.POINTER(C.c_double)]
+    p = params(d)
+    ds = [_abi.dseq(s) for s in seqs]
+    out = np.zeros(len(d["ia"]))
+    for k, (i, j) in enumerate(zip(d["ia"], d["ib"])):
+        v = C.c_double()
+        rc = L.g2g_oracle_alnscored(C.byref(p), C.byref(ds[i]), C.byref(ds[j]), C.byref(v))
+        assert rc == 0, rc
+        out[k] = v.value
+    return out

@@ -1,0 +1,36 @@
+"""f3, CPU side: the restatement of Fwd2d::forwardD (oracle/g2g_oracle.c: g2g_oracle_alnscored) against the reference's
+alnScoreD on every pair of every committed fixture (tests/golden/dist, made by tools/make_dist_golden.py), and the host
+mirror of alnscore2dist / dpscore (prrn_aln_amd/guide.py) against the reference's distances."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import distlib
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "dist", "*.npz")))
+
+
+def test_fixtures_present():
+    assert len(GOLD) >= 7
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_oracle_alnscored_matches_reference(path):
+    d = dict(np.load(path))
+    seqs = distlib.split(d)
+    got = distlib.oracle_scores(d, seqs)
+    assert np.array_equal(got, d["alnscored"]), np.abs(got - d["alnscored"]).max()
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_host_distance_formula_matches_reference(path):
+    """alnscore2dist (aln2.cc:325-333) + dpscore's denominator (phyl.cc:229) from the reference's own scores"""
+    from prrn_aln_amd import guide
+    d = dict(np.load(path))
+    seqs = distlib.split(d)
+    selfs = np.array([guide.self_score(s, d["simmtx"]) for s in seqs])
+    assert np.array_equal(selfs, d["selfscr"])
+    got = guide.scores_to_dist(d["alnscored"], d["ia"], d["ib"], d["lens"], selfs, float(d["u"][0]))
+    assert np.array_equal(got, d["dist"]), np.abs(got - d["dist"]).max()
