@@ -305,6 +305,46 @@ def main():
             del b2
         except Exception as e:
             prog = {"error": str(e)[:200]}
+    # two more read-outs of the same context (not the metric, outside the timed region):
+    #  - the whole refinement loop (f2: Randiv order, windows of speculative divisions batched on the GPU, in-order acceptance)
+    #    on a family the reference's own trajectory is committed for: wall time, and whether the final MSA is the reference's
+    #    byte for byte (then the SP-score delta of the refined alignment vs the reference is exactly 0)
+    #  - the guide-tree stage (f3: alnScoreD for all pairs of the bench family, one launch)
+    refinement = guide_tree = None
+    if world == 1 and not args.shard_of and not args.limit and not args.no_cpu:
+        try:
+            from prrn_aln_amd.refine import KTree, Refiner
+            f = json.load(open(os.path.join(ROOT, "tests", "golden", "refine_prot20x100_s11.json")))
+            t = f["tree"]
+            tree = KTree(t["left"], t["right"], t["parent"], t["vol"], t["cur"])
+            ralp = op.AlnParam(ls=f["ls"], molc=f["molc"], max_code=25 if f["molc"] == 1 else 17)
+            t1 = time.perf_counter()
+            r = Refiner(ctx, op.encode(f["rows"], f["molc"]), tree, ralp, seed=1, maxitr=10, window=16)
+            final = r.run()
+            rt = time.perf_counter() - t1
+            refinement = {"family": "20 proteins x 100 aa (tests/golden/refine_prot20x100_s11.json: trace of the reference's Prrn::rir)",
+                          "wall_ms": 1e3 * rt, "divisions_evaluated": len(r.steps), "accepted_moves": sum(1 for x in r.steps if x.accepted),
+                          "gpu_batches": r.batches, "same_branch_sequence_as_reference": [x.branch for x in r.steps] == f["branches"],
+                          "final_msa_identical_to_reference": bool(np.array_equal(final, op.encode(f["final_rows"], f["molc"]))),
+                          "sp_delta_vs_reference": 0.0 if np.array_equal(final, op.encode(f["final_rows"], f["molc"])) else None}
+        except Exception as e:
+            refinement = {"error": str(e)[:200]}
+        try:
+            from prrn_aln_amd import guide
+            if not args.dna:
+                prm, _mtx_keep = alp.to_c()
+                gseqs = [op.encode([row.replace("-", "")], alp.molc)[:, 0].copy() for row in fam.msa]
+                gia, gib = guide.all_pairs(len(gseqs))
+                guide.alnscored_batch(ctx, prm, gseqs, gia[:8], gib[:8])
+                t1 = time.perf_counter()
+                gsc, gst = guide.alnscored_batch(ctx, prm, gseqs, gia, gib)
+                gt = time.perf_counter() - t1
+                glen = np.array([len(x) for x in gseqs], np.int64)
+                guide_tree = {"what": "alnScoreD (Fwd2d::forwardD) for all pairs of the bench family, one call from host buffers",
+                              "pairs": int(len(gia)), "wall_ms": 1e3 * gt, "full_matrix_cells": int((glen[gia] * glen[gib]).sum()),
+                              "failed": int((gst != 0).sum())}
+        except Exception as e:
+            guide_tree = {"error": str(e)[:200]}
     bad = [mine[i] for i, (scr, skl, st) in enumerate(out) if st != 0 or len(skl) < 2]
     my_cells = int(sum(sw.cells[k] for k in mine))
     total_cells = int(sw.cells.sum())
@@ -351,6 +391,10 @@ def main():
         }
         if prog is not None:
             line["config"]["progressive_start"] = prog
+        if refinement is not None:
+            line["config"]["refinement"] = refinement
+        if guide_tree is not None:
+            line["config"]["guide_tree"] = guide_tree
         if sp_ms is not None:
             line["config"]["calcSpScore_ms"] = sp_ms
             line["config"]["calcSpScore_failed"] = sp_bad

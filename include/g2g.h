@@ -254,6 +254,14 @@ typedef struct g2g_dseq {
 } g2g_dseq;
 int        g2g_alnscored_batch(g2g_ctx *ctx, const g2g_params *prm, int nseq, const g2g_dseq *seqs,
                                int npairs, const int32_t *ia, const int32_t *ib, double *score, int32_t *status);
+/* <-> SKL* alignB_ng(const Seq* seqs[], const PwdB* pwd, VTYPE* scr) (reference src/fwd2b1.cc:1347-1353) for the DPs the
+ * reference traces in one piece (fewer than MaxVmfSpace = 16 M cells, lspB_ng :1062-1069 -> trcbkalignB_ng :1025-1051):
+ * Aln2b1::forwardB_ng (:145-279; affine gaps, with prm->ls = 3 the second, long-gap pair of layers) + initB_ng / lastB_ng
+ * (:64-143) + the Vmf record chain + stdskl.  PwdB's constants (BasicGOP ... codonk1, src/aln2.cc:80-120) are formed from
+ * prm's u, v, u1, k1, ls, scale, molc as the reference does.  skl[i]: malloc'ed corners ascending (g2g_free), nskl[i] of them.
+ * Larger DPs (the linear-space recursion) and one-diagonal bands get status G2G_ERR_MODE; local modes are not on this path. */
+int        g2g_alignb_ng_batch(g2g_ctx *ctx, const g2g_params *prm, int nseq, const g2g_dseq *seqs, int npairs,
+                               const int32_t *ia, const int32_t *ib, double *scr, g2g_skl **skl, int *nskl, int32_t *status);
 
 #ifdef __cplusplus
 }

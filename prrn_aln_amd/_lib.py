@@ -50,6 +50,9 @@ def lib():
     L.g2g_stdskl.argtypes = [C.POINTER(_abi.Skl), C.c_int, C.POINTER(C.c_int)]
     L.g2g_alnscored_batch.argtypes = [C.c_void_p, C.POINTER(_abi.Params), C.c_int, C.POINTER(_abi.DSeq), C.c_int,
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), _abi.c_f64p, C.POINTER(C.c_int32)]
+    L.g2g_alignb_ng_batch.argtypes = [C.c_void_p, C.POINTER(_abi.Params), C.c_int, C.POINTER(_abi.DSeq), C.c_int,
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), _abi.c_f64p, C.POINTER(C.POINTER(_abi.Skl)),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int32)]
     bind_level1(L)
     _lib = L
     return L

@@ -1272,3 +1272,4 @@ extern "C" int g2g_forward_batch(g2g_ctx *ctx, int n, const g2g_problem *const *
 }
 
 #include "g2g_dist.hip"                // f3: the guide-tree DPs (own kernels, own entry point; shares the context)
+#include "g2g_pairaln.hip"             // f3: alignB_ng (pairwise alignment of single sequences with the path)

@@ -61,6 +61,35 @@ def alnscored_batch(ctx, prm: "_abi.Params", seqs: Sequence[np.ndarray], ia: Seq
     return out, st
 
 
+def alignb_ng_batch(ctx, prm: "_abi.Params", seqs: Sequence[np.ndarray], ia: Sequence[int], ib: Sequence[int]):
+    """alignB_ng for every index pair: [(score, skeleton (n, 2) int32, status)]"""
+    L = lib()
+    ds = (_abi.DSeq * len(seqs))()
+    keep = []
+    for k, s in enumerate(seqs):
+        x = np.ascontiguousarray(s, np.uint8)
+        keep.append(x)
+        ds[k].res = x.ctypes.data_as(_abi.c_u8p)
+        ds[k].len, ds[k].left, ds[k].right = len(x), 0, len(x)
+    ia = np.ascontiguousarray(ia, np.int32); ib = np.ascontiguousarray(ib, np.int32)
+    n = len(ia)
+    scr = np.zeros(n, np.float64); st = np.zeros(n, np.int32)
+    skl = (C.POINTER(_abi.Skl) * max(n, 1))(); nskl = (C.c_int * max(n, 1))()
+    rc = L.g2g_alignb_ng_batch(ctx._h, C.byref(prm), len(seqs), ds, n, ia.ctypes.data_as(C.POINTER(C.c_int32)),
+                               ib.ctypes.data_as(C.POINTER(C.c_int32)), scr.ctypes.data_as(_abi.c_f64p), skl, nskl,
+                               st.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise G2GError("g2g_alignb_ng_batch rc=%d: %s" % (rc, last_error()))
+    out = []
+    for k in range(n):
+        a = np.zeros((nskl[k], 2), np.int32)
+        if nskl[k] and skl[k]:
+            a[:] = np.ctypeslib.as_array(C.cast(skl[k], C.POINTER(C.c_int32)), shape=(nskl[k] * 2,)).reshape(-1, 2)
+            L.g2g_free(skl[k])
+        out.append((float(scr[k]), a, int(st[k])))
+    return out
+
+
 def distance_matrix(ctx, prm: "_abi.Params", seqs: Sequence[np.ndarray], simmtx: np.ndarray) -> np.ndarray:
     """dpscore over all pairs: the condensed distance vector (pair order of all_pairs), 100 x as the reference stores it"""
     ia, ib = all_pairs(len(seqs))

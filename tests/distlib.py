@@ -36,3 +36,21 @@ def oracle_scores(d, seqs):
         assert rc == 0, rc
         out[k] = v.value
     return out
+
+
+def oracle_alignb(d, seqs, k1=7, u1=0.6):
+    """g2g_oracle_alignb_ng for every pair of a fixture: [(score, skeleton (n, 2) int32, pwd constants)]"""
+    L = oraclelib.load()
+    L.g2g_oracle_alignb_ng.argtypes = [C.POINTER(_abi.Params), C.POINTER(_abi.DSeq), C.POINTER(_abi.DSeq), C.POINTER(C.c_double),
+                                       C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    p = params(d)
+    p.k1, p.u1, p.molc = k1, u1, int(d["molc"][0])
+    ds = [_abi.dseq(s) for s in seqs]
+    out = []
+    for i, j in zip(d["ia"], d["ib"]):
+        v = C.c_double(); sk = C.POINTER(_abi.Skl)(); n = C.c_int(); pw = (C.c_double * 6)()
+        rc = L.g2g_oracle_alignb_ng(C.byref(p), C.byref(ds[i]), C.byref(ds[j]), C.byref(v), C.byref(sk), C.byref(n), pw)
+        assert rc == 0, rc
+        out.append((v.value, oraclelib.skl_to_np(sk, n.value), list(pw)))
+        L.g2g_oracle_free(sk)
+    return out

@@ -34,3 +34,17 @@ def test_host_distance_formula_matches_reference(path):
     assert np.array_equal(selfs, d["selfscr"])
     got = guide.scores_to_dist(d["alnscored"], d["ia"], d["ib"], d["lens"], selfs, float(d["u"][0]))
     assert np.array_equal(got, d["dist"]), np.abs(got - d["dist"]).max()
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_oracle_alignb_ng_matches_reference(path):
+    """g2g_oracle_alignb_ng (forwardB_ng + initB_ng + lastB_ng + the Vmf chain + stdskl) against the reference's alignB_ng: score,
+    skeleton and PwdB's constants for every pair"""
+    d = dict(np.load(path))
+    seqs = distlib.split(d)
+    res = distlib.oracle_alignb(d, seqs)
+    off = np.concatenate([[0], np.cumsum(d["alignb_nskl"])])
+    for k, (scr, skl, pw) in enumerate(res):
+        assert scr == d["alignb_scr"][k], (k, scr, d["alignb_scr"][k])
+        assert np.array_equal(skl, d["alignb_skl"][off[k]:off[k + 1]]), k
+        assert pw == list(d["pwdb"])

@@ -77,3 +77,47 @@ def test_bad_sequences_fail_their_pairs_only(ctx):
     assert np.array_equal(got[~hit], d["alnscored"][~hit])
     got, st = guide.alnscored_batch(ctx, distlib.params(d), seqs, [], [])
     assert len(got) == 0
+
+
+def _alp_params(d):
+    p = distlib.params(d)
+    p.k1, p.u1, p.molc = 7, 0.6, int(d["molc"][0])
+    return p
+
+
+@pytest.mark.parametrize("hbm", [False, True], ids=["lds", "hbm"])
+def test_alignb_ng_matches_reference_goldens(ctx, hbm):
+    """g2g_alignb_ng_batch: score and standardised skeleton of every pair equal the reference's alignB_ng (Noll 2 and 3,
+    banded and not, terminal gaps discounted and not)"""
+    ctx.reset_options()
+    if hbm:
+        ctx.set_option("DIST_HBM", 1)
+    try:
+        for path in GOLD:
+            d = dict(np.load(path))
+            seqs = distlib.split(d)
+            res = guide.alignb_ng_batch(ctx, _alp_params(d), seqs, d["ia"], d["ib"])
+            off = np.concatenate([[0], np.cumsum(d["alignb_nskl"])])
+            for k, (scr, skl, st) in enumerate(res):
+                assert st == 0, (path, k, st)
+                assert scr == d["alignb_scr"][k], (path, k, scr, d["alignb_scr"][k])
+                assert np.array_equal(skl, d["alignb_skl"][off[k]:off[k + 1]]), (path, k)
+    finally:
+        ctx.reset_options()
+
+
+@pytest.mark.parametrize("ls", [1, 3])
+def test_alignb_ng_larger_vs_oracle(ctx, ls):
+    g = dict(np.load([p for p in GOLD if "prot12" in p][0]))
+    g["ls"] = np.array([ls])
+    from prrn_aln_amd import operator as op
+    fam = make_family(16, 500, 61 + ls, indel=0.05, max_indel=60)
+    rows = [r.replace("-", "")[: 200 + 25 * k] for k, r in enumerate(fam.msa)]
+    seqs = [op.encode([r], op.PROTEIN)[:, 0].copy() for r in rows]
+    ia, ib = guide.all_pairs(len(seqs))
+    d = dict(g); d["ia"], d["ib"] = ia, ib
+    got = guide.alignb_ng_batch(ctx, _alp_params(g), seqs, ia, ib)
+    want = distlib.oracle_alignb(d, seqs)
+    for k, ((scr, skl, st), (oscr, oskl, _)) in enumerate(zip(got, want)):
+        assert st == 0 and scr == oscr, (k, st, scr, oscr)
+        assert np.array_equal(skl, oskl), k
