@@ -44,12 +44,16 @@ namespace {
 
 struct Stats {
 	long	calls, gpu, cpu, mismatch, batches, maxbatch;
+	long	dcalls, dgpu, dcpu, dmismatch, dbatches, dmaxbatch;	// alnScoreD (the guide-tree stage)
 	~Stats() {
-	    if (getenv("G2G_BIND_STATS"))
+	    if (getenv("G2G_BIND_STATS")) {
 		fprintf(stderr, "g2g_bind: %ld align2 calls, %ld on the GPU, %ld by the reference, %ld mismatches"
 		    "; %ld GPU batches, largest %ld\n", calls, gpu, cpu, mismatch, batches, maxbatch);
+		fprintf(stderr, "g2g_bind: %ld alnScoreD calls, %ld on the GPU, %ld by the reference, %ld mismatches"
+		    "; %ld GPU batches, largest %ld\n", dcalls, dgpu, dcpu, dmismatch, dbatches, dmaxbatch);
+	    }
 	}
-} stats = {0, 0, 0, 0, 0, 0};
+} stats = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 std::mutex	stats_mu;		// (prrn5 -t<n> calls align2 from several pthreads)
 #define COUNT(field) do {std::lock_guard<std::mutex> l_(stats_mu); ++stats.field;} while (0)
 
@@ -327,4 +331,116 @@ extern "C" SKL* __wrap__Z6align2PP4mSeqP4PwdMPdP6Gsinfo(mSeq* seqs[], PwdM* pwdm
 	if (handled) {COUNT(gpu); return skl;}
 	COUNT(cpu);
 	return __real__Z6align2PP4mSeqP4PwdMPdP6Gsinfo(seqs, pwdm, scr, GsI);
+}
+
+// ---- f3: alnScoreD (src/fwd2d1.cc:324-338), the score-only DP behind dpscore() (src/phyl.cc:222-252) ------------------
+// DistMat runs dpscore for every pair of members, one call per pair, from as many pthreads as -t gives: the calls that
+// arrive together go to the device as ONE g2g_alnscored_batch (same leader scheme as align2 above).
+extern "C" VTYPE __real__Z9alnScoreDPPK3SeqPK6SimmtxPi(const Seq* seqs[], const Simmtx* sm, int* ends);
+
+namespace {
+
+struct DReq {const Seq* a; const Seq* b; const Simmtx* sm; double score; int status; bool done;};
+struct DistBatcher {
+	std::mutex	mu;
+	std::condition_variable	cv;
+	std::vector<DReq*>	pending;
+	std::set<std::thread::id>	callers;
+	bool	busy;
+	DistBatcher() : busy(false) {}
+	void run(g2g_ctx* ctx, std::vector<DReq*>& mine) {
+	    const int	n = (int) mine.size();
+	    const Simmtx*	sm = mine[0]->sm;
+	    std::vector<double>	mtx((size_t) sm->rows * sm->dim);
+	    for (int i = 0; i < sm->rows; ++i)
+		for (int j = 0; j < sm->dim; ++j) mtx[(size_t) i * sm->dim + j] = sm->mtx[i][j];
+	    g2g_params	prm;
+	    memset(&prm, 0, sizeof prm);
+	    prm.u = alprm.u; prm.v = alprm.v; prm.scale = alprm.scale; prm.tgapf = alprm.tgapf; prm.sh = alprm.sh;
+	    prm.u1 = alprm.u1; prm.k1 = alprm.k1; prm.ls = alprm.ls;
+	    prm.simmtx = mtx.data(); prm.simdim = sm->dim; prm.simrows = sm->rows;
+	    std::vector<g2g_dseq>	sq(2 * (size_t) n);
+	    std::vector<int32_t>	ia(n), ib(n), st(n);
+	    std::vector<double>	sc(n);
+	    for (int i = 0; i < n; ++i) {
+		const Seq*	s2[2] = {mine[i]->a, mine[i]->b};
+		for (int k = 0; k < 2; ++k) {
+		    g2g_dseq&	d = sq[2 * i + k];
+		    d.res = s2[k]->at(0); d.len = s2[k]->len; d.left = s2[k]->left; d.right = s2[k]->right;
+		}
+		ia[i] = 2 * i; ib[i] = 2 * i + 1;
+	    }
+	    const int	rc = g2g_alnscored_batch(ctx, &prm, 2 * n, sq.data(), n, ia.data(), ib.data(), sc.data(), st.data());
+	    for (int i = 0; i < n; ++i) {mine[i]->score = sc[i]; mine[i]->status = rc != G2G_OK? rc: st[i];}
+	    std::lock_guard<std::mutex>	l2(stats_mu);
+	    ++stats.dbatches;
+	    if (n > stats.dmaxbatch) stats.dmaxbatch = n;
+	}
+	void submit(g2g_ctx* ctx, DReq* q) {
+	    std::unique_lock<std::mutex>	lk(mu);
+	    callers.insert(std::this_thread::get_id());
+	    pending.push_back(q);
+	    cv.notify_all();
+	    while (!q->done) {
+		if (busy) {cv.wait(lk); continue;}
+		busy = true;
+		if (callers.size() > 1) {
+		    static const long	quiet = getenv("G2G_BIND_QUIET_US")? atol(getenv("G2G_BIND_QUIET_US")): 500;
+		    const auto	t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(15 * quiet);
+		    for (;;) {
+			const size_t	before = pending.size();
+			cv.wait_for(lk, std::chrono::microseconds(quiet));
+			if (pending.size() == before || pending.size() >= callers.size() ||
+			    std::chrono::steady_clock::now() >= t_end) break;
+		    }
+		}
+		std::vector<DReq*>	mine, rest;
+		for (DReq* r : pending) (r->sm == pending[0]->sm? mine: rest).push_back(r);	// (one matrix per batch)
+		pending.swap(rest);
+		lk.unlock();
+		run(ctx, mine);
+		lk.lock();
+		for (DReq* r : mine) r->done = true;
+		busy = false;
+		cv.notify_all();
+	    }
+	}
+} dist_batcher;
+
+}	// namespace
+
+extern "C" VTYPE __wrap__Z9alnScoreDPPK3SeqPK6SimmtxPi(const Seq* seqs[], const Simmtx* sm, int* ends)
+{
+	static const char*	mode = getenv("G2G_BIND");
+	COUNT(dcalls);
+	const bool	off = mode && !strcmp(mode, "off");
+	const bool	verify = mode && !strcmp(mode, "verify");
+	const Seq*	a = seqs[0];
+	const Seq*	b = seqs[1];
+	if (!sm) sm = getSimmtx(0);
+	// on the GPU path: the global, score-only branch between two single sequences taken whole (Fwd2d with exgl = exgr = 0 and
+	// left = 0, what dpscore passes); everything else is the reference's
+	static const bool	no_dist = getenv("G2G_BIND_NO_DIST") != 0;	// (A/B switch of this wrap alone)
+	g2g_ctx*	ctx = (off || no_dist)? 0: context();
+	if (!ctx || ends || (algmode.lcl & 16) || a->many != 1 || b->many != 1 || a->left || b->left ||
+	    a->inex.exgl || b->inex.exgl || a->inex.exgr || b->inex.exgr || a->right <= a->left || b->right <= b->left) {
+	    COUNT(dcpu);
+	    return __real__Z9alnScoreDPPK3SeqPK6SimmtxPi(seqs, sm, ends);
+	}
+	DReq	q = {a, b, sm, 0, 0, false};
+	dist_batcher.submit(ctx, &q);
+	if (q.status != G2G_OK) {
+	    COUNT(dcpu);
+	    return __real__Z9alnScoreDPPK3SeqPK6SimmtxPi(seqs, sm, ends);
+	}
+	COUNT(dgpu);
+	if (verify) {
+	    const VTYPE	ref = __real__Z9alnScoreDPPK3SeqPK6SimmtxPi(seqs, sm, ends);
+	    if (ref != (VTYPE) q.score) {
+		COUNT(dmismatch);
+		fprintf(stderr, "g2g_bind: MISMATCH alnScoreD %.17g vs %.17g\n", q.score, (double) ref);
+	    }
+	    return ref;
+	}
+	return (VTYPE) q.score;
 }

@@ -80,8 +80,19 @@ extern "C" const char *g2g_get_option(const g2g_ctx *c, const char *name)
 
 extern "C" __global__ void g2g_clock_kernel(unsigned long long *out) { *out = __builtin_amdgcn_s_memrealtime(); }
 
+// The first HIP call of a process initialises the runtime, and that initialisation draws from / reseeds glibc's random()
+// state (measured: srand(1); rand(); <HIP init>; rand() no longer gives 846930886).  The reference seeds its own generator
+// from rand() (McRand, src/randiv.cc:41-50) and breaks ties with rand() elsewhere, so a drop-in library must leave that
+// state alone: HIP initialises against a private state array, the caller's is put back.  (Later HIP calls do not touch it.)
+struct RandStateGuard {
+    char buf[256]; char *prev;
+    RandStateGuard() { prev = initstate(1u, buf, sizeof buf); }
+    ~RandStateGuard() { if (prev) setstate(prev); }
+};
+
 extern "C" g2g_ctx *g2g_create(int device)
 {
+    RandStateGuard keep_host_rand;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         g2g_set_error("%s", "no HIP device visible");

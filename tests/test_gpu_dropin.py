@@ -122,3 +122,33 @@ def test_aln_intron_annotated_pair_stays_with_the_reference():
     assert calls == 1 and gpu == 0 and cpu == 1 and bad == 0, err[-500:]
     assert "Score = 2325.0" in out
     assert out == ref_out
+
+
+def _dstats(err):
+    m = re.search(r"g2g_bind: (\d+) alnScoreD calls, (\d+) on the GPU, (\d+) by the reference, (\d+) mismatches; (\d+) GPU batches, largest (\d+)", err)
+    assert m, err[-2000:]
+    return tuple(int(x) for x in m.groups())
+
+
+@pytest.mark.parametrize("threads", [[], ["-t8"]], ids=["serial", "t8"])
+def test_prrn5_from_unaligned_sequences_guide_tree_on_gpu(tmp_path, threads):
+    """The whole program from unaligned sequences: the distance matrix (dpscore -> alnScoreD, one call per pair of members),
+    the progressive alignment and the refinement.  With the binding every alnScoreD and align2 runs on the GPU (f3 + a1..a9);
+    the output must be the unmodified program's, byte for byte."""
+    tmp = str(tmp_path)
+    fam = make_family(n_seq=14, length=120, seed=21, indel=0.03, max_indel=8)
+    with open(os.path.join(tmp, "fam.fa"), "w") as fd:
+        for i, r in enumerate(fam.msa):
+            fd.write(">s%03d\n%s\n" % (i, r.replace("-", "")))
+    opts = ["-R1", "-O4"] + threads + ["fam.fa"]
+    ref_out, _ = _run("prrn5", opts, tmp)
+    out, err = _run("prrn5_g2g", opts, tmp, G2G_BIND_QUIET_US="3000")
+    dcalls, dgpu, dcpu, dbad, dbatches, dlargest = _dstats(err)
+    assert dcalls >= 14 * 13 // 2 and dgpu == dcalls and dbad == 0, err[-600:]
+    calls, gpu, cpu, bad = _stats(err)
+    assert gpu > 0 and bad == 0
+    assert out == ref_out
+    if threads:
+        assert dlargest > 1 and dbatches < dgpu, (dbatches, dlargest, dgpu)
+    out, err = _run("prrn5_g2g", opts, tmp, mode="verify")
+    assert _dstats(err)[3] == 0 and _stats(err)[3] == 0, err[-600:]

@@ -140,3 +140,15 @@ def test_context_options(ctx, monkeypatch):
     finally:
         other.close()
         ctx.reset_options()
+
+
+def test_context_creation_leaves_the_hosts_rand_sequence_alone():
+    """HIP's initialisation perturbs glibc's random() state; the reference seeds its division order from rand() (randiv.cc:41),
+    so g2g_create must hand the state back untouched (fresh process: the runtime initialises only once)."""
+    import subprocess, sys
+    code = ("import ctypes, sys; libc = ctypes.CDLL('libc.so.6'); libc.srand(1); a = libc.rand();\n"
+            "from prrn_aln_amd import engine; c = engine.Context(); b = libc.rand(); d = libc.rand(); c.close(); print(a, b, d)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-800:]
+    assert out.stdout.split() == ["1804289383", "846930886", "1681692777"], out.stdout
