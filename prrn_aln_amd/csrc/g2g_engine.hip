@@ -252,6 +252,7 @@ struct g2g_batch {
     long long ntiles;
     float fwd_ms, tb_ms;
     double *simscr[20]; size_t simscr_cap[20];
+    int hdr_img[G2G_HDR + 4];       // host image of the queue heads + wait header of the current run
     std::vector<const g2g_problem *> src;        // the caller's problems (kept alive by the caller until the batch is freed): a DP
                                                  // that lost a wait is re-run from here on the non-polling kernel
     int fail_off;                                // offset of the per-DP fail flags in d_flags
@@ -907,13 +908,16 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             ++b->gen;
         }
         {   // queue heads; header of the waits (g2g_wait_ge): time-outs, first slot, offset of the fail flags, wall-clock limit
-            int hdr[G2G_HDR + 4];
-            memset(hdr, 0, sizeof hdr);
-            double limit_ms = 20000.;
+            // (the image lives in the batch: an asynchronous copy from pageable memory may read its source after the call returns)
+            int *hdr = b->hdr_img;
+            memset(hdr, 0, sizeof b->hdr_img);
+            // a legitimate wait lasts as long as the strip above needs for one publish interval, or a boundary chain for its
+            // sequential walk: milliseconds.  3 s of wall clock means the producer is not running.
+            double limit_ms = 3000.;
             if (const char *e = g2g_opt(ctx, "WAIT_LIMIT_MS")) { const double v = atof(e); if (v > 0) limit_ms = v; }
             hdr[G2G_HDR + 2] = b->fail_off;
             hdr[G2G_HDR + 3] = (int) std::min(2.0e9, limit_ms * ctx->rt_ticks_per_ms / 65536.) + 1;
-            HIPCHK(hipMemcpyAsync(b->d_flags, hdr, sizeof hdr, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemcpyAsync(b->d_flags, hdr, sizeof b->hdr_img, hipMemcpyHostToDevice, ctx->stream));
             HIPCHK(hipMemsetAsync(b->d_flags + b->fail_off, 0, sizeof(int) * (size_t) (b->n > 0 ? b->n : 1), ctx->stream));
         }
         HIPCHK(hipEventRecord(ctx->vev[4], ctx->stream));
@@ -1056,7 +1060,12 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipMemcpy(fail.data(), b->d_flags + b->fail_off, sizeof(int) * (size_t) b->n, hipMemcpyDeviceToHost));
             std::vector<int> lost;
             for (int i = 0; i < b->n; ++i) if (fail[i] && !b->status[i]) lost.push_back(i);
-            if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] s_memrealtime: %.0f ticks/ms; ", ctx->rt_ticks_per_ms); fprintf(stderr, "[g2g] %d waits timed out (first: queue slot %d): re-running %zu DP(s) on g2g_forward_kernel\n", rep[G2G_HDR], rep[G2G_HDR + 1], lost.size()); fflush(stderr); }
+            if (g2g_opt(ctx, "DEBUG") || g2g_opt(ctx, "WARN")) {
+                fprintf(stderr, "[g2g] s_memrealtime: %.0f ticks/ms; ", ctx->rt_ticks_per_ms);
+                fprintf(stderr, "[g2g] %d waits timed out (first: queue slot %d, gen %d): re-running %zu DP(s) on g2g_forward_kernel:", rep[G2G_HDR], rep[G2G_HDR + 1], b->gen, lost.size());
+                for (size_t k = 0; k < lost.size() && k < 12; ++k) fprintf(stderr, " %d(kernel %d, %d x %d)", lost[k], b->dp[lost[k]].v2_ok, b->dp[lost[k]].a.right - b->dp[lost[k]].a.left, b->dp[lost[k]].b.right - b->dp[lost[k]].b.left);
+                fprintf(stderr, "\n"); fflush(stderr);
+            }
             if (b->force_v1 || lost.empty()) { g2g_set_error("%s", "scheduler: a wait timed out and no DP could be singled out"); return G2G_ERR_DEVICE; }
             std::vector<const g2g_problem *> pp;
             for (int i : lost) pp.push_back(b->src[i]);
