@@ -240,6 +240,45 @@ int        g2g_homscore(g2g_ctx *ctx, g2g_pwdm *p, double *scr, int64_t rr[2]);
 int        g2g_align2_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *p, double *scr,
                             g2g_skl **skl, int *nskl, int *status);
 
+/* ---- f2: the refinement loop --------------------------------------------------------------------------------------
+ * <-> Prrn::rir (reference src/prrn5.cc:633-666) with onecycle / divideseq / gather / calcfact (:414-543), Randiv in TREEDIV
+ * mode + McRand (src/randiv.cc:34-239, the glibc rand() seeding included), delcommongap / synthgap (src/mgaps.cc:181-369) and
+ * gap2skl (src/gaps.cc:274): randomised iterative refinement of an MSA over the branches of its weighting tree.  The SERIAL
+ * trajectory of the reference is reproduced -- same branch sequence, same accepted moves, same final MSA -- while the DPs of a
+ * WINDOW of upcoming divisions run as one batch on the GPU (speculation: the divisions behind an accepted move are drawn again).
+ *   codes: len x many residue codes [column][member] (gap = 1), no all-gap column.
+ *   tree : Ktree::lead[] (src/phyl.h): node id = tid, leaves 0 .. many-1 are the members, left / right / parent = -1 where
+ *          absent, vol / cur = the Kirchhoff weights the reference's Ktree computed (building the tree is phylogeny code,
+ *          outside this path).
+ *   opts : seed (Randiv's rn: 1 = "seed from rand()" as prrn does), maxitr (prrn -I, default 10), window (largest speculative
+ *          batch, default 32).  rank / world / exchange: with world > 1 every rank calls g2g_refine with the SAME inputs; a
+ *          window is sharded (largest rectangles first, round-robin), each rank scores its share and `exchange` all-gathers
+ *          the fixed-size result slots (n_ints int32 per rank in, world x n_ints out, rank-major) -- RCCL / MPI / gloo on the
+ *          caller's side; every rank then takes the same decisions and ends with the same MSA.  Return 0 from the callback.
+ * Outputs: *out_codes (malloc'ed, *out_len x many; g2g_free), the trajectory (*steps, malloc'ed; may be NULL) and counters. */
+typedef struct g2g_tree {
+    int32_t n_nodes;                /* 2 * many - 1                                                */
+    const int32_t *left, *right, *parent;
+    const double  *vol, *cur;
+} g2g_tree;
+typedef int (*g2g_exchange_fn)(void *user, const int32_t *mine, int n_ints, int32_t *all);
+typedef struct g2g_refine_opts {
+    int32_t seed, maxitr, window;
+    int32_t rank, world, slot_cap;  /* slot_cap: most corners of a skeleton an exchange slot holds (default 4096) */
+    g2g_exchange_fn exchange;
+    void   *exchange_user;
+} g2g_refine_opts;
+typedef struct g2g_refine_step {
+    int32_t branch, na, nb, swp, accepted, skipped;   /* skipped: neither group had a column to drop -- no DP (prrn5.cc:497) */
+    double  scr, val_new, val_old, delta;             /* DP score; fstat.val of the new alignment; raw score of the current one */
+} g2g_refine_step;
+typedef struct g2g_refine_stats {
+    int32_t divisions, accepted, batches, divisions_scored_here, divisions_wasted, reserved;
+} g2g_refine_stats;
+int        g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len, const uint8_t *codes, const g2g_tree *tree,
+                      const g2g_refine_opts *opts, uint8_t **out_codes, int *out_len, g2g_refine_step **steps, int *nsteps,
+                      g2g_refine_stats *stats);
+
 /* ---- f3: the guide-tree stage -- score-only pairwise DPs between single sequences ----------------------
  * <-> VTYPE alnScoreD(const Seq* seqs[], const Simmtx* sm, int* ends = 0) (reference src/fwd2d1.cc:324-338), global branch:
  * Fwd2d::Fwd2d (the boundary values, :58-93), Fwd2d::forwardD (:136-158, anti-diagonal order, affine gaps -(v + k u),

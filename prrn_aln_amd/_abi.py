@@ -68,6 +68,30 @@ def dseq(codes: np.ndarray) -> "DSeq":
     return d
 
 
+class Tree(C.Structure):
+    """g2g_tree: the weighting tree (Ktree::lead[]) of g2g_refine"""
+    _fields_ = [("n_nodes", C.c_int32), ("left", C.POINTER(C.c_int32)), ("right", C.POINTER(C.c_int32)),
+                ("parent", C.POINTER(C.c_int32)), ("vol", c_f64p), ("cur", c_f64p)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32))
+
+
+class RefineOpts(C.Structure):
+    _fields_ = [("seed", C.c_int32), ("maxitr", C.c_int32), ("window", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
+                ("slot_cap", C.c_int32), ("exchange", EXCHANGE_FN), ("exchange_user", C.c_void_p)]
+
+
+class RefineStep(C.Structure):
+    _fields_ = [("branch", C.c_int32), ("na", C.c_int32), ("nb", C.c_int32), ("swp", C.c_int32), ("accepted", C.c_int32),
+                ("skipped", C.c_int32), ("scr", C.c_double), ("val_new", C.c_double), ("val_old", C.c_double), ("delta", C.c_double)]
+
+
+class RefineStats(C.Structure):
+    _fields_ = [("divisions", C.c_int32), ("accepted", C.c_int32), ("batches", C.c_int32), ("divisions_scored_here", C.c_int32),
+                ("divisions_wasted", C.c_int32), ("reserved", C.c_int32)]
+
+
 def _ptr(arr: np.ndarray, typ):
     return arr.ctypes.data_as(typ)
 

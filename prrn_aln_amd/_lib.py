@@ -53,6 +53,9 @@ def lib():
     L.g2g_alignb_ng_batch.argtypes = [C.c_void_p, C.POINTER(_abi.Params), C.c_int, C.POINTER(_abi.DSeq), C.c_int,
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), _abi.c_f64p, C.POINTER(C.POINTER(_abi.Skl)),
                                       C.POINTER(C.c_int), C.POINTER(C.c_int32)]
+    L.g2g_refine.argtypes = [C.c_void_p, C.POINTER(_abi.Params), C.c_int, C.c_int, _abi.c_u8p, C.POINTER(_abi.Tree),
+                             C.POINTER(_abi.RefineOpts), C.POINTER(_abi.c_u8p), C.POINTER(C.c_int),
+                             C.POINTER(C.POINTER(_abi.RefineStep)), C.POINTER(C.c_int), C.POINTER(_abi.RefineStats)]
     bind_level1(L)
     _lib = L
     return L

@@ -1,0 +1,411 @@
+// g2g_refine.cpp -- SURVEY.md section 8, row f2: prrn's randomised iterative refinement behind the C ABI (g2g_refine), host side
+// in C++ on top of level 1 of the same ABI (g2g_group_create / g2g_pwdm_create / g2g_align2_batch / g2g_spscore_batch).
+//
+// What the reference does (Prrn::rir / onecycle / divideseq / gather / calcfact, reference src/prrn5.cc:414-666; Randiv and
+// McRand, src/randiv.cc:34-239; synthgap / delcommongap / aggregate, src/mgaps.cc:181-369; gap2skl, src/gaps.cc:274): draw a
+// branch of the weighting tree, split the MSA into the two groups on either side of it, drop the columns that became all-gap
+// in each, re-align the two groups, and keep the new alignment if its weighted sum-of-pairs score beats the current one's.
+// One accepted move changes the MSA every later division is taken from: a sequential hill climb.
+//
+// Here the SAME trajectory is produced with the DPs batched.  The branch sequence does not depend on outcomes (a mixed
+// congruential generator), so a WINDOW of upcoming divisions is built from the current MSA (groups and PwdMs on host threads),
+// evaluated in one g2g_align2_batch + one g2g_spscore_batch, looked at in generator order; the first improving division is
+// applied and the ones behind it are drawn again.  With an exchange callback the window is sharded over ranks: every rank
+// scores its share, the callback all-gathers fixed-size result slots (RCCL / gloo on the caller's side), and every rank takes
+// the same decisions on the same numbers -- no broadcast of the MSA is ever needed.
+//
+// Own formulation, not the reference's data structures: the MSA is a (columns x members) matrix of residue codes instead of
+// per-member gap-run lists; a division's current skeleton is read off that matrix; an accepted skeleton is applied by
+// interleaving the two groups' columns.  The tree (topology, Kirchhoff vol / cur per node) is an input.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <algorithm>
+#include <thread>
+#include <atomic>
+#include "../../include/g2g.h"
+#include "g2g_internal.h"
+
+namespace {
+
+const uint8_t GAP = 1;
+const double FEPS = 1.0e-7;                                   // reference src/cmn.h:54
+
+// glibc's rand() / srand() (TYPE_3 additive feedback, r[i] = r[i-3] + r[i-31]): McRand seeds itself from them
+// (src/randiv.cc:41-51).  Restated so that the library neither depends on nor disturbs the host's generator.
+struct GlibcRand {
+    std::vector<uint32_t> r;
+    explicit GlibcRand(uint32_t seed = 1) { srand_(seed); }
+    void srand_(uint32_t seed)
+    {
+        if (seed == 0) seed = 1;
+        int64_t s[34];
+        s[0] = (int32_t) seed;
+        for (int i = 1; i < 31; ++i) {
+            const int64_t hi = s[i - 1] / 127773, lo = s[i - 1] % 127773;       // (C division: truncation toward zero)
+            int64_t w = 16807 * lo - 2836 * hi;
+            if (w < 0) w += 2147483647;
+            s[i] = w;
+        }
+        for (int i = 31; i < 34; ++i) s[i] = s[i - 31];
+        r.clear();
+        for (int i = 0; i < 34; ++i) r.push_back((uint32_t) s[i]);
+        for (int i = 0; i < 310; ++i) next();
+    }
+    uint32_t next()
+    {
+        const uint32_t v = r[r.size() - 31] + r[r.size() - 3];
+        r.push_back(v);
+        if (r.size() > 64) r.erase(r.begin(), r.end() - 34);
+        return v;
+    }
+    int rand_() { return (int) (next() >> 1); }
+};
+
+// mixed congruential generator over [0, 2^p), src/randiv.cc:34-56, randiv.h:36-47
+struct McRand {
+    uint64_t mod, coef, val;
+    McRand(int p, int rn)
+    {
+        GlibcRand libc;
+        mod = (uint64_t) 1 << p;
+        if (rn == 0) { coef = 1; val = mod - 1; return; }
+        const int v = rn == 1 ? libc.rand_() : rn;
+        libc.srand_((uint32_t) v);
+        coef = (uint64_t) ((libc.rand_() / 4 * 4 + 5) % (int64_t) mod);
+        val = (uint64_t) v % mod;
+    }
+    int next() { val = (coef * val + 1) % mod; return (int) val; }
+};
+
+struct Tree {
+    int nn, nleaf;
+    const int32_t *left, *right, *parent;
+    const double *vol, *cur;
+    void leaves(int tid, std::vector<int> &out) const
+    {
+        out.clear();
+        std::vector<int> st(1, tid);
+        while (!st.empty()) {
+            const int k = st.back(); st.pop_back();
+            if (left[k] < 0 && right[k] < 0) out.push_back(k);
+            else { st.push_back(right[k]); st.push_back(left[k]); }
+        }
+        std::sort(out.begin(), out.end());
+    }
+    // Prrn::calcfact / childfact (src/prrn5.cc:414-441): weight of every member when the tree is cut above node tid
+    double calcfact(int tid, std::vector<double> &w) const
+    {
+        w.assign((size_t) nleaf, 0.);
+        std::vector<int> lv;
+        auto child = [&](int node, double fact) { leaves(node, lv); for (int l : lv) w[l] = vol[l] * fact; };
+        int node = tid;
+        child(node, 1.0 / vol[node]);
+        double fact = 1.0;
+        while (parent[node] >= 0) {
+            const int father = parent[node];
+            const int other = left[father] != node ? left[father] : right[father];
+            child(other, fact / vol[father]);
+            node = father;
+            fact *= cur[node];
+        }
+        return cur[tid];
+    }
+};
+
+// lt(0, delta), src/cmn.h:63
+inline bool lt0(double d) { return 0.0 < d - FEPS * std::max(1.0, fabs(d)); }
+
+typedef std::vector<g2g_skl> Skl;
+
+struct Division {
+    int branch;
+    std::vector<int> la, lb;                                  // (larger group, smaller group); ties keep the complement first
+    bool skip;
+    double pwt;
+    std::vector<uint8_t> a, b;                                // the groups without their all-gap columns, [row][member]
+    int ra, rb;                                               // rows of a, b
+    Skl old, neu, neu_ab;                                     // current / new skeleton in PwdM order; new in (la, lb) order
+    g2g_group *ga, *gb;
+    g2g_pwdm *pw;
+    int swp;
+    double scr, val_old, val_new, delta;
+    int status;
+    Division() : branch(0), skip(false), pwt(0), ra(0), rb(0), ga(0), gb(0), pw(0), swp(0), scr(0), val_old(0), val_new(0), delta(0), status(0) {}
+};
+
+struct Msa { int len, many; std::vector<uint8_t> c; uint8_t at(int r, int m) const { return c[(size_t) r * many + m]; } };
+
+// the two groups of a division without their all-gap columns, and the skeleton of their CURRENT alignment (what delcommongap +
+// gap2skl give the reference): corners (m, n) where the heading changes
+void split_columns(const Msa &M, Division &d)
+{
+    const int na = (int) d.la.size(), nb = (int) d.lb.size();
+    d.a.clear(); d.b.clear(); d.old.clear();
+    std::vector<g2g_skl> pts;
+    g2g_skl p = {0, 0};
+    pts.push_back(p);
+    for (int r = 0; r < M.len; ++r) {
+        bool ka = false, kb = false;
+        for (int i = 0; i < na && !ka; ++i) ka = M.at(r, d.la[i]) != GAP;
+        for (int j = 0; j < nb && !kb; ++j) kb = M.at(r, d.lb[j]) != GAP;
+        if (ka) { for (int i = 0; i < na; ++i) d.a.push_back(M.at(r, d.la[i])); ++p.m; }
+        if (kb) { for (int j = 0; j < nb; ++j) d.b.push_back(M.at(r, d.lb[j])); ++p.n; }
+        if (ka || kb) pts.push_back(p);
+    }
+    d.ra = p.m; d.rb = p.n;
+    for (size_t k = 0; k < pts.size(); ++k) {
+        bool corner = k == 0 || k + 1 == pts.size();
+        if (!corner) corner = (pts[k + 1].m - pts[k].m != pts[k].m - pts[k - 1].m) || (pts[k + 1].n - pts[k].n != pts[k].n - pts[k - 1].n);
+        if (corner) d.old.push_back(pts[k]);
+    }
+}
+
+// apply a skeleton (synthgap, src/mgaps.cc:350): interleave the columns of the two groups
+bool join_columns(const Division &d, const Skl &skl, int many, Msa &out)
+{
+    const int na = (int) d.la.size(), nb = (int) d.lb.size();
+    out.many = many; out.c.clear();
+    int rows = 0;
+    for (size_t k = 0; k + 1 < skl.size(); ++k) {
+        const int m0 = skl[k].m, n0 = skl[k].n, dm = skl[k + 1].m - m0, dn = skl[k + 1].n - n0;
+        if (!(dm == dn || dm == 0 || dn == 0) || dm < 0 || dn < 0) return false;
+        const int seg = std::max(dm, dn);
+        out.c.resize((size_t) (rows + seg) * many, GAP);
+        for (int t = 0; t < seg; ++t) {
+            uint8_t *row = &out.c[(size_t) (rows + t) * many];
+            if (dm) for (int i = 0; i < na; ++i) row[d.la[i]] = d.a[(size_t) (m0 + t) * na + i];
+            if (dn) for (int j = 0; j < nb; ++j) row[d.lb[j]] = d.b[(size_t) (n0 + t) * nb + j];
+        }
+        rows += seg;
+    }
+    out.len = rows;
+    return true;
+}
+
+void swap_skl(const Skl &in, Skl &out) { out.resize(in.size()); for (size_t k = 0; k < in.size(); ++k) { out[k].m = in[k].n; out[k].n = in[k].m; } }
+
+void free_division(Division &d)
+{
+    if (d.pw) g2g_pwdm_free(d.pw);
+    if (d.ga) g2g_group_free(d.ga);
+    if (d.gb) g2g_group_free(d.gb);
+    d.pw = 0; d.ga = d.gb = 0;
+}
+
+}   // namespace
+
+extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len, const uint8_t *codes, const g2g_tree *tree,
+                          const g2g_refine_opts *opts, uint8_t **out_codes, int *out_len, g2g_refine_step **steps, int *nsteps,
+                          g2g_refine_stats *stats)
+{
+    if (!ctx || !prm || !codes || !tree || !out_codes || !out_len || many < 2 || len < 1) return G2G_ERR_ARG;
+    if (tree->n_nodes != 2 * many - 1 || !tree->left || !tree->right || !tree->parent || !tree->vol || !tree->cur) {
+        g2g_set_error("%s", "g2g_refine: the tree must have 2 * many - 1 nodes (leaves 0 .. many - 1 = the members)");
+        return G2G_ERR_ARG;
+    }
+    g2g_refine_opts O;
+    memset(&O, 0, sizeof O);
+    if (opts) O = *opts;
+    if (O.seed == 0) O.seed = 1;
+    if (O.maxitr <= 0) O.maxitr = 10;
+    if (O.window <= 0) O.window = 32;
+    if (O.world <= 0) { O.world = 1; O.rank = 0; }
+    if (O.slot_cap <= 0) O.slot_cap = 4096;
+    const bool sharded = O.exchange && O.world > 1;
+    const int slot_ints = 9 + 2 * O.slot_cap;
+
+    Tree T;
+    T.nn = tree->n_nodes; T.nleaf = many; T.left = tree->left; T.right = tree->right; T.parent = tree->parent; T.vol = tree->vol; T.cur = tree->cur;
+    // Randiv in TREEDIV mode (src/randiv.cc:158-178,217-226)
+    const int cycle = 2 * many - 3;
+    int p2 = 0;
+    for (int x = 1; x < cycle; x <<= 1) ++p2;
+    McRand mcr(p2, O.seed);
+    auto next_branch = [&]() { for (;;) { const int r = mcr.next(); if (r < cycle) return r; } };
+
+    Msa M;
+    M.len = len; M.many = many; M.c.assign(codes, codes + (size_t) len * many);
+    std::vector<g2g_refine_step> log;
+    g2g_refine_stats S;
+    memset(&S, 0, sizeof S);
+    int rc_all = G2G_OK;
+
+    const int maxi = O.maxitr * cycle;
+    int nrep = 0, it = 0, win = 2;
+    std::vector<int> pending;
+    unsigned nthr = std::thread::hardware_concurrency();
+    if (nthr > 16) nthr = 16;
+    if (nthr < 1) nthr = 1;
+
+    while (it < maxi && rc_all == G2G_OK) {
+        while ((int) pending.size() < std::min(win, maxi - it)) pending.push_back(next_branch());
+        const int nw = std::min(win, (int) pending.size());
+        std::vector<Division> D((size_t) nw);
+        // ---- build the window's divisions from the current MSA (host threads: the builders touch only their own objects) ----
+        std::atomic<int> nextd(0), fail(0);
+        auto build = [&]() {
+            std::vector<int> inside;
+            std::vector<double> w;
+            for (int k; (k = nextd.fetch_add(1)) < nw; ) {
+                Division &d = D[k];
+                d.branch = pending[k];
+                T.leaves(d.branch, inside);
+                std::vector<char> in((size_t) many, 0);
+                for (int l : inside) in[l] = 1;
+                std::vector<int> outside;
+                for (int i = 0; i < many; ++i) if (!in[i]) outside.push_back(i);
+                // bin2lst2 + the swap of Prrn::divideseq: (larger group, smaller group)
+                if (outside.size() < inside.size()) { d.la = inside; d.lb = outside; } else { d.la = outside; d.lb = inside; }
+                d.pwt = T.calcfact(d.branch, w);
+                split_columns(M, d);
+                if (d.ra == M.len && d.rb == M.len) { d.skip = true; continue; }     // nothing to re-align (src/prrn5.cc:497-498,518-521)
+                // a group of one member is the member itself in the reference (aliaseq): weight 1
+                std::vector<double> wa, wb;
+                for (int l : d.la) wa.push_back(d.la.size() > 1 ? w[l] : 1.0);
+                for (int l : d.lb) wb.push_back(d.lb.size() > 1 ? w[l] : 1.0);
+                d.ga = g2g_group_create(ctx, prm, (int) d.la.size(), d.ra, d.a.data(), wa.data());
+                d.gb = g2g_group_create(ctx, prm, (int) d.lb.size(), d.rb, d.b.data(), wb.data());
+                if (d.ga && d.gb) d.pw = g2g_pwdm_create(ctx, prm, d.ga, d.gb, &d.swp);
+                if (!d.pw) { fail = 1; continue; }
+                if (d.swp) { Skl t; swap_skl(d.old, t); d.old.swap(t); }
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            const unsigned use = std::min<unsigned>(nthr, (unsigned) nw);
+            for (unsigned t = 1; t < use; ++t) th.emplace_back(build);
+            build();
+            for (auto &t : th) t.join();
+        }
+        if (fail) { g2g_set_error("%s", "g2g_refine: building a division's groups failed"); rc_all = G2G_ERR_ARG; for (auto &d : D) free_division(d); break; }
+        // ---- score: my share of the window (largest rectangles first, round-robin), then the exchange ----
+        std::vector<int> live;
+        for (int k = 0; k < nw; ++k) if (!D[k].skip) live.push_back(k);
+        std::vector<int> order(live.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int) i;
+        if (sharded) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return (long long) D[live[x]].ra * D[live[x]].rb > (long long) D[live[y]].ra * D[live[y]].rb; });
+        std::vector<int> mine;
+        for (size_t i = (size_t) (sharded ? O.rank : 0); i < order.size(); i += (size_t) (sharded ? O.world : 1)) mine.push_back(order[i]);
+        const int nm = (int) mine.size();
+        if (nm) {
+            std::vector<g2g_pwdm *> pw((size_t) nm);
+            for (int i = 0; i < nm; ++i) pw[i] = D[live[mine[i]]].pw;
+            std::vector<double> scr((size_t) nm);
+            std::vector<g2g_skl *> skl((size_t) nm, (g2g_skl *) 0);
+            std::vector<int> nskl((size_t) nm), st((size_t) nm);
+            int rc = g2g_align2_batch(ctx, nm, pw.data(), scr.data(), skl.data(), nskl.data(), st.data());
+            if (rc == G2G_OK) {
+                std::vector<g2g_pwdm *> pw2(pw); pw2.insert(pw2.end(), pw.begin(), pw.end());
+                std::vector<const g2g_skl *> sk2((size_t) 2 * nm);
+                std::vector<int> ns2((size_t) 2 * nm);
+                for (int i = 0; i < nm; ++i) {
+                    Division &d = D[live[mine[i]]];
+                    sk2[i] = d.old.data(); ns2[i] = (int) d.old.size();
+                    sk2[nm + i] = skl[i]; ns2[nm + i] = nskl[i];
+                }
+                std::vector<g2g_fstat> fs((size_t) 2 * nm);
+                rc = g2g_spscore_batch(ctx, 2 * nm, pw2.data(), sk2.data(), ns2.data(), fs.data());
+                for (int i = 0; i < nm && rc == G2G_OK; ++i) {
+                    Division &d = D[live[mine[i]]];
+                    if (st[i] != 0 || fs[i].status != 0 || fs[nm + i].status != 0) { rc = st[i] ? st[i] : fs[i].status ? fs[i].status : fs[nm + i].status; break; }
+                    d.scr = scr[i]; d.val_old = fs[i].raw; d.val_new = fs[nm + i].val;
+                    d.neu.assign(skl[i], skl[i] + nskl[i]);
+                }
+            }
+            for (int i = 0; i < nm; ++i) g2g_free(skl[i]);
+            if (rc != G2G_OK) { rc_all = rc; for (auto &d : D) free_division(d); break; }
+            S.divisions_scored_here += nm;
+        }
+        ++S.batches;
+        if (sharded) {
+            // fixed-size slots {index in the window's live list, 0, corners, DP score, raw current score, new fstat.val, corners...}
+            const int ntot = (int) live.size();
+            const int nslots = (ntot + O.world - 1) / O.world;
+            std::vector<int32_t> mybuf((size_t) nslots * slot_ints, -1), all((size_t) nslots * O.world * slot_ints, -1);
+            bool ok = true;
+            for (int i = 0; i < nm && ok; ++i) {
+                const Division &d = D[live[mine[i]]];
+                int32_t *s = &mybuf[(size_t) i * slot_ints];
+                if ((int) d.neu.size() > O.slot_cap) { ok = false; break; }
+                s[0] = mine[i]; s[1] = 0; s[2] = (int32_t) d.neu.size();
+                memcpy(s + 3, &d.scr, 8); memcpy(s + 5, &d.val_old, 8); memcpy(s + 7, &d.val_new, 8);
+                for (size_t k = 0; k < d.neu.size(); ++k) { s[9 + 2 * k] = d.neu[k].m; s[10 + 2 * k] = d.neu[k].n; }
+            }
+            if (!ok) { g2g_set_error("%s", "g2g_refine: a skeleton exceeds the exchange slot capacity"); rc_all = G2G_ERR_ARG; for (auto &d : D) free_division(d); break; }
+            const int rc = O.exchange(O.exchange_user, mybuf.data(), nslots * slot_ints, all.data());
+            if (rc != 0) { g2g_set_error("%s", "g2g_refine: the exchange callback failed"); rc_all = G2G_ERR_DEVICE; for (auto &d : D) free_division(d); break; }
+            int seen = 0;
+            for (int q = 0; q < nslots * O.world; ++q) {
+                const int32_t *s = &all[(size_t) q * slot_ints];
+                if (s[0] < 0 || s[0] >= ntot) continue;
+                Division &d = D[live[s[0]]];
+                memcpy(&d.scr, s + 3, 8); memcpy(&d.val_old, s + 5, 8); memcpy(&d.val_new, s + 7, 8);
+                d.neu.resize((size_t) s[2]);
+                for (int k = 0; k < s[2]; ++k) { d.neu[k].m = s[9 + 2 * k]; d.neu[k].n = s[10 + 2 * k]; }
+                ++seen;
+            }
+            if (seen != ntot) { g2g_set_error("%s", "g2g_refine: the exchange did not return every division of the window"); rc_all = G2G_ERR_DEVICE; for (auto &d : D) free_division(d); break; }
+        }
+        for (int k : live) {
+            Division &d = D[k];
+            bool same = d.neu.size() == d.old.size();
+            for (size_t q = 0; same && q < d.neu.size(); ++q) same = d.neu[q].m == d.old[q].m && d.neu[q].n == d.old[q].n;
+            // Prrn::onecycle (src/prrn5.cc:523,535): the NEW alignment enters with Gsinfo.fstat.val (rescaled by PwdM::Vab), the
+            // CURRENT one with the return value of calcSpScore(SKL*), which is not rescaled -- kept as the reference has it
+            d.delta = same ? 0.0 : d.pwt * (d.val_new - d.val_old);
+            if (d.swp) swap_skl(d.neu, d.neu_ab); else d.neu_ab = d.neu;
+        }
+        // ---- look at the window in generator order ----
+        int consumed = 0;
+        bool accepted = false;
+        for (int k = 0; k < nw; ++k) {
+            Division &d = D[k];
+            ++consumed; ++it;
+            g2g_refine_step e;
+            memset(&e, 0, sizeof e);
+            e.branch = d.branch; e.na = (int) d.la.size(); e.nb = (int) d.lb.size();
+            if (d.skip) {
+                e.skipped = 1; e.delta = -INFINITY;
+                log.push_back(e);
+                ++nrep;
+                if (nrep >= cycle || it >= maxi) break;
+                continue;
+            }
+            const bool ok = lt0(d.delta);
+            e.swp = d.swp; e.scr = d.scr; e.val_new = d.val_new; e.val_old = d.val_old; e.delta = d.delta; e.accepted = ok;
+            log.push_back(e);
+            if (ok) {
+                Msa N;
+                if (!join_columns(d, d.neu_ab, many, N)) { g2g_set_error("%s", "g2g_refine: a skeleton segment is neither diagonal nor a gap"); rc_all = G2G_ERR_DEVICE; break; }
+                M.len = N.len; M.c.swap(N.c);
+                nrep = 1; accepted = true; ++S.accepted;
+                break;
+            }
+            ++nrep;
+            if (nrep >= cycle || it >= maxi) break;
+        }
+        S.divisions_wasted += nw - consumed;
+        for (auto &d : D) free_division(d);
+        pending.erase(pending.begin(), pending.begin() + consumed);
+        if (rc_all != G2G_OK || nrep >= cycle) break;
+        win = accepted ? 2 : std::min(O.window, 2 * win);
+    }
+    if (rc_all != G2G_OK) return rc_all;
+    S.divisions = (int) log.size();
+    *out_len = M.len;
+    *out_codes = (uint8_t *) malloc(M.c.size() ? M.c.size() : 1);
+    if (!*out_codes) return G2G_ERR_NOMEM;
+    memcpy(*out_codes, M.c.data(), M.c.size());
+    if (steps && nsteps) {
+        *nsteps = (int) log.size();
+        *steps = (g2g_refine_step *) malloc(sizeof(g2g_refine_step) * (log.size() ? log.size() : 1));
+        if (!*steps) { free(*out_codes); *out_codes = 0; return G2G_ERR_NOMEM; }
+        memcpy(*steps, log.data(), sizeof(g2g_refine_step) * log.size());
+    }
+    if (stats) *stats = S;
+    return G2G_OK;
+}

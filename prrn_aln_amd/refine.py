@@ -383,3 +383,66 @@ class Refiner:
                 break
             win = 2 if accepted else min(self.window, 2 * win)
         return self.codes
+
+
+# ---- the same loop in C++ behind the C ABI (g2g_refine, csrc/g2g_refine.cpp) ------------------------------------------
+def torch_exchange(device=None):
+    """An exchange callback for g2g_refine on torch.distributed (RCCL when `device` is a GPU, gloo on the CPU): all-gathers the
+    ranks' slot buffers.  Returns (callback object to keep alive, rank, world)."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from . import _abi
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    def cb(user, mine, n_ints, out):
+        try:
+            t = torch.from_numpy(np.ctypeslib.as_array(mine, shape=(n_ints,)).copy())
+            if device is not None:
+                t = t.to(device)
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            dst = np.ctypeslib.as_array(out, shape=(world * n_ints,))
+            for r, part in enumerate(parts):
+                dst[r * n_ints:(r + 1) * n_ints] = part.cpu().numpy()
+            return 0
+        except Exception:
+            return 1
+    return _abi.EXCHANGE_FN(cb), rank, world
+
+
+def refine_native(ctx, codes: np.ndarray, tree: KTree, alp: op.AlnParam, seed: int = 1, maxitr: int = 10, window: int = 32,
+                  exchange=None):
+    """g2g_refine: (refined MSA (len, many) uint8, [RefineStep-like dicts], stats dict).  `exchange`: the triple torch_exchange
+    returns, for a run sharded over ranks."""
+    import ctypes as C
+    from . import _abi
+    from ._lib import G2GError, last_error, lib
+    L = lib()
+    codes = np.ascontiguousarray(codes, np.uint8)
+    ln, many = codes.shape
+    prm, _sm = alp.to_c()
+    arr = lambda x, t: np.ascontiguousarray(x, t)
+    left, right, parent = arr(tree.left, np.int32), arr(tree.right, np.int32), arr(tree.parent, np.int32)
+    vol, cur = arr(tree.vol, np.float64), arr(tree.cur, np.float64)
+    T = _abi.Tree()
+    T.n_nodes = len(left)
+    i32p = C.POINTER(C.c_int32)
+    T.left, T.right, T.parent = left.ctypes.data_as(i32p), right.ctypes.data_as(i32p), parent.ctypes.data_as(i32p)
+    T.vol, T.cur = vol.ctypes.data_as(_abi.c_f64p), cur.ctypes.data_as(_abi.c_f64p)
+    O = _abi.RefineOpts()
+    O.seed, O.maxitr, O.window = seed, maxitr, window
+    if exchange is not None:
+        O.exchange, O.rank, O.world = exchange
+    out = _abi.c_u8p(); olen = C.c_int(); steps = C.POINTER(_abi.RefineStep)(); ns = C.c_int(); st = _abi.RefineStats()
+    rc = L.g2g_refine(ctx._h, C.byref(prm), many, ln, codes.ctypes.data_as(_abi.c_u8p), C.byref(T), C.byref(O), C.byref(out),
+                      C.byref(olen), C.byref(steps), C.byref(ns), C.byref(st))
+    if rc != 0:
+        raise G2GError("g2g_refine rc=%d: %s" % (rc, last_error()))
+    final = np.ctypeslib.as_array(out, shape=(olen.value * many,)).reshape(olen.value, many).copy()
+    L.g2g_free(out)
+    log = [dict(branch=s.branch, na=s.na, nb=s.nb, swp=bool(s.swp), accepted=bool(s.accepted), skipped=bool(s.skipped), scr=s.scr,
+                val_new=s.val_new, val_old=s.val_old, delta=s.delta) for s in (steps[i] for i in range(ns.value))]
+    L.g2g_free(steps)
+    stats = {k: getattr(st, k) for k, _ in _abi.RefineStats._fields_ if k != "reserved"}
+    return final, log, stats
