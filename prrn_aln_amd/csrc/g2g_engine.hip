@@ -240,7 +240,7 @@ struct g2g_batch {
     V2Tile *d_tiles;                // tiles: per variant (v2: hf2, hf3, pf2, pf3; v3: the same four) a queue ordered by wavefront i + j
     int var_off[25];                // variant v owns tiles [var_off[v], var_off[v+1])
     V3Lds v3lds[8];                 // LDS plan of the v3 variants
-    V6Lds v6lds[4];                 // LDS plans of the v6 (_pf, one lane per cell, rank-form merges) launches: Noll 2, 3 x {small, large} footprint
+    V6Lds v6lds[6];                 // LDS plans of the v6 (_pf, one lane per cell, rank-form merges) launches: Noll 2, 3 x footprint class A / B / C
     int v2_cols;
     int v2_threads;                 // workgroup size of the v2 kernels: 256 (32-row strips) or 128 (16-row strips)
     int v2_sweep;                   // v2 (_pf): the same
@@ -251,7 +251,7 @@ struct g2g_batch {
     std::vector<int> flags0;        // initial contents of d_flags (re-uploaded when the 11-bit generation of the progress counters wraps)
     long long ntiles;
     float fwd_ms, tb_ms;
-    double *simscr[20]; size_t simscr_cap[20];
+    double *simscr[24]; size_t simscr_cap[24];
     int hdr_img[G2G_HDR + 4];       // host image of the queue heads + wait header of the current run
     std::vector<const g2g_problem *> src;        // the caller's problems (kept alive by the caller until the batch is freed): a DP
                                                  // that lost a wait is re-run from here on the non-polling kernel
@@ -316,6 +316,13 @@ static V6Lds v6_layout(int rows_bytes, int ca4max, const V6Ring &R)
 static int v6_small_lds(const g2g_ctx *c) { const char *e = g2g_opt(c, "V6_SMALL_KB"); return e ? atoi(e) * 1024 : 53 * 1024; }
 #define V6_SMALL_LDS (v6_small_lds(ctx))
 static const int V6_CLASS_A = 40 * 1024;
+// footprint classes of the v6 launches (one LDS plan per launch = the largest of its DPs): A up to 40 KB (4 strips per CU), B up to
+// V6_SMALL_LDS (53 KB: 3 per CU), and -- only when option V6_LARGE_KB asks for it -- C up to that many KB (2 per CU at 80).  Class C is
+// OFF by default: the DPs it would take (the most balanced divisions: long column lists, the scanning cell instance) run faster on
+// the 8-lanes-per-cell kernel -- bench sweep 751 ms without it, 771 / 899 / 879 ms with a limit of 64 / 80 / 96 KB.
+static int v6_large_lds(const g2g_ctx *c) { const char *e = g2g_opt(c, "V6_LARGE_KB"); return e ? atoi(e) * 1024 : 0; }
+#define V6_LARGE_LDS (v6_large_lds(ctx))
+static inline int v6_slot(int cls) { return cls < 4 ? 12 + cls : 16 + cls; }      // queue / variant slot of class index (footprint class x 2 + Noll 3)
 static int v6_rows_bytes(const DevProb &d)
 {
     const int lsz = ((d.capa + 3) & ~3) + ((d.capb + 3) & ~3);
@@ -500,7 +507,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
     };
     g2g_batch *b = new g2g_batch();
     b->ctx = ctx; b->n = n; b->d_arena = 0; b->d_probs = 0; b->fwd_ms = b->tb_ms = 0;
-    for (int k = 0; k < 20; ++k) { b->simscr[k] = 0; b->simscr_cap[k] = 0; }
+    for (int k = 0; k < 24; ++k) { b->simscr[k] = 0; b->simscr_cap[k] = 0; }
     b->src.assign(prob, prob + n); b->fail_off = 0; b->force_v1 = force_v1; b->n_recovered = 0;
     b->recovered.assign(n, g2g_result()); b->was_recovered.assign(n, 0);
     b->v3_cols = 128; b->v2_cols = G2G_V2_TILE_COLS;
@@ -632,7 +639,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         if ((d.kind == 1 || d.kind == 2) && !force_v1 && !g2g_opt(ctx, "FORCE_V1") && p->a.len + p->b.len < 65000) {
             // _pf: one lane per cell with rank-form merges (v6) when the rows' static lists fit the register file
             if (!g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_V6") && !g2g_opt(ctx, "V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V6_NA && d.a.r_from_t &&
-                v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(p)).total <= V6_SMALL_LDS) d.v2_ok = 6;
+                v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(p)).total <= std::max(V6_SMALL_LDS, V6_LARGE_LDS)) d.v2_ok = 6;
             else if (!g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_AREG") && (d.kind == 1 || g2g_opt(ctx, "V3_PF")) && d.a.maxlist <= G2G_V3_NA &&
                 v3_need(d, p, b->v3_cols, true).total <= (int) V2_LDS_MAX) d.v2_ok = 3;
             else {
@@ -738,8 +745,8 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         std::vector<V2Tile> pre[G2G_HDR];                 // boundary chains of sweep-mode DPs: they head their variant's queue
         std::vector<int> ip;                              // the other DPs: chains in the prologue kernel
         const bool chainq = !g2g_opt(ctx, "NO_CHAINQ");
-        int v6rows[4] = {0, 0, 0, 0}, v6ca4[4] = {0, 0, 0, 0};
-        V6Ring v6rs[4] = {{{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}};
+        int v6rows[6] = {0, 0, 0, 0, 0, 0}, v6ca4[6] = {0, 0, 0, 0, 0, 0};
+        V6Ring v6rs[6] = {{{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}};
         V3Need need[8];
         memset(need, 0, sizeof need);
         for (int i = 0; i < n; ++i) {
@@ -761,11 +768,13 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
             const int nstrip = (ar - al + R - 1) / R, nblk = (br - bl_ + C - 1) / C;
             // (one LDS plan per launch = the largest of its DPs: DPs whose column lists need a big ring get a launch of their own,
             //  or a handful of balanced divisions would cost every strip of the sweep its occupancy)
-            const int var = d.v2_ok == 8 ? 18 + (d.noll == 3 ? 1 : 0) : d.v2_ok == 7 ? 16 + (d.noll == 3 ? 1 : 0) : d.v2_ok == 6 ? 12 + (d.noll == 3 ? 1 : 0) + (v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(prob[i])).total > V6_CLASS_A ? 2 : 0) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
+            int v6cls = 0;
+            if (d.v2_ok == 6) { const int tot = v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(prob[i])).total; v6cls = (d.noll == 3 ? 1 : 0) + (tot > V6_SMALL_LDS ? 4 : tot > V6_CLASS_A ? 2 : 0); }
+            const int var = d.v2_ok == 8 ? 18 + (d.noll == 3 ? 1 : 0) : d.v2_ok == 7 ? 16 + (d.noll == 3 ? 1 : 0) : d.v2_ok == 6 ? v6_slot(v6cls) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
             if (d.v2_ok == 6) {
-                v6rows[var - 12] = std::max(v6rows[var - 12], v6_rows_bytes(d));
-                v6ca4[var - 12] = std::max(v6ca4[var - 12], (d.capa + 3) & ~3);
-                { const V6Ring rn = v6_ring_need(prob[i]); for (int q = 0; q < 3; ++q) v6rs[var - 12].rs[q] = std::max(v6rs[var - 12].rs[q], rn.rs[q]); }
+                v6rows[v6cls] = std::max(v6rows[v6cls], v6_rows_bytes(d));
+                v6ca4[v6cls] = std::max(v6ca4[v6cls], (d.capa + 3) & ~3);
+                { const V6Ring rn = v6_ring_need(prob[i]); for (int q = 0; q < 3; ++q) v6rs[v6cls].rs[q] = std::max(v6rs[v6cls].rs[q], rn.rs[q]); }
             } else if (d.v2_ok >= 7) {
             } else if (d.v2_ok >= 2) {
                 const V3Need nd = v3_need(d, prob[i], C, d.v2_ok == 3);
@@ -818,7 +827,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
             for (size_t k = 0; k < q[v].size(); ++k) all.insert(all.end(), q[v][k].begin(), q[v][k].end());
         }
         b->var_off[G2G_HDR] = (int) all.size();
-        for (int v = 0; v < 4; ++v) b->v6lds[v] = v6_layout(v6rows[v], v6ca4[v], v6rs[v]);
+        for (int v = 0; v < 6; ++v) b->v6lds[v] = v6_layout(v6rows[v], v6ca4[v], v6rs[v]);
         for (int v = 0; v < 8; ++v) b->v3lds[v] = v3_layout(need[v].rows_bytes, need[v].ca4, need[v].apool, need[v].bpool, b->v3_cols);
         // test hook: G2G_INJECT_STALL=<i> makes the first strip / tile of problem i depend on a flag nobody ever writes
         if (const char *e = g2g_opt(ctx, "INJECT_STALL")) {
@@ -990,14 +999,15 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipEventRecord(ctx->vev[v & 3], vs));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[v & 3], 0));
         }
-        for (int vi = 0; vi < 4; ++vi) {
-            const int v = 3 - vi;                    // (the larger-footprint launch first)
-            const int cnt = b->var_off[v + 13] - b->var_off[v + 12];
+        for (int vi = 0; vi < 6; ++vi) {
+            const int v = 5 - vi;                    // (the larger-footprint launch first)
+            const int slot = v6_slot(v);
+            const int cnt = b->var_off[slot + 1] - b->var_off[slot];
             if (!cnt) continue;
             typedef void (*v6k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V6Lds, int, int, double *);
-            static const v6k_t v6k[4] = {g2g_v6_pf2, g2g_v6_pf3, g2g_v6_pf2, g2g_v6_pf3};
-            hipStream_t vs = ctx->vstream[v < 2 ? 2 + v : 2 + v];        // small: streams 2, 3; large footprint: 4, 5
-            const int jev = v < 2 ? 2 + v : 3 + v;
+            static const v6k_t v6k[6] = {g2g_v6_pf2, g2g_v6_pf3, g2g_v6_pf2, g2g_v6_pf3, g2g_v6_pf2, g2g_v6_pf3};
+            hipStream_t vs = ctx->vstream[v < 4 ? 2 + v : v - 4];        // class A: streams 2, 3; B: 4, 5; C: 0, 1
+            const int jev = v < 2 ? 2 + v : v < 4 ? 3 + v : v - 4;
             const V6Lds &LO = b->v6lds[v];
             if (LO.total > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *) v6k[v], hipFuncAttributeMaxDynamicSharedMemorySize, LO.total));
             HIPCHK(hipStreamWaitEvent(vs, ctx->vev[4], 0));
@@ -1007,11 +1017,11 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             const int grid = std::min(cnt, ncu * wpc);
             const int pint = b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= ncu * wpc ? 4 : cnt < 4 * ncu * wpc ? 16 : 32;   // publish interval (power of 2)
             if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] v6 variant %d: %d strips, grid %d, lds %d (rings %d / %d / %d entries), publish every %d, gen %d\n", v, cnt, grid, LO.total, LO.rs[0], LO.rs[1], LO.rs[2], pint, b->gen); fflush(stderr); }
-            double *simscr6 = sim_scratch(12 + v, grid);
+            double *simscr6 = sim_scratch(slot, grid);
             if (!simscr6) { g2g_set_error("%s", "hipMalloc(column-score scratch)"); return G2G_ERR_NOMEM; }
             hipLaunchKernelGGL(v6k[v], dim3(grid), dim3(64), (size_t) LO.total, vs,
-                               (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v + 12]), cnt,
-                               b->d_flags + 12 + v, b->d_flags, b->gen, LO, pint,
+                               (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[slot]), cnt,
+                               b->d_flags + slot, b->d_flags, b->gen, LO, pint,
                                (pro_off && pro_off + (int) PRO_LDS_BYTES <= LO.svals) ? pro_off : 0, simscr6);
             HIPCHK(hipGetLastError());
             if (g2g_opt(ctx, "DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v6 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
@@ -1145,7 +1155,7 @@ extern "C" void g2g_batch_free(g2g_batch *b)
     release_arena(b);
     if (b->d_tiles) hipFree(b->d_tiles);
     if (b->d_flags) hipFree(b->d_flags);
-    for (int k = 0; k < 20; ++k) if (b->simscr[k]) hipFree(b->simscr[k]);
+    for (int k = 0; k < 24; ++k) if (b->simscr[k]) hipFree(b->simscr[k]);
     for (size_t i = 0; i < b->recovered.size(); ++i) free(b->recovered[i].trace);
     delete b;
 }
