@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define G2G_ABI_VERSION 2
+#define G2G_ABI_VERSION 3
 
 /* error codes (negative) */
 enum {
@@ -93,6 +93,12 @@ typedef struct g2g_side {
        mseq.h:148-160), (len+2)*many each, position -1 first; NULL otherwise */
     const double  *gapdens;
     const double  *postgapdens;
+    /* exon-boundary (intron position) annotation of the group, reference SigII::pfq (src/gsinfo.h:33,41-46): npfq entries
+       ascending in pos (nucleotide coordinate: column x pfq_step + phase), dns = weighted number of members with an intron
+       there; pfq_step = SigII::step (3 for protein columns, 1 for nucleotides).  npfq = 0 / NULL: not annotated.          */
+    int32_t        npfq, pfq_step;
+    const int32_t *pfq_pos;
+    const double  *pfq_dns;
 } g2g_side;
 
 typedef struct g2g_problem {
@@ -111,6 +117,9 @@ typedef struct g2g_problem {
     const double *simmtx;           /* rows x dim substitution matrix, Simmtx::mtx (simmtx.h:49)  */
     int32_t  simdim, simrows;
     g2g_side a, b;
+    double   spb_fact;              /* SpbFact = alprm.scale * alprm2.spb (src/gsinfo.cc:35): weight of the intron-position bonus
+                                       PfqItr::match_score adds in forwardB (src/fwd2c.h:378-379,446-452,472) when BOTH sides are
+                                       annotated; 0 switches it off.  DPs with the bonus run on g2g_forward_kernel.            */
 } g2g_problem;
 
 /* result of one DP */

@@ -146,7 +146,8 @@ int crg_id(const PwdM* pwd)
 }
 
 struct SideBuf {
-	std::vector<double>	thk, gd, pg, wt;
+	std::vector<double>	thk, gd, pg, wt, pdns;
+	std::vector<int32_t>	ppos;
 	std::vector<int32_t>	off[3], glen[3];
 	std::vector<double>	freq[3];
 };
@@ -179,6 +180,11 @@ void side(g2g_side& s, mSeq* q, const FTYPE* wt, bool naive, SideBuf& B)
 		    B.pg[ix] = q->internalres? q->postgapdensity(r, k): 1;
 		}
 	    s.gapdens = B.gd.data(); s.postgapdens = B.pg.data();
+	}
+	if (q->sigII && q->sigII->pfqnum > 0 && q->sigII->pfq) {	// exon boundaries (SigII::pfq, gsinfo.h:33,41-46): the intron-position bonus
+	    for (int i = 0; i < q->sigII->pfqnum; ++i) {B.ppos.push_back(q->sigII->pfq[i].pos); B.pdns.push_back(q->sigII->pfq[i].dns);}
+	    s.npfq = q->sigII->pfqnum; s.pfq_step = q->sigII->step;
+	    s.pfq_pos = B.ppos.data(); s.pfq_dns = B.pdns.data();
 	}
 	s.has_gfq = (q->gfq && q->inex.dels)? 1: 0;
 	if (s.has_gfq) {				// the three views, lists with their terminators (gfreq.cc:230-312)
@@ -226,6 +232,7 @@ SKL* alignC_g2g(mSeq* seqs[], PwdM* pwd, VTYPE* scr)
 	SideBuf	A, B;
 	side(p.a, seqs[0], pwd->wta, naive, A);
 	side(p.b, seqs[1], pwd->wtb, naive, B);
+	p.spb_fact = SpbFact;						// gsinfo.cc:33-35
 	Req	q;
 	q.p = &p; q.done = false;
 	memset(&q.r, 0, sizeof(q.r));
@@ -251,10 +258,11 @@ bool on_gpu_path(mSeq* seqs[], PwdM* pwdm, Gsinfo* GsI)
 	// and synchronisation, about 3e4 cells of a host core); default 0 = everything on the path goes to the GPU
 	static const double	min_cells = getenv("G2G_BIND_MIN_CELLS")? atof(getenv("G2G_BIND_MIN_CELLS")): 0;
 	if (min_cells > 0 && (double) (seqs[0]->right - seqs[0]->left) * (seqs[1]->right - seqs[1]->left) < min_cells) return false;
-	// Intron-position bonus (PfqItr::match_score, fwd2c.h:367-379,446-452): live when BOTH inputs carry exon-boundary
-	// annotations (`;C join(...)` lines -> Seq::sigII) and SpbFact != 0.  libg2g.so does not evaluate it, so such pairs
-	// stay with the reference's own forwardB (e.g. `aln -s sample/pas ce13a1 ce13a2`).
-	if (SpbFact != 0 && seqs[0]->sigII && seqs[1]->sigII && seqs[0]->sigII->pfqnum && seqs[1]->sigII->pfqnum) return false;
+	// (Intron-position bonus -- PfqItr::match_score, fwd2c.h:367-379,446-452, live when BOTH inputs carry exon-boundary
+	//  annotations and SpbFact != 0: the flattened problem carries the boundary lists since ABI 3 and libg2g.so applies it.
+	//  G2G_BIND_NO_INTRON=1 keeps such pairs with the reference's own forwardB, as before.)
+	static const bool	no_intron = getenv("G2G_BIND_NO_INTRON") != 0;
+	if (no_intron && SpbFact != 0 && seqs[0]->sigII && seqs[1]->sigII && seqs[0]->sigII->pfqnum && seqs[1]->sigII->pfqnum) return false;
 	switch (pwdm->alnmode) {
 	    case NGP_ALB: case HLF_ALB: case RHF_ALB: case GPF_ALB: case NTV_ALB: return true;
 	    default: return false;

@@ -97,6 +97,14 @@ void dump_side(Dump& d, const char* pfx, mSeq* s)
 	    std::vector<double> w(s->weight, s->weight + s->many);
 	    d.put((p + "weight").c_str(), 3, w.data(), s->many);
 	}
+	if (s->sigII && s->sigII->pfqnum > 0) {		// exon-boundary annotation (SigII::pfq, gsinfo.h:33,41-46)
+	    std::vector<int>	pos(s->sigII->pfqnum);
+	    std::vector<double>	dns(s->sigII->pfqnum);
+	    for (int i = 0; i < s->sigII->pfqnum; ++i) {pos[i] = s->sigII->pfq[i].pos; dns[i] = s->sigII->pfq[i].dns;}
+	    d.put((p + "pfq_pos").c_str(), 1, pos.data(), s->sigII->pfqnum);
+	    d.put((p + "pfq_dns").c_str(), 3, dns.data(), s->sigII->pfqnum);
+	    d.i32((p + "pfq_step").c_str(), s->sigII->step);
+	}
 	d.i32((p + "nelm").c_str(), s->nelm);
 	d.i32((p + "felm").c_str(), s->felm);
 	if (s->inex.vect && s->pseq)		// fat(-1) .. fat(len)  (mseq.h:123)
@@ -271,6 +279,7 @@ int ref_align_dump(void* ga, void* gb, const char* path)
 	d.i32("algmode_bnd", algmode.bnd);
 	d.i32("algmode_qck", algmode.qck);
 	d.i32("algmode_lcl", algmode.lcl);
+	d.f64("spb_fact", SpbFact);
 	{
 	    const Simmtx*	sm = pwd.simmtx;
 	    d.i32("simmtx_dim", sm->dim);

@@ -27,7 +27,8 @@ class Side(C.Structure):
                 ("nelm", C.c_int32), ("felm", C.c_int32),
                 ("pseq", c_f64p), ("thk", c_f64p),
                 ("has_gfq", C.c_int32), ("gfq", GapProf),
-                ("gapdens", c_f64p), ("postgapdens", c_f64p)]
+                ("gapdens", c_f64p), ("postgapdens", c_f64p),
+                ("npfq", C.c_int32), ("pfq_step", C.c_int32), ("pfq_pos", C.POINTER(C.c_int32)), ("pfq_dns", c_f64p)]
 
 
 class Problem(C.Structure):
@@ -37,7 +38,7 @@ class Problem(C.Structure):
                 ("basic_gop", C.c_double), ("weighted_gop", C.c_double), ("u", C.c_double),
                 ("u2divu1", C.c_double), ("v2divv1", C.c_double),
                 ("simmtx", c_f64p), ("simdim", C.c_int32), ("simrows", C.c_int32),
-                ("a", Side), ("b", Side)]
+                ("a", Side), ("b", Side), ("spb_fact", C.c_double)]
 
 
 class Result(C.Structure):
@@ -156,6 +157,11 @@ def problem_from_arrays(d: Dict[str, np.ndarray]) -> ProblemHolder:
         if pfx + "gapdens" in d:
             side.gapdens = _ptr(h.arr(g("gapdens"), np.float64), c_f64p)
             side.postgapdens = _ptr(h.arr(g("postgapdens"), np.float64), c_f64p)
+        if pfx + "pfq_pos" in d and len(g("pfq_pos")):
+            side.npfq = len(g("pfq_pos")); side.pfq_step = int(g("pfq_step")[0])
+            side.pfq_pos = _ptr(h.arr(g("pfq_pos"), np.int32), c_i32p)
+            side.pfq_dns = _ptr(h.arr(g("pfq_dns"), np.float64), c_f64p)
+    p.spb_fact = float(sc("spb_fact")) if "spb_fact" in d else 0.0
     return h
 
 

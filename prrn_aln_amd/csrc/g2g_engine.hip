@@ -465,6 +465,47 @@ static void pack_side(Blob &bl, const g2g_side &s, DevSide &d, int kind, bool ne
         d.gapdens = OFF<const double>(bl.put(s.gapdens, sizeof(double) * cols * s.many));
         d.postgapdens = OFF<const double>(bl.put(s.postgapdens, sizeof(double) * cols * s.many));
     }
+    if (s.npfq > 0 && s.pfq_pos && s.pfq_dns) {
+        d.npfq = s.npfq; d.pfq_step = s.pfq_step;
+        d.pfq_pos = OFF<const int>(bl.put(s.pfq_pos, sizeof(int) * (size_t) s.npfq));
+        d.pfq_dns = OFF<const double>(bl.put(s.pfq_dns, sizeof(double) * (size_t) s.npfq));
+    }
+}
+
+// The intron-position bonus of forwardB (reference src/fwd2c.h:367-370,378-379,446-452,472; PfqItr src/gsinfo.h:132-231) as a
+// table of cells.  The reference walks two cursors: `api` over a's exon boundaries (it advances by one entry at the end of
+// every row whose codon holds the current entry), and per such row `bpi` over b's, restarted at the row's first column and
+// advanced by one entry at every column whose codon holds ITS current entry -- a cursor that has fallen behind the column
+// (two boundaries in one codon) never catches up.  Both walks depend only on the inputs and the band, not on scores.
+struct BonusCell { int m, n; double h, mx; };
+static bool in_codon(int pos, int step, int col) { return step == 1 ? pos == col : ((long long) col * step <= pos && pos < (long long) col * step + step); }
+static void intron_bonus_table(const g2g_problem *p, std::vector<BonusCell> &out)
+{
+    out.clear();
+    const g2g_side &a = p->a, &b = p->b;
+    if (p->spb_fact == 0 || a.npfq <= 0 || b.npfq <= 0 || !a.pfq_pos || !b.pfq_pos || !a.pfq_dns || !b.pfq_dns) return;
+    const int sa = a.pfq_step, sb = b.pfq_step;
+    int ka = 0;
+    while (ka < a.npfq && a.pfq_pos[ka] < (long long) a.left * sa) ++ka;
+    for (int m = a.left; m < a.right; ++m) {
+        if (ka >= a.npfq) break;                                   // (the cursor only moves forward)
+        if (!in_codon(a.pfq_pos[ka], sa, m)) continue;
+        const int n0 = std::max(m + p->lw, b.left), n9 = std::min(m + p->up + 1, b.right);
+        int kb = 0;
+        while (kb < b.npfq && b.pfq_pos[kb] < (long long) n0 * sb) ++kb;
+        for (int n = n0; n < n9 && kb < b.npfq; ++n) {
+            if (!in_codon(b.pfq_pos[kb], sb, n)) continue;
+            const int apos = a.pfq_pos[ka], bpos = b.pfq_pos[kb];
+            BonusCell c;
+            c.m = m; c.n = n;
+            const bool phase = sa == 1 || (apos - bpos) % sa == 0;   // match_score: the two positions in the same codon phase
+            c.h = phase ? p->spb_fact * a.pfq_dns[ka] * b.pfq_dns[kb] : 0;
+            c.mx = (phase && (sa == 1 || apos % sa == 0)) ? p->spb_fact * a.pfq_dns[ka] * b.pfq_dns[kb] : 0;
+            out.push_back(c);
+            ++kb;
+        }
+        ++ka;
+    }
 }
 
 static void rebase_side(DevSide &d, char *base)
@@ -472,6 +513,7 @@ static void rebase_side(DevSide &d, char *base)
     rebase(d.seq, base); rebase(d.weight, base); rebase(d.pseq, base); rebase(d.thk, base);
     for (int v = 0; v < 3; ++v) { rebase(d.off[v], base); rebase(d.glen[v], base); rebase(d.freq[v], base); }
     rebase(d.gapdens, base); rebase(d.postgapdens, base);
+    rebase(d.pfq_pos, base); rebase(d.pfq_dns, base);
 }
 
 // a batch gives its arena back: the context keeps ONE (the larger) for the next prepare
@@ -551,6 +593,20 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         if (p->simmtx) d.simmtx = OFF<const double>(bl.put(p->simmtx, sizeof(double) * (size_t) p->simdim * p->simrows));
         pack_side(bl, p->a, d.a, d.kind, d.kind == 1 || d.kind == 2);
         pack_side(bl, p->b, d.b, d.kind, d.kind == 2);
+        d.spb_fact = p->spb_fact;
+        {
+            std::vector<BonusCell> bc;
+            intron_bonus_table(p, bc);
+            if (!bc.empty()) {
+                std::vector<int> bm, bn; std::vector<double> bh, bx;
+                for (const BonusCell &c : bc) { bm.push_back(c.m); bn.push_back(c.n); bh.push_back(c.h); bx.push_back(c.mx); }
+                d.nbonus = (int) bc.size();
+                d.bon_m = OFF<const int>(bl.put(bm.data(), sizeof(int) * bm.size()));
+                d.bon_n = OFF<const int>(bl.put(bn.data(), sizeof(int) * bn.size()));
+                d.bon_h = OFF<const double>(bl.put(bh.data(), sizeof(double) * bh.size()));
+                d.bon_mx = OFF<const double>(bl.put(bx.data(), sizeof(double) * bx.size()));
+            }
+        }
     }
     // Tile widths.  Tiles of one DP run as a wavefront, at most min(strips, blocks) of them at a time: a sweep with
     // hundreds of DPs fills the GPU with wide tiles (few block-boundary records, short fill/drain share), a rank
@@ -655,6 +711,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
                 else if (v2fit) d.v2_ok = 1;
             }
         }
+        if (d.nbonus) d.v2_ok = 0;               // the intron-position bonus lives in g2g_forward_kernel only
         if (!d.v2_ok) v1_state();
         else {                                  // g2g_spscore_kernel keeps its two dynamic lists in dla/dlb[XH] (stride spw)
             d.spw = 1;
@@ -714,6 +771,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         DevProb &d = b->dp[i];
         if (d.kind < 0) continue;
         rebase(d.simmtx, b->d_arena);
+        rebase(d.bon_m, b->d_arena); rebase(d.bon_n, b->d_arena); rebase(d.bon_h, b->d_arena); rebase(d.bon_mx, b->d_arena);
         rebase_side(d.a, b->d_arena); rebase_side(d.b, b->d_arena);
         for (int x = 0; x < NX; ++x) {
             rebase(d.val[x], b->d_arena); rebase(d.dir[x], b->d_arena); rebase(d.dla[x], b->d_arena);

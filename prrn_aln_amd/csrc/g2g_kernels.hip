@@ -512,6 +512,10 @@ __device__ void cell(const DevProb &P, int m, int n, uint8_t *tr)
             if (val_of(P, f2) >= val_of(P, mx)) { mx = f2; sel2 = 1; }
         }
     }
+    if (P.nbonus) {                                      // intron-position bonus, fwd2c.h:446-452 (table: g2g_engine.hip)
+        for (int k = 0; k < P.nbonus; ++k)
+            if (P.bon_m[k] == m && P.bon_n[k] == n) { val_of(P, h) += P.bon_h[k]; val_of(P, mx) += P.bon_mx[k]; break; }
+    }
     // diagonal wins ties (fwd2c.h:453)
     if (val_of(P, mx) > val_of(P, h)) { rec_copy<KIND>(P, h, mx); if (sel2) bits |= T_SEL2; }
     *tr = (uint8_t)(bits | dir2code(dir_of(P, h)));
@@ -1022,6 +1026,36 @@ __device__ void sp_calscr_ntv(const DevProb &P, const NtvState &N, int mi, int n
         }
     }
 }
+// ---- Iiinfo + Iiinfo::StoreIIinfo (src/gsinfo.cc:64-83, 622-684): the intron-position term of SpScore::calcSkl -------------
+// Two cursors over the sides' exon-boundary lists; after every diagonal run and every gap of the skeleton the boundaries
+// passed so far are compared in the alignment's common coordinate (position + the gaps inserted on that side): each pair
+// that coincides adds dns_a x dns_b.  Tiny lists, no parallelism: every lane walks them identically.
+struct IiDev { const DevSide *a, *b; int ka, kb, step, on; long long agap, bgap; double spb; };
+__device__ __forceinline__ long long ii_pos(const DevSide &s, int k) { return k < s.npfq ? (long long) s.pfq_pos[k] : (long long) s.len * s.pfq_step; }
+__device__ __forceinline__ bool ii_before(const DevSide &s, int k, int col) { return k < s.npfq && (long long) s.pfq_pos[k] < (long long) col * s.pfq_step; }
+__device__ void ii_init(IiDev &I, const DevProb &P)
+{
+    I.a = &P.a; I.b = &P.b; I.ka = I.kb = 0; I.agap = I.bgap = 0; I.spb = P.spb_fact;
+    I.on = P.spb_fact > 0 && (P.a.npfq > 0 || P.b.npfq > 0);
+    if (!I.on) return;
+    while (I.ka < P.a.npfq && (long long) P.a.pfq_pos[I.ka] < (long long) P.a.left * P.a.pfq_step) ++I.ka;
+    while (I.kb < P.b.npfq && (long long) P.b.pfq_pos[I.kb] < (long long) P.b.left * P.b.pfq_step) ++I.kb;
+    I.step = P.a.npfq > 0 ? P.a.pfq_step : P.b.pfq_step;
+    const int igap = P.a.left - P.b.left;
+    if (igap > 0) I.bgap = (long long) igap * I.step; else I.agap = -(long long) igap * I.step;
+}
+__device__ double ii_store(IiDev &I, int m, int n)
+{
+    double scr = 0;
+    bool an = ii_before(*I.a, I.ka, m), bn = ii_before(*I.b, I.kb, n);
+    while (an || bn) {
+        const long long apos = ii_pos(*I.a, I.ka) + I.agap, bpos = ii_pos(*I.b, I.kb) + I.bgap;
+        if (an && bn && apos == bpos) scr += I.a->pfq_dns[I.ka] * I.b->pfq_dns[I.kb];
+        if (an && apos <= bpos) { ++I.ka; an = ii_before(*I.a, I.ka, m); }
+        if (bn && bpos <= apos) { ++I.kb; bn = ii_before(*I.b, I.kb, n); }
+    }
+    return I.spb * scr;
+}
 template <int KIND>
 __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *skl, int nskl, double *out, int *gepws)
 {
@@ -1049,6 +1083,8 @@ __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *
     int m = skl[0].x, n = skl[0].y, glb = 0;
     int apos = m - 1, bpos = n - 1;
     double scr = 0, tgap = 0;
+    IiDev II;
+    ii_init(II, P);
     for (int k = 1; k < nskl; ++k) {
         const int mi = skl[k].x - m, ni = skl[k].y - n, i = mi - ni;
         auto run = [&](int mi_, int ni_) {
@@ -1058,6 +1094,15 @@ __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *
         if (!i || !mi || !ni) run(mi, ni);
         else if (i > 0) { run(ni, ni); run(i, 0); }
         else { run(mi, mi); run(0, -i); }
+        if (II.on) {                                               // fspscore.h:231-247
+            int d = i >= 0 ? ni : mi;
+            if (d) { m += d; n += d; scr += ii_store(II, m, n); }
+            if (i < 0) { d = -i; n -= i; } else if (i > 0) { d = i; m += i; } else d = 0;
+            if (d) {
+                if (i > 0) II.bgap += (long long) d * II.step; else II.agap += (long long) d * II.step;
+                scr += ii_store(II, m, n);
+            }
+        }
         m = skl[k].x; n = skl[k].y;
     }
     gep_wave_sync();

@@ -110,18 +110,24 @@ def test_prrn5_threaded_calls_are_batched(tmp_path):
     assert out == ref_out
 
 
-def test_aln_intron_annotated_pair_stays_with_the_reference():
+def test_aln_intron_annotated_pair_on_the_gpu():
     """BASELINE configs[0]: `aln -s sample/pas ce13a1 ce13a2` (tests/golden/pas/ holds the two data files of the
     reference's sample/).  Both inputs carry `;C join(...)` exon annotations, so the intron-position bonus
-    (PfqItr::match_score, reference src/fwd2c.h:446-452) is live; libg2g.so does not evaluate it and the binding must
-    route the pair to the reference's own forwardB: Score = 2325.0, byte-identical output, DP counted by the reference."""
+    (PfqItr::match_score, reference src/fwd2c.h:446-452) is live.  Since ABI 3 the flattened problem carries the exon-boundary
+    lists and the DP runs on the GPU: Score = 2325.0, byte-identical output, the DP counted on the GPU; `verify` finds no
+    mismatch; G2G_BIND_NO_INTRON=1 still routes the pair to the reference's own forwardB."""
     pas = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pas")
     ref_out, _ = _run("aln", ["-s", pas, "ce13a1", "ce13a2"], pas)
     out, err = _run("aln_g2g", ["-s", pas, "ce13a1", "ce13a2"], pas)
     calls, gpu, cpu, bad = _stats(err)
-    assert calls == 1 and gpu == 0 and cpu == 1 and bad == 0, err[-500:]
+    assert calls == 1 and gpu == 1 and cpu == 0 and bad == 0, err[-500:]
     assert "Score = 2325.0" in out
     assert out == ref_out
+    out, err = _run("aln_g2g", ["-s", pas, "ce13a1", "ce13a2"], pas, mode="verify")
+    assert _stats(err)[1] == 1 and _stats(err)[3] == 0, err[-500:]
+    out, err = _run("aln_g2g", ["-s", pas, "ce13a1", "ce13a2"], pas, G2G_BIND_NO_INTRON="1")
+    calls, gpu, cpu, bad = _stats(err)
+    assert gpu == 0 and cpu == 1 and out == ref_out
 
 
 def _dstats(err):

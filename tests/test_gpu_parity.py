@@ -67,3 +67,30 @@ def test_golden_single(ctx, path):
     assert st == 0
     assert scr == d["scr"][0]
     assert np.array_equal(tr, d["vmf_trace"])
+
+
+def test_intron_position_bonus_goldens(ctx, L):
+    """Inputs with exon-boundary annotations (reference sample/pas/ce13a*; BASELINE configs[0]'s pair among them): the bonus
+    PfqItr::match_score adds in forwardB (fwd2c.h:446-452) and the Iiinfo term of calcSkl (gsinfo.cc:622-684), level 0 of the
+    ABI: DP score, traceback and fstat.val / gap equal the reference's, and differ from a run with the annotations removed."""
+    gold = [f for f in GOLD if os.path.basename(f).startswith("intron_")]
+    assert len(gold) >= 7
+    ds = [dict(np.load(f)) for f in gold]
+    hs = [_abi.problem_from_arrays(d) for d in ds]
+    assert all(h.c.a.npfq > 0 and h.c.b.npfq > 0 and h.c.spb_fact > 0 for h in hs)
+    batch = ctx.prepare(hs)
+    batch.run()
+    res = batch.fetch()
+    for f, d, (scr, cells, tr, st) in zip(gold, ds, res):
+        assert st == 0 and scr == d["scr"][0] and np.array_equal(tr, d["vmf_trace"]), (os.path.basename(f), st, scr, float(d["scr"][0]))
+    sps = [_abi.SpParams(float(d["Vab"][0]), float(d["BasicGEP"][0]), float(d["LongGEP"][0]) - float(d["BasicGEP"][0]), float(d["diff_u"][0])) for d in ds]
+    fs = batch.spscore(sps, [d["align2_skl"] for d in ds])
+    for f, d, r in zip(gold, ds, fs):
+        assert r[2] == 0 and r[0] == d["fstat_val"][0] and r[1] == d["fstat_gap"][0], (os.path.basename(f), r, float(d["fstat_val"][0]))
+    batch.free()
+    plain = []
+    for d in ds:
+        e = {k: v for k, v in d.items() if "pfq" not in k}
+        plain.append(_abi.problem_from_arrays(e))
+    res0 = ctx.forward_batch(plain)
+    assert any(r0[0] != r[0] for r0, r in zip(res0, res))             # the annotation does change the score

@@ -48,7 +48,7 @@ def test_oracle_homscore(L, path):
     assert [rr[0], rr[1]] == d["homscore_rr"].tolist()
 
 
-SP_GOLD = [f for f in GOLD if int(np.load(f)["alnmode"][0]) in (6, 8, 9, 10)]        # Noll 2 and 3 (Gep1st); naive units
+SP_GOLD = [f for f in GOLD if int(np.load(f)["alnmode"][0]) in (6, 7, 8, 9, 10)]     # Noll 2 and 3 (Gep1st); naive units
 
 
 def sp_from_golden(d):

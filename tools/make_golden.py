@@ -192,7 +192,29 @@ def job_sim23():
         split_case(R, fam, small, None, "syn30x60_nogap_small%d_first_i" % k)
 
 
-JOBS = {"sim23": job_sim23, "protein": job_protein, "dna_ls3": job_dna_ls3, "protein_ls3": job_protein_ls3,
+def job_intron():
+    """inputs that carry exon-boundary annotations (';C join(...)' lines -> SigII): the intron-position bonus of forwardB
+    (PfqItr::match_score, reference src/fwd2c.h:378-379,446-452,472).  BASELINE configs[0]'s own pair and groups of the
+    annotated family sample/pas/ce13a*."""
+    import refdump
+    R = refdump.RefLib(molc=refdump.PROTEIN)
+    pas = os.path.join(SAMPLE, "pas")
+    pairs = [("ce13a1", "ce13a2"), ("ce13a3", "ce13a5"), ("ce13a4", "ce13a6"), ("ce13a7", "ce13a2"), ("ce13a5", "ce13a1"),
+             ("ce13a.msa", "ce13a1"), ("ce13a.msa", "ce13a17.fa"), ("ce13a10", "ce13a4")]
+    n = 0
+    for fa, fb in pairs:
+        ga = R.group_file(os.path.join(pas, fa))
+        gb = R.group_file(os.path.join(pas, fb))
+        d = R.align_dump(ga, gb)
+        if not ("a_pfq_pos" in d and "b_pfq_pos" in d and d["spb_fact"][0] != 0):
+            print("(%s x %s: not annotated on both sides, skipped)" % (fa, fb))
+            continue
+        save("intron_%s_%s" % (fa.replace(".", "_"), fb.replace(".", "_")), d)
+        n += 1
+    assert n >= 4
+
+
+JOBS = {"intron": job_intron, "sim23": job_sim23, "protein": job_protein, "dna_ls3": job_dna_ls3, "protein_ls3": job_protein_ls3,
         "protein_tgapf": job_protein_tgapf, "w21_protein": job_w21_protein, "w21_dna_ls3": job_w21_dna_ls3}
 
 if __name__ == "__main__":
