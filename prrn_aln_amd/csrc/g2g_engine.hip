@@ -252,6 +252,7 @@ struct g2g_batch {
     long long ntiles;
     float fwd_ms, tb_ms;
     double *simscr[24]; size_t simscr_cap[24];
+    bool v6_on;                     // this batch is large enough for v6 (else its _pf DPs go to v2: shorter critical path)
     int hdr_img[G2G_HDR + 4];       // host image of the queue heads + wait header of the current run
     std::vector<const g2g_problem *> src;        // the caller's problems (kept alive by the caller until the batch is freed): a DP
                                                  // that lost a wait is re-run from here on the non-polling kernel
@@ -637,6 +638,17 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         b->v2_cols = pick(2, b->v2_threads / 8, G2G_V2_TILE_COLS, 64, ncu * (768 / b->v2_threads));
         if (const char *e = g2g_opt(ctx, "V2_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v2_cols = c; }
         if (const char *e = g2g_opt(ctx, "V3_COLS")) { const int c = atoi(e); if (c >= 16 && c <= 4096) b->v3_cols = c; }
+        // v6 or v2 for the _pf DPs of this batch?  v6 has the higher throughput (a full sweep: 750 vs 800 ms) but the longer critical
+        // path per DP (64-row strips at one wave per SIMD, ~19 us per step): a batch that cannot fill the machine -- a rank's share of
+        // a sharded sweep -- finishes sooner on v2's 16-row strips.  Measured on shares of the bench sweep (v6 / v2, ms): 1/2 436 / 456,
+        // 1/3 405 / 311, 1/4 327 / 254, 1/8 283 / 163.  Threshold: 35 strips of 64 rows per CU (between the 1/2 and the 1/3 share).
+        {
+            long long s6 = 0;
+            for (int i = 0; i < n; ++i) if (b->dp[i].kind == 2) s6 += (b->dp[i].a.right - b->dp[i].a.left + 63) / 64;
+            long long min_strips = 35LL * ncu;
+            if (const char *e = g2g_opt(ctx, "V6_MIN_STRIPS")) min_strips = atoll(e);
+            b->v6_on = s6 >= min_strips;
+        }
         b->v3_sweep = g2g_opt(ctx, "V3_SWEEP") ? atoi(g2g_opt(ctx, "V3_SWEEP")) : 1;
         b->v2_sweep = g2g_opt(ctx, "V2_SWEEP") ? atoi(g2g_opt(ctx, "V2_SWEEP")) : 1;
     }
@@ -694,7 +706,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         }
         if ((d.kind == 1 || d.kind == 2) && !force_v1 && !g2g_opt(ctx, "FORCE_V1") && p->a.len + p->b.len < 65000) {
             // _pf: one lane per cell with rank-form merges (v6) when the rows' static lists fit the register file
-            if (!g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_V6") && !g2g_opt(ctx, "V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V6_NA && d.a.r_from_t &&
+            if (b->v6_on && !g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_V6") && !g2g_opt(ctx, "V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V6_NA && d.a.r_from_t &&
                 v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(p)).total <= std::max(V6_SMALL_LDS, V6_LARGE_LDS)) d.v2_ok = 6;
             else if (!g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_AREG") && (d.kind == 1 || g2g_opt(ctx, "V3_PF")) && d.a.maxlist <= G2G_V3_NA &&
                 v3_need(d, p, b->v3_cols, true).total <= (int) V2_LDS_MAX) d.v2_ok = 3;

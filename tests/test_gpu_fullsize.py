@@ -37,21 +37,30 @@ def _maxlist(q):
 
 
 def _check_vs_oracle(ctx, pwds):
+    """twice: as the engine would run so small a batch (its _pf DPs on v2: shortest critical path), and with v6 forced (what a
+    full sweep uses)"""
     L = oraclelib.load()
-    res = op.align2_batch(ctx, pwds)
     hs = []
     for pw in pwds:
         class H:
             c = pw.problem
         hs.append(H)
-    raw = ctx.forward_batch(hs)
-    for pw, H, (scr, skl, st), (rscr, rcells, rtr, rst) in zip(pwds, hs, res, raw):
-        assert st == 0 and rst == 0
-        oscr, ocells, otr = oraclelib.forward(L, H)
-        assert rcells == ocells
-        assert scr == oscr and rscr == oscr, (pw.alnmode, scr, oscr)
-        assert np.array_equal(rtr, otr), pw.alnmode
-        assert np.array_equal(skl, oraclelib.stdskl(L, otr))
+    want = [oraclelib.forward(L, H) for H in hs]
+    for opts in ({}, {"V6_MIN_STRIPS": 0}):
+        ctx.reset_options()
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        try:
+            res = op.align2_batch(ctx, pwds)
+            raw = ctx.forward_batch(hs)
+        finally:
+            ctx.reset_options()
+        for pw, (oscr, ocells, otr), (scr, skl, st), (rscr, rcells, rtr, rst) in zip(pwds, want, res, raw):
+            assert st == 0 and rst == 0
+            assert rcells == ocells
+            assert scr == oscr and rscr == oscr, (opts, pw.alnmode, scr, oscr)
+            assert np.array_equal(rtr, otr), (opts, pw.alnmode)
+            assert np.array_equal(skl, oraclelib.stdskl(L, otr))
 
 
 def test_bench_family_divisions_vs_oracle(ctx):

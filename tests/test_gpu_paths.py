@@ -32,8 +32,9 @@ CONFIGS = {
     "no_v7": {"G2G_NO_V7": "1"},                                     # DPunit on v1 instead of the strip kernel
     "no_v8": {"G2G_NO_V8": "1"},                                     # DPunit_nv on v1 instead of the strip kernel
     "no_v6": {"G2G_NO_V6": "1"},                                     # _pf on the 8-lanes-per-cell kernel instead of v6
-    "v6_publish4": {"G2G_V2_SWEEP": "4"},                            # progress counters published every 4 steps
-    "v6_class_c": {"G2G_V6_LARGE_KB": "96"},                         # a third footprint class for v6 (off by default: slower than v2 there)
+    "v6": {"G2G_V6_MIN_STRIPS": "0"},                                # v6 for _pf whatever the batch size (by default only batches that fill the GPU)
+    "v6_publish4": {"G2G_V6_MIN_STRIPS": "0", "G2G_V2_SWEEP": "4"},  # progress counters published every 4 steps
+    "v6_class_c": {"G2G_V6_MIN_STRIPS": "0", "G2G_V6_LARGE_KB": "96"},                         # a third footprint class for v6 (off by default: slower than v2 there)
     "v2": {"G2G_FORCE_V2": "1"},
     "v2_t128": {"G2G_FORCE_V2": "1", "G2G_V2_THREADS": "128"},
     "v2_tiles": {"G2G_FORCE_V2": "1", "G2G_V2_SWEEP": "0"},
@@ -93,7 +94,7 @@ FAMILIES = [
 ]
 
 
-@pytest.mark.parametrize("name", ["default", "v6_publish4", "v6_class_c", "no_v6", "v3r_cols32", "v3r_tiles", "v3lds_all", "v3_pf", "v2", "v2_t128", "v2_tiles", "v2_tiles_t128"])
+@pytest.mark.parametrize("name", ["default", "v6", "v6_publish4", "v6_class_c", "no_v6", "v3r_cols32", "v3r_tiles", "v3lds_all", "v3_pf", "v2", "v2_t128", "v2_tiles", "v2_tiles_t128"])
 @pytest.mark.parametrize("fam", FAMILIES, ids=[f[0] for f in FAMILIES])
 def test_large_divisions_every_path(ctx, L, monkeypatch, name, fam):
     """Group-vs-rest divisions of a 650-700 column family (many strips and blocks) per forced path."""
