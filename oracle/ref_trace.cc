@@ -124,4 +124,30 @@ bool __wrap__Z8synthgapPP8GapsListP3SKLPPi(GapsList* glists[], SKL* skl, int* ls
 	}
 	return __real__Z8synthgapPP8GapsListP3SKLPPi(glists, skl, lst);
 }
+
+// Ssrel::pairsum_ss (src/fspscore.cc:896-922): the whole-MSA sum-of-pairs score prrn reports -- "P <use_pw> <value> <many> <len>"
+VTYPE __real__ZN5Ssrel10pairsum_ssEP4mSeqb(Ssrel* self, mSeq* sd, bool use_pw);
+VTYPE __wrap__ZN5Ssrel10pairsum_ssEP4mSeqb(Ssrel* self, mSeq* sd, bool use_pw)
+{
+	const VTYPE	v = __real__ZN5Ssrel10pairsum_ssEP4mSeqb(self, sd, use_pw);
+	FILE*	fd = trace_fd();
+	if (fd) {
+	    if (self->ktree && self->ktree->lead) {			// the tree THIS call used (the -O4 read-out builds a new Ssrel from the refined MSA)
+		Knode*	lead = self->ktree->lead;
+		for (int k = 0; k < 2 * sd->many - 1; ++k) {
+		    Knode&	nd = lead[k];
+		    fprintf(fd, "Q %d %d %d %d %.17g %.17g\n", nd.tid, nd.left? nd.left->tid: -1, nd.right? nd.right->tid: -1,
+			nd.parent? nd.parent->tid: -1, (double) nd.vol, (double) nd.cur);
+		}
+	    }
+	    fprintf(fd, "P %d %.17g %d %d |", use_pw? 1: 0, (double) v, sd->many, sd->len);
+	    for (int m = 0; m < sd->many; ++m) {			// the MSA it was computed on, member by member (residue codes)
+		fprintf(fd, " ");
+		for (int i = 0; i < sd->len; ++i) fprintf(fd, "%c", 'A' + (int) sd->at(i)[m]);
+	    }
+	    fprintf(fd, "\n");
+	}
+	return v;
+}
+
 }
