@@ -288,6 +288,16 @@ int        g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len, co
                       const g2g_refine_opts *opts, uint8_t **out_codes, int *out_len, g2g_refine_step **steps, int *nsteps,
                       g2g_refine_stats *stats);
 
+/* <-> VTYPE Ssrel::pairsum_ss(mSeq* sd, bool use_pw) (reference src/fspscore.cc:896-922; Sptree::sptree :784-821): the weighted
+ * sum-of-pairs score of a whole MSA, the number prrn reports for an alignment (initial / refined, the -O4 line).  The reference
+ * walks the weighting tree: a node of at most ndesc_thr = 60 leaves is scored naively (Msap::ps_nml with the pair weights of
+ * Ktree::recalcpw when use_pw), a larger node is the sum of its children plus the score BETWEEN their two groups
+ * (calcscore_grp: PwdM + SpScore::calcJxt).  Here the naive nodes run on the GPU (g2g_pairsum_kernel) and the joins through the
+ * level-1 builders + g2g_batch_spscore; the sum is formed in the reference's order.  codes / tree as for g2g_refine.
+ * Not on this path: tgapf != 1, the ether term (u0), exon-boundary annotations (spSigII), subset trees (ss->num < ss->elms). */
+int        g2g_pairsum(g2g_ctx *ctx, const g2g_params *prm, int many, int len, const uint8_t *codes, const g2g_tree *tree,
+                       int use_pw, double *out);
+
 /* ---- f3: the guide-tree stage -- score-only pairwise DPs between single sequences ----------------------
  * <-> VTYPE alnScoreD(const Seq* seqs[], const Simmtx* sm, int* ends = 0) (reference src/fwd2d1.cc:324-338), global branch:
  * Fwd2d::Fwd2d (the boundary values, :58-93), Fwd2d::forwardD (:136-158, anti-diagonal order, affine gaps -(v + k u),

@@ -56,6 +56,8 @@ def lib():
     L.g2g_refine.argtypes = [C.c_void_p, C.POINTER(_abi.Params), C.c_int, C.c_int, _abi.c_u8p, C.POINTER(_abi.Tree),
                              C.POINTER(_abi.RefineOpts), C.POINTER(_abi.c_u8p), C.POINTER(C.c_int),
                              C.POINTER(C.POINTER(_abi.RefineStep)), C.POINTER(C.c_int), C.POINTER(_abi.RefineStats)]
+    L.g2g_pairsum.argtypes = [C.c_void_p, C.POINTER(_abi.Params), C.c_int, C.c_int, _abi.c_u8p, C.POINTER(_abi.Tree), C.c_int,
+                              C.POINTER(C.c_double)]
     bind_level1(L)
     _lib = L
     return L

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "g2g_engine.hip")]
 EXTRA_CPP = [os.path.join(HERE, "csrc", f) for f in ("g2g_host.cpp", "g2g_refine.cpp")]
 DEPS = [os.path.join(HERE, "csrc", f) for f in
-        ("g2g_engine.hip", "g2g_kernels.hip", "g2g_kernels_v2.hip", "g2g_kernels_v3.hip", "g2g_kernels_v6.hip", "g2g_kernels_v7.hip", "g2g_kernels_v8.hip", "g2g_dist.hip", "g2g_pairaln.hip", "g2g_device.h", "g2g_internal.h", "g2g_host.cpp", "g2g_refine.cpp")] + \
+        ("g2g_engine.hip", "g2g_kernels.hip", "g2g_kernels_v2.hip", "g2g_kernels_v3.hip", "g2g_kernels_v6.hip", "g2g_kernels_v7.hip", "g2g_kernels_v8.hip", "g2g_dist.hip", "g2g_pairaln.hip", "g2g_pairsum.hip", "g2g_device.h", "g2g_internal.h", "g2g_host.cpp", "g2g_refine.cpp")] + \
        [os.path.join(os.path.dirname(HERE), "include", "g2g.h")]
 LIB = os.path.join(HERE, "libg2g.so")
 

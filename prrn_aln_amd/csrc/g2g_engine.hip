@@ -1373,3 +1373,4 @@ extern "C" int g2g_forward_batch(g2g_ctx *ctx, int n, const g2g_problem *const *
 
 #include "g2g_dist.hip"                // f3: the guide-tree DPs (own kernels, own entry point; shares the context)
 #include "g2g_pairaln.hip"             // f3: alignB_ng (pairwise alignment of single sequences with the path)
+#include "g2g_pairsum.hip"             // f1: Ssrel::pairsum_ss (naive nodes on the GPU, joins through calcSpScore)

@@ -446,3 +446,26 @@ def refine_native(ctx, codes: np.ndarray, tree: KTree, alp: op.AlnParam, seed: i
     L.g2g_free(steps)
     stats = {k: getattr(st, k) for k, _ in _abi.RefineStats._fields_ if k != "reserved"}
     return final, log, stats
+
+
+def pairsum(ctx, codes: np.ndarray, tree: KTree, alp: op.AlnParam, use_pw: bool = True) -> float:
+    """g2g_pairsum: Ssrel::pairsum_ss of an MSA -- the sum-of-pairs score prrn reports"""
+    import ctypes as C
+    from . import _abi
+    from ._lib import G2GError, last_error, lib
+    codes = np.ascontiguousarray(codes, np.uint8)
+    ln, many = codes.shape
+    prm, _sm = alp.to_c()
+    arr = lambda x, t: np.ascontiguousarray(x, t)
+    left, right, parent = arr(tree.left, np.int32), arr(tree.right, np.int32), arr(tree.parent, np.int32)
+    vol, cur = arr(tree.vol, np.float64), arr(tree.cur, np.float64)
+    T = _abi.Tree()
+    T.n_nodes = len(left)
+    i32p = C.POINTER(C.c_int32)
+    T.left, T.right, T.parent = left.ctypes.data_as(i32p), right.ctypes.data_as(i32p), parent.ctypes.data_as(i32p)
+    T.vol, T.cur = vol.ctypes.data_as(_abi.c_f64p), cur.ctypes.data_as(_abi.c_f64p)
+    out = C.c_double()
+    rc = lib().g2g_pairsum(ctx._h, C.byref(prm), many, ln, codes.ctypes.data_as(_abi.c_u8p), C.byref(T), 1 if use_pw else 0, C.byref(out))
+    if rc != 0:
+        raise G2GError("g2g_pairsum rc=%d: %s" % (rc, last_error()))
+    return out.value

@@ -1,0 +1,33 @@
+"""f1 on the GPU: g2g_pairsum (Ssrel::pairsum_ss) against the values traced out of the reference (tests/golden/pairsum): families of
+up to 60 members (the naive branch: g2g_pairsum_kernel) and of more (the tree recursion: naive sub-trees + calcscore_grp joins through
+the level-1 builders and g2g_batch_spscore), weighted and unweighted, Noll 2 and 3."""
+import glob
+import json
+import os
+
+import pytest
+
+import pairsumlib
+from prrn_aln_amd import engine
+from prrn_aln_amd.refine import KTree, pairsum
+
+pytestmark = pytest.mark.gpu
+FIX = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "pairsum", "*.json")))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = engine.Context()
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("path", FIX, ids=[os.path.basename(p)[:-5] for p in FIX])
+def test_pairsum_matches_reference(ctx, path):
+    f = json.load(open(path))
+    alp = pairsumlib.alp_of(f)
+    for c in f["cases"]:
+        t = c["tree"]
+        tree = KTree(t["left"], t["right"], t["parent"], t["vol"], t["cur"])
+        got = pairsum(ctx, pairsumlib.case_codes(c), tree, alp, use_pw=bool(c["use_pw"]))
+        assert got == c["value"], (f["name"], c["use_pw"], got, c["value"])
