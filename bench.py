@@ -313,7 +313,7 @@ def main():
     refinement = guide_tree = None
     if world == 1 and not args.shard_of and not args.limit and not args.no_cpu:
         try:
-            from prrn_aln_amd.refine import KTree, refine_native
+            from prrn_aln_amd.refine import KTree, refine_native, pairsum
             f = json.load(open(os.path.join(ROOT, "tests", "golden", "refine_prot20x100_s11.json")))
             t = f["tree"]
             tree = KTree(t["left"], t["right"], t["parent"], t["vol"], t["cur"])
@@ -329,7 +329,9 @@ def main():
                           "wall_ms": 1e3 * rt, "divisions_evaluated": rstats["divisions"], "accepted_moves": rstats["accepted"],
                           "gpu_batches": rstats["batches"], "divisions_recomputed": rstats["divisions_wasted"],
                           "same_branch_sequence_as_reference": [x["branch"] for x in rsteps] == f["branches"],
-                          "final_msa_identical_to_reference": same, "sp_delta_vs_reference": 0.0 if same else None}
+                          "final_msa_identical_to_reference": same, "sp_delta_vs_reference": 0.0 if same else None,
+                          # Ssrel::pairsum_ss (g2g_pairsum) of the start and of the refined MSA, on the trace's tree
+                          "pairsum_ss_start": pairsum(ctx, start, tree, ralp), "pairsum_ss_refined": pairsum(ctx, final, tree, ralp)}
         except Exception as e:
             refinement = {"error": str(e)[:200]}
         try:
