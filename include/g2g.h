@@ -99,6 +99,8 @@ typedef struct g2g_side {
     int32_t        npfq, pfq_step;
     const int32_t *pfq_pos;
     const double  *pfq_dns;
+    double         sumwt;           /* Seq::sumwt: sum of the members' weights (the member count when unweighted); read by the
+                                       PwdM::stt?? statistics (van / vbn and the thickness of the zero iterators)          */
 } g2g_side;
 
 typedef struct g2g_problem {
@@ -109,7 +111,7 @@ typedef struct g2g_problem {
     int32_t  lw, up;                /* band: WINDOW from stripe() (aln2.cc:156-174)               */
     int32_t  crg2_kind;             /* NTV engines: which PwdM::crg?? (maln2.cc:881-1024,1454-1614):
                                        11, 120/121 (12i/12w), 210/211, 220/221; 0 otherwise         */
-    int32_t  reserved1;
+    int32_t  dvsp;                  /* PwdB::DvsP: 0 nucleotide x nucleotide (the statistics read compacted codes), 3 protein x protein */
     double   basic_gop;             /* PwdM::Basic_GOP  = -scale*v (maln2.cc:232)                 */
     double   weighted_gop;          /* PwdM::Weighted_GOP = -v     (maln2.cc:237)                 */
     double   u;                     /* alnprm.u, unpaired-column penalty in unp1 (maln.h:185)     */
@@ -234,6 +236,8 @@ typedef struct {
     int32_t status, reserved;
     double  raw;         /* the score BEFORE rescale = the return value of PreSpScore::calcSpScore(SKL*), src/fspscore.cc:544-582:
                             Prrn::onecycle takes THIS for the current alignment and fstat.val for the new one (src/prrn5.cc:523,535) */
+    double  mch, mmc, unp;   /* FSTAT::mch / mmc / unp after rescale: matched, mismatched and unpaired member pairs per unit pair
+                                weight (PwdM::stt?? src/maln2.cc:627-850,1300-1450; the naive units count in calcstat)        */
 } g2g_fstat;
 /* level 0: on a prepared batch (inputs resident in HBM); skl[i] = the standardised skeleton of problem i
  * (g2g_stdskl output: corners ascending, first = (a.left, b.left), last = (a.right, b.right))              */

@@ -157,6 +157,7 @@ void side(g2g_side& s, mSeq* q, const FTYPE* wt, bool naive, SideBuf& B)
 	memset(&s, 0, sizeof(s));
 	s.many = q->many; s.len = q->len; s.left = q->left; s.right = q->right;
 	s.nils = q->inex.nils; s.dels = q->inex.dels;
+	s.sumwt = q->sumwt;
 	s.seq = q->at(-1);				// Seq::at(), seq.h:348: [pos][member], position -1 first
 	if (!wt) wt = q->weight;
 	if (wt) {B.wt.assign(wt, wt + q->many); s.weight = B.wt.data();}
@@ -217,7 +218,7 @@ SKL* alignC_g2g(mSeq* seqs[], PwdM* pwd, VTYPE* scr)
 	g2g_problem	p;
 	memset(&p, 0, sizeof(p));
 	p.alnmode = pwd->alnmode; p.noll = pwd->Noll; p.codonk1 = pwd->codonk1;
-	p.sim2_kind = sk; p.crg2_kind = ck;
+	p.sim2_kind = sk; p.crg2_kind = ck; p.dvsp = pwd->DvsP;
 	p.basic_gop = pwd->Basic_GOP; p.weighted_gop = pwd->Weighted_GOP; p.u = pwd->alnprm.u;
 	p.u2divu1 = pwd->BasicGEP < 0? pwd->LongGEP / pwd->BasicGEP: 0;		// fwd2c.h:85-86
 	p.v2divv1 = pwd->BasicGOP < 0? pwd->LongGOP / pwd->BasicGOP: 0;

@@ -28,13 +28,14 @@ class Side(C.Structure):
                 ("pseq", c_f64p), ("thk", c_f64p),
                 ("has_gfq", C.c_int32), ("gfq", GapProf),
                 ("gapdens", c_f64p), ("postgapdens", c_f64p),
-                ("npfq", C.c_int32), ("pfq_step", C.c_int32), ("pfq_pos", C.POINTER(C.c_int32)), ("pfq_dns", c_f64p)]
+                ("npfq", C.c_int32), ("pfq_step", C.c_int32), ("pfq_pos", C.POINTER(C.c_int32)), ("pfq_dns", c_f64p),
+                ("sumwt", C.c_double)]
 
 
 class Problem(C.Structure):
     _fields_ = [("alnmode", C.c_int32), ("sim2_kind", C.c_int32), ("noll", C.c_int32),
                 ("codonk1", C.c_int32), ("lw", C.c_int32), ("up", C.c_int32),
-                ("crg2_kind", C.c_int32), ("reserved1", C.c_int32),
+                ("crg2_kind", C.c_int32), ("dvsp", C.c_int32),
                 ("basic_gop", C.c_double), ("weighted_gop", C.c_double), ("u", C.c_double),
                 ("u2divu1", C.c_double), ("v2divv1", C.c_double),
                 ("simmtx", c_f64p), ("simdim", C.c_int32), ("simrows", C.c_int32),
@@ -121,6 +122,7 @@ def problem_from_arrays(d: Dict[str, np.ndarray]) -> ProblemHolder:
     p.noll = int(sc("Noll"))
     p.codonk1 = int(sc("codonk1"))
     p.crg2_kind = int(sc("crg2_kind")) if "crg2_kind" in d else 0
+    p.dvsp = int(sc("DvsP")) if "DvsP" in d else 3
     p.lw = int(sc("wdw_lw"))
     p.up = int(sc("wdw_up"))
     p.basic_gop = float(sc("Basic_GOP"))
@@ -138,6 +140,7 @@ def problem_from_arrays(d: Dict[str, np.ndarray]) -> ProblemHolder:
         side.many = int(g("many")[0]); side.len = int(g("len")[0])
         side.left = int(g("left")[0]); side.right = int(g("right")[0])
         side.nils = int(g("nils")[0]); side.dels = int(g("dels")[0])
+        side.sumwt = float(g("sumwt")[0]) if (pfx + "sumwt") in d else float(side.many)
         side.seq = _ptr(h.arr(g("seq"), np.uint8), c_u8p)
         if wkey in d:
             side.weight = _ptr(h.arr(d[wkey], np.float64), c_f64p)
@@ -170,4 +173,5 @@ class SpParams(C.Structure):
 
 
 class Fstat(C.Structure):
-    _fields_ = [("val", C.c_double), ("gap", C.c_double), ("status", C.c_int32), ("reserved", C.c_int32), ("raw", C.c_double)]
+    _fields_ = [("val", C.c_double), ("gap", C.c_double), ("status", C.c_int32), ("reserved", C.c_int32), ("raw", C.c_double),
+                ("mch", C.c_double), ("mmc", C.c_double), ("unp", C.c_double)]

@@ -26,6 +26,7 @@ struct DevSide {
     const double  *freq[3];
     const double  *gapdens;
     const double  *postgapdens;
+    double         sumwt;            // Seq::sumwt (read by the stt?? statistics)
     int            npfq, pfq_step;   // exon-boundary annotation (SigII::pfq): positions ascending, density per position
     const int     *pfq_pos;
     const double  *pfq_dns;
@@ -38,6 +39,7 @@ struct DevProb {
     int kind;            // 0 DPunit, 1 _hf, 2 _pf, 3 _nv   (reference src/dpunit.h:31-51)
     int noll, sim2_kind, crg2_kind, codonk1, lw, up, width;
     double basic_gop, weighted_gop, u, u2divu1, v2divv1;
+    int dvsp;            // PwdB::DvsP (0: nucleotide x nucleotide)
     double spb_fact;     // SpbFact; > 0 with both sides annotated: the intron-position bonus (fwd2c.h:446-452) is live
     int nbonus;          // cells of the DP that receive it, ascending in (m, n): precomputed by the host from PfqItr's walk
     const int *bon_m, *bon_n;

@@ -431,7 +431,7 @@ static void pack_side(Blob &bl, const g2g_side &s, DevSide &d, int kind, bool ne
 {
     memset(&d, 0, sizeof d);
     d.many = s.many; d.len = s.len; d.left = s.left; d.right = s.right; d.nils = s.nils;
-    d.nelm = s.nelm; d.felm = s.felm;
+    d.nelm = s.nelm; d.felm = s.felm; d.sumwt = s.sumwt > 0 ? s.sumwt : (double) s.many;
     const size_t cols = (size_t) s.len + 2;
     d.seq = OFF<const uint8_t>(bl.put(s.seq, cols * s.many));
     if (s.weight) d.weight = OFF<const double>(bl.put(s.weight, sizeof(double) * s.many));
@@ -594,7 +594,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         if (p->simmtx) d.simmtx = OFF<const double>(bl.put(p->simmtx, sizeof(double) * (size_t) p->simdim * p->simrows));
         pack_side(bl, p->a, d.a, d.kind, d.kind == 1 || d.kind == 2);
         pack_side(bl, p->b, d.b, d.kind, d.kind == 2);
-        d.spb_fact = p->spb_fact;
+        d.spb_fact = p->spb_fact; d.dvsp = p->dvsp;
         {
             std::vector<BonusCell> bc;
             intron_bonus_table(p, bc);
@@ -1255,7 +1255,7 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
     for (int i = 0; i < n; ++i) { off[i] = (int) tot; cnt[i] = (skl[i] && nskl[i] > 0) ? nskl[i] : 0; tot += cnt[i]; }
     std::vector<g2g_skl> all(tot ? tot : 1);
     for (int i = 0; i < n; ++i) if (cnt[i]) memcpy(&all[off[i]], skl[i], sizeof(g2g_skl) * cnt[i]);
-    const size_t b_skl = sizeof(g2g_skl) * all.size(), b_int = sizeof(int) * n, b_sp = sizeof(g2g_spparams) * n, b_out = sizeof(double) * 3 * n;
+    const size_t b_skl = sizeof(g2g_skl) * all.size(), b_int = sizeof(int) * n, b_sp = sizeof(g2g_spparams) * n, b_out = sizeof(double) * 6 * n;
     char *d = 0;
     const size_t o_skl = 0, o_off = (b_skl + 15) & ~(size_t) 15, o_cnt = o_off + ((b_int + 15) & ~(size_t) 15),
                  o_sp = o_cnt + ((b_int + 15) & ~(size_t) 15), o_out = o_sp + ((b_sp + 15) & ~(size_t) 15),
@@ -1288,7 +1288,7 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
                            gints ? (int *) (d + o_gws) : (int *) 0, (const long long *) (d + o_goff));
         e = hipGetLastError();
     }
-    std::vector<double> ho(3 * (size_t) n);
+    std::vector<double> ho(6 * (size_t) n);
     std::vector<int> hs(n);
     if (e == hipSuccess) e = hipMemcpyAsync(ho.data(), d + o_out, b_out, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(hs.data(), d + o_st, b_int, hipMemcpyDeviceToHost, ctx->stream);
@@ -1296,7 +1296,8 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
     hipFree(d);
     if (e != hipSuccess) { g2g_set_error("spscore: %s", hipGetErrorString(e)); return G2G_ERR_DEVICE; }
     for (int i = 0; i < n; ++i) {
-        out[i].val = ho[3 * i]; out[i].gap = ho[3 * i + 1]; out[i].raw = ho[3 * i + 2]; out[i].reserved = 0;
+        out[i].val = ho[6 * i]; out[i].gap = ho[6 * i + 1]; out[i].raw = ho[6 * i + 2]; out[i].reserved = 0;
+        out[i].mch = ho[6 * i + 3]; out[i].mmc = ho[6 * i + 4]; out[i].unp = ho[6 * i + 5];
         out[i].status = b->status[i] ? b->status[i] : hs[i] == 0 ? G2G_OK : hs[i] == -2 ? G2G_ERR_MODE : G2G_ERR_ARG;
     }
     return G2G_OK;

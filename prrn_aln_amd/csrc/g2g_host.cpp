@@ -477,6 +477,7 @@ void fill_side(g2g_group &g, g2g_side &s, bool ntv)
     s.pseq = g.vect ? g.pseq.data() : 0;
     flatten_thk(g);
     s.thk = g.thk_pos.data();
+    s.sumwt = g.sumwt;                                       // (set by mkthick)
     s.has_gfq = (g.gfq && g.dels) ? 1 : 0;
     if (s.has_gfq) {
         s.gfq.hetero = g.gfq->hetero;
@@ -619,6 +620,7 @@ extern "C" g2g_pwdm *g2g_pwdm_create(g2g_ctx *, const g2g_params *prm, g2g_group
     q.alnmode = alnmode; q.sim2_kind = sim2;
     const bool ntv = alnmode == G2G_NTV_ALB || alnmode == G2G_NTV_ALN;
     q.crg2_kind = ntv ? crg2 : 0;
+    q.dvsp = DvsP;
     q.noll = Noll; q.codonk1 = codonk1;
     q.basic_gop = (double) (-f_scale * f_v);                 // resetuab, src/maln2.cc:227-243 (float arithmetic)
     q.weighted_gop = (double) -f_v;

@@ -755,16 +755,166 @@ __device__ double gep_longup_both(const GepDev &g, const SList df, const DList d
     gep_shift(g, res, pos);
     return lunp;
 }
+// ---- PwdM::stt?? (src/maln2.cc:627-850, 1300-1450): matched / mismatched / unpaired member pairs of a column pair -> FSTAT.
+// ha / hb false: the "zero" iterator of a gap segment (res = vss = NULL, thickness {sumwt, 0, sumwt}).  Every lane replays it.
+struct SpStat { double mch, mmc, unp; };
+__device__ void sp_stt2(const DevProb &P, const int apos, const int bpos, const bool ha, const bool hb, SpStat &S)
+{
+    const DevSide &a = P.a, &b = P.b;
+    const uint8_t *ca = ha ? res_at(a, apos) : (const uint8_t *) 0, *cb = hb ? res_at(b, bpos) : (const uint8_t *) 0;
+    const double *va = (ha && a.pseq) ? vss_at(a, apos) : (const double *) 0, *vb = (hb && b.pseq) ? vss_at(b, bpos) : (const double *) 0;
+    const double aefq = ha ? thk_at(a, apos)[2] : a.sumwt, befq = hb ? thk_at(b, bpos)[2] : b.sumwt;
+    const double van = a.sumwt, vbn = b.sumwt;
+    const double *wa = a.weight, *wb = b.weight;
+    const int an = a.many, bn = b.many;
+    const bool dxd = P.dvsp == 0;
+    const uint8_t cmp[17] = {0, 1, 2, 3, 6, 4, 6, 6, 6, 5, 6, 6, 6, 6, 6, 6, 6};       // nccmpctab, seq.cc:32
+#define SP_NOTGAP(x) ((x) && (x)[0] > 1)
+#define SP_TRUEGAP(x) (!(x) || (x)[0] == 1)
+    switch (P.sim2_kind) {
+    case G2G_SIM11:
+        if (SP_NOTGAP(ca)) {
+            if (SP_NOTGAP(cb)) { if (ca[0] == cb[0]) ++S.mch; else ++S.mmc; }
+            else if (SP_TRUEGAP(ca)) ++S.unp;
+        } else if (SP_NOTGAP(cb) && SP_TRUEGAP(ca)) ++S.unp;
+        break;
+    case G2G_SIM12I: {
+        int sm = 0, g = 0, u = 0;
+        if (SP_NOTGAP(ca)) {
+            if (cb) {
+                for (int j = 0; j < bn; ++j) { if (cb[j] == ca[0]) ++sm; else { if (cb[j] <= 1) ++u; if (cb[j] == 1) ++g; } }
+                S.mch += sm; S.mmc += bn - sm - u; S.unp += g;
+            } else S.unp += befq;
+        } else if (cb && SP_TRUEGAP(ca)) { for (int j = 0; j < bn; ++j) if (cb[j] > 1) ++g; S.unp += g; }
+        break; }
+    case G2G_SIM12W: {
+        double sm = 0, g = 0, u = 0;
+        if (SP_NOTGAP(ca)) {
+            if (cb) {
+                for (int j = 0; j < bn; ++j) { if (cb[j] == ca[0]) sm += wb[j]; else { if (cb[j] <= 1) u += wb[j]; if (cb[j] == 1) g += wb[j]; } }
+                S.mch += sm; S.mmc += vbn - sm - u; S.unp += g;
+            } else S.unp += befq;
+        } else if (cb && SP_TRUEGAP(ca)) { for (int j = 0; j < bn; ++j) if (cb[j] > 1) S.unp += wb[j]; }
+        break; }
+    case G2G_SIM13:
+        if (SP_NOTGAP(ca)) {
+            if (vb) {
+                int cca = ca[0];
+                if (dxd) cca = cmp[cca];
+                S.mch += vb[cca]; S.mmc += vbn - vb[1] - vb[cca] - vb[0]; S.unp += vb[1];
+            } else S.unp += befq;
+        } else if (vb && SP_TRUEGAP(ca)) S.unp += vbn - vb[1] - vb[0];
+        break;
+    case G2G_SIM21I: {
+        int sm = 0, g = 0, u = 0;
+        if (SP_NOTGAP(cb)) {
+            if (ca) {
+                for (int i = 0; i < an; ++i) { if (ca[i] == cb[0]) ++sm; else if (ca[i] <= 1) ++u; if (ca[i] == 1) ++g; }
+                S.mch += sm; S.mmc += an - sm - u; S.unp += g;
+            } else S.unp += aefq;
+        } else if (ca && SP_TRUEGAP(cb)) { for (int i = 0; i < an; ++i) if (ca[i] > 1) ++g; S.unp += g; }
+        break; }
+    case G2G_SIM21W: {
+        double sm = 0, g = 0, u = 0;
+        if (SP_NOTGAP(cb)) {
+            if (ca) {
+                for (int i = 0; i < an; ++i) { if (ca[i] == cb[0]) sm += wa[i]; else if (ca[i] <= 1) u += wa[i]; if (ca[i] == 1) g += wa[i]; }
+                S.mch += sm; S.mmc += van - sm - u; S.unp += g;
+            } else S.unp += aefq;
+        } else if (ca && SP_TRUEGAP(cb)) { for (int i = 0; i < an; ++i) if (ca[i] > 1) S.unp += wa[i]; }
+        break; }
+    case G2G_SIM22I: {
+        int sm = 0, m = 0, g = 0;
+        if (ca && cb) {
+            for (int j = 0; j < bn; ++j) {
+                if (cb[j] > 1) { for (int i = 0; i < an; ++i) { if (ca[i] == cb[j]) ++sm; else if (ca[i] > 1) ++m; if (ca[i] == 1) ++g; } }
+                else if (cb[j] == 1) { for (int i = 0; i < an; ++i) if (ca[i] > 1) ++g; }
+            }
+        } else if (ca) { for (int i = 0; i < an; ++i) if (ca[i] > 1) g += (int) befq; }
+        else if (cb) { for (int j = 0; j < bn; ++j) if (cb[j] > 1) g += (int) aefq; }
+        S.mch += sm; S.mmc += m; S.unp += g;
+        break; }
+    case G2G_SIM22W:
+        if (ca && cb) {
+            for (int j = 0; j < bn; ++j) {
+                double sm = 0, g = 0, u = 0;
+                if (cb[j] > 1) {
+                    for (int i = 0; i < an; ++i) { if (ca[i] == cb[j]) sm += wa[i]; else { if (ca[i] <= 1) u += wa[i]; if (ca[i] == 1) g += wa[i]; } }
+                    S.mmc += (van - sm - u) * wb[j]; S.mch += sm * wb[j]; S.unp += g * wb[j];
+                } else if (cb[j] == 1) {
+                    for (int i = 0; i < an; ++i) if (ca[i] > 1) g += wa[i];
+                    S.unp += g * wb[j];
+                }
+            }
+        } else if (ca) { for (int i = 0; i < an; ++i) if (ca[i] > 1) S.unp += befq * wa[i]; }
+        else if (cb) { for (int j = 0; j < bn; ++j) if (cb[j] > 1) S.unp += aefq * wb[j]; }
+        break;
+    case G2G_SIM23I: case G2G_SIM23W: {
+        const bool w = P.sim2_kind == G2G_SIM23W;
+        if (ca) {
+            for (int i = 0; i < an; ++i) {
+                int cca = ca[i];
+                if (dxd) cca = cmp[cca];
+                if (cca > 1) {
+                    if (vb) {
+                        if (w) { S.mch += vb[cca] * wa[i]; S.mmc += (vbn - vb[1] - vb[cca] - vb[0]) * wa[i]; S.unp += vb[1] * wa[i]; }
+                        else { S.mch += vb[cca]; S.mmc += vbn - vb[1] - vb[cca] - vb[0]; S.unp += vb[1]; }
+                    } else if ((w ? (int) ca[i] : cca) == 1) S.unp += befq;
+                } else if (vb && (w ? (int) ca[i] : cca) == 1) { if (w) S.unp += (vbn - vb[1] - vb[0]) * wa[i]; else S.unp += vbn - vb[1] - vb[0]; }
+            }
+        } else if (vb) S.unp += aefq * (vbn - vb[1] - vb[0]);
+        break; }
+    case G2G_SIM31:
+        if (SP_NOTGAP(cb)) {
+            if (va) {
+                int ccb = cb[0];
+                if (dxd) ccb = cmp[ccb];
+                S.mch += va[ccb]; S.mmc += van - va[1] - va[ccb] - va[0]; S.unp += va[1];
+            } else S.unp += aefq;
+        } else if (va && SP_TRUEGAP(cb)) S.unp += van - va[1] - va[0];
+        break;
+    case G2G_SIM32I: case G2G_SIM32W: {
+        const bool w = P.sim2_kind == G2G_SIM32W;
+        if (cb) {
+            for (int j = 0; j < bn; ++j) {
+                int ccb = cb[j];
+                if (dxd) ccb = cmp[ccb];
+                if (ccb > 1) {
+                    if (va) {
+                        if (w) { S.mch += va[ccb] * wb[j]; S.mmc += (van - va[1] - va[ccb] - va[0]) * wb[j]; S.unp += va[1] * wb[j]; }
+                        else { S.mch += va[ccb]; S.mmc += van - va[1] - va[ccb] - va[0]; S.unp += va[1]; }
+                    } else if ((w ? (int) cb[j] : ccb) == 1) S.unp += aefq;
+                } else if (va && (w ? (int) cb[j] : ccb) == 1) { if (w) S.unp += (van - va[1] - va[0]) * wb[j]; else S.unp += van - va[1] - va[0]; }
+            }
+        } else if (va) S.unp += befq * (van - va[1] - va[0]);
+        break; }
+    case G2G_SIM33: case G2G_SIM33N:
+        if (va && vb) {
+            double sm = 0;
+            S.mmc += (van - va[1] - va[0]) * (vbn - vb[1] - vb[0]);
+            S.unp += va[1] * (vbn - vb[1] - vb[0]) + (van - va[1] - va[0]) * vb[1];
+            const int base = dxd ? 2 : 3, top = a.felm - 2;           // va + base_code .. va + felm - 2 (:834-838, as written)
+            for (int k = base; k < top; ++k) sm += va[k] * vb[k];
+            S.mch += sm; S.mmc -= sm;
+        } else if (va) S.unp += (van - va[1] - va[0]) * befq;
+        else if (vb) S.unp += (vbn - vb[1] - vb[0]) * aefq;
+        break;
+    default: break;
+    }
+#undef SP_NOTGAP
+#undef SP_TRUEGAP
+}
 template <int KIND>
 __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int ni, int &apos, int &bpos, int &glb,
                           const DList dla, const DList dlb, double &scr, double &tgap,
-                          const bool gep, const GepDev &agep, const GepDev &bgep, double &lunp)
+                          const bool gep, const GepDev &agep, const GepDev &bgep, double &lunp, SpStat &St)
 {
     const DevSide &a = P.a, &b = P.b;
     if (KIND == 0) {
         if (mi == ni) {
-            while (mi--) { ++apos; ++bpos; scr += sim2(P, apos, bpos); }
+            while (mi--) { ++apos; ++bpos; scr += sim2(P, apos, bpos); sp_stt2(P, apos, bpos, true, true, St); }
         } else if (mi) {
+            St.unp += mi;
             const double efq = thk_at(b, bpos)[2];
             tgap += sp.vab * efq;
             double unp = mi * sp.basic_gep;                                       // UnpPenalty, aln.h:275-279
@@ -772,6 +922,7 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
             scr += unp * efq;
             apos += mi;
         } else if (ni) {
+            St.unp += ni;
             const double efq = thk_at(a, apos)[2];
             tgap += sp.vab * efq;
             double unp = ni * sp.basic_gep;
@@ -785,6 +936,7 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
                 ++apos; ++bpos;
                 scr += sim2(P, apos, bpos);
                 tgap += newgap_di(gfq_at(a, 1, apos), glb, dla);
+                sp_stt2(P, apos, bpos, true, true, St);
                 newdelta(dla, gfq_at(a, 1, apos), dla);
                 if (gep) { lunp += gep_longup_half(bgep, gfq_at(a, 1, apos), dla, bpos); gep_shift(agep, res_at(a, apos), apos); }
                 glb = 0;
@@ -794,6 +946,7 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
                 ++apos;
                 scr += unpa(P, apos, bpos);
                 tgap += newgap_cj(gfq_at(a, 0, apos), dla, glb);
+                sp_stt2(P, apos, bpos, true, false, St);
                 newdelta(dla, gfq_at(a, 1, apos), dla);
                 ++glb;
                 if (gep) lunp += gep_longup_res(agep, res_at(a, apos), apos, glb, true);
@@ -803,6 +956,7 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
                 ++bpos;
                 scr += unpb(P, bpos, apos);
                 tgap += newgap_di(gfq_at(a, 2, apos), glb, dla);
+                sp_stt2(P, apos, bpos, false, true, St);
                 incdelta2(dla, dla);
                 if (gep) lunp += gep_longup_half(bgep, gfq_at(a, 2, apos), dla, bpos);
             }
@@ -814,6 +968,7 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
                 scr += sim2(P, apos, bpos);
                 tgap += newgap4(gfq_at(a, 0, apos), dla, gfq_at(b, 1, bpos), dlb)
                       + newgap4(gfq_at(b, 0, bpos), dlb, gfq_at(a, 1, apos), dla);
+                sp_stt2(P, apos, bpos, true, true, St);
                 newdelta(dla, gfq_at(a, 1, apos), dla);
                 newdelta(dlb, gfq_at(b, 1, bpos), dlb);
                 if (gep) {
@@ -826,6 +981,7 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
                 ++apos;
                 scr += unpa(P, apos, bpos);
                 tgap += newgap4(gfq_at(a, 0, apos), dla, gfq_at(b, 2, bpos), dlb);
+                sp_stt2(P, apos, bpos, true, false, St);
                 newdelta(dla, gfq_at(a, 1, apos), dla);
                 incdelta2(dlb, dlb);
                 if (gep) lunp += gep_longup_both(agep, gfq_at(b, 2, bpos), dlb, res_at(a, apos), apos);
@@ -835,6 +991,7 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
                 ++bpos;
                 scr += unpb(P, bpos, apos);
                 tgap += newgap4(gfq_at(b, 0, bpos), dlb, gfq_at(a, 2, apos), dla);
+                sp_stt2(P, apos, bpos, false, true, St);
                 newdelta(dlb, gfq_at(b, 1, bpos), dlb);
                 incdelta2(dla, dla);
                 if (gep) lunp += gep_longup_both(bgep, gfq_at(a, 2, apos), dla, res_at(b, bpos), bpos);
@@ -860,7 +1017,7 @@ __device__ void sp_pregap(const DevSide &sd, int *gl)
     }
 }
 __device__ void sp_calcstat_ntv(const DevProb &P, const NtvState &N, int d3, int apos, int bpos, double &scr, double &tgap,
-                                const bool gep, const GepDev &agep, const GepDev &bgep, double &lunp)
+                                const bool gep, const GepDev &agep, const GepDev &bgep, double &lunp, SpStat &St)
 {
     const DevSide &a = P.a, &b = P.b;
     const int an = a.many, bn = b.many;
@@ -873,11 +1030,13 @@ __device__ void sp_calcstat_ntv(const DevProb &P, const NtvState &N, int d3, int
         if (d3 == 0) {
             const bool ar = as[0] > 1, br = bs[0] > 1;
             const double au = agd[0], bu = bgd[0];
-            if (ar && br) ;
+            if (ar && br) { if (as[0] == bs[0]) ++St.mch; else ++St.mmc; }
             else if (ar && bu > 0) {
+                St.unp += bu;
                 if (glb <= gla) tgap += bu;
                 else if (gep) lunp += gep_longup_res(agep, as, apos, glb + 1, true) * bu;
             } else if (au > 0 && br) {
+                St.unp += au;
                 if (gla <= glb) tgap += au;
                 else if (gep) lunp += gep_longup_res(bgep, bs, bpos, gla + 1, true) * au;
             }
@@ -885,6 +1044,7 @@ __device__ void sp_calcstat_ntv(const DevProb &P, const NtvState &N, int d3, int
             if (as[0] > 1) {
                 const double bu = thk_at(b, bpos)[2];
                 if (bu > 0) {
+                    St.unp += bu;
                     if (glb <= gla) tgap += bu;
                     else if (gep) lunp += gep_longup_res(agep, as, apos, glb + 1, true) * bu;
                 }
@@ -893,6 +1053,7 @@ __device__ void sp_calcstat_ntv(const DevProb &P, const NtvState &N, int d3, int
             if (bs[0] > 1) {
                 const double au = thk_at(a, apos)[2];
                 if (au > 0) {
+                    St.unp += au;
                     if (gla <= glb) tgap += au;
                     else if (gep) lunp += gep_longup_res(bgep, bs, bpos, gla + 1, true) * au;
                 }
@@ -909,11 +1070,13 @@ __device__ void sp_calcstat_ntv(const DevProb &P, const NtvState &N, int d3, int
             for (int i = 0; i < an; ++i) {
                 const bool ar = as[i] > 1;
                 const double au = agd[i];
-                if (ar && br) ;
+                if (ar && br) { if (as[i] == bs[0]) St.mch += wa[i]; else St.mmc += wa[i]; }
                 else if (ar && bu > 0) {
+                    St.unp += wa[i] * bu;
                     if (glb <= N.gla[i]) tgap += wa[i] * bu;
                     else if (gep && gep_long1(agep, i, apos, glb + 1)) lunp += wa[i] * bu;
                 } else if (au > 0 && br) {
+                    St.unp += wa[i] * au;
                     if (N.gla[i] <= glb) tgap += wa[i] * au;
                     else if (gep && gep_long1(bgep, 0, bpos, N.gla[i] + 1)) lunp += wa[i] * au;
                 }
@@ -924,6 +1087,7 @@ __device__ void sp_calcstat_ntv(const DevProb &P, const NtvState &N, int d3, int
             for (int i = 0; i < an; ++i)
                 if (as[i] > 1) {
                     if (bu > 0) {
+                        St.unp += wa[i] * bu;
                         if (glb <= N.gla[i]) tgap += wa[i] * bu;
                         else if (gep && gep_long1(agep, i, apos, glb + 1)) lunp += wa[i] * bu;
                     }
@@ -933,6 +1097,7 @@ __device__ void sp_calcstat_ntv(const DevProb &P, const NtvState &N, int d3, int
             for (int i = 0; i < an; ++i) {
                 const double au = apg[i];
                 if (au > 0) {
+                    St.unp += wa[i] * au;
                     if (N.gla[i] <= glb) tgap += wa[i] * au;
                     else if (gep && gep_long1(bgep, 0, bpos, N.gla[i] + 1)) lunp += wa[i] * au;
                 }
@@ -944,28 +1109,33 @@ __device__ void sp_calcstat_ntv(const DevProb &P, const NtvState &N, int d3, int
     }
     const bool w = N.unit == 2;                                // SPunit_w22 weighs the inner sums, SPunit_nv adds them raw
     const double *wta = a.weight, *wtb = b.weight;
+    int nmch = 0, nmmc = 0;                                    // SPunit_nv counts locally and adds once (fspscore.cc:63-65,134-138)
+    double nunp = 0;
     if (d3 == 0) {
         for (int i = 0; i < an; ++i) {
             const bool ar = as[i] > 1;
             const double au = agd[i];
-            double g = 0, l = 0;
+            double g = 0, l = 0, sm = 0, u = 0;
             for (int j = 0; j < bn; ++j) {
                 const bool br = bs[j] > 1;
                 const double bu = bgd[j];
-                if (ar && br) ;
+                if (ar && br) { if (w) { if (as[i] == bs[j]) sm += wtb[j]; } else { if (as[i] == bs[j]) ++nmch; else ++nmmc; } }
                 else if (ar && bu > 0) {
+                    if (w) u += wtb[j] * bu; else nunp += bu;
                     if (N.glb[j] <= N.gla[i]) { if (w) g += wtb[j] * bu; else tgap += bu; }
                     else if (gep && gep_long1(agep, i, apos, N.glb[j] + 1)) { if (w) l += wtb[j] * bu; else lunp += bu; }
                 } else if (au > 0 && br) {
+                    if (w) u += wtb[j] * au; else nunp += au;
                     if (N.gla[i] <= N.glb[j]) { if (w) g += wtb[j] * au; else tgap += au; }
                     else if (gep && gep_long1(bgep, j, bpos, N.gla[i] + 1)) { if (w) l += wtb[j] * au; else lunp += au; }
                 }
             }
-            if (w) { tgap += g * wta[i]; lunp += l * wta[i]; }
+            if (w) { tgap += g * wta[i]; lunp += l * wta[i]; St.mch += sm * wta[i]; St.mmc += (b.sumwt - sm - u) * wta[i]; St.unp += u * wta[i]; }
             if (ar && gep) gep_shift1(agep, i, apos);
         }
         if (gep) { gep_wave_sync(); gep_shift(bgep, bs, bpos); }
     } else if (d3 > 0) {
+        if (w) St.unp += thk_at(b, bpos)[2] * thk_at(a, apos)[0]; else nunp += thk_at(a, apos)[0] * thk_at(b, bpos)[2];
         for (int i = 0; i < an; ++i)
             if (as[i] > 1) {
                 double g = 0, l = 0;
@@ -980,6 +1150,7 @@ __device__ void sp_calcstat_ntv(const DevProb &P, const NtvState &N, int d3, int
                 if (gep) gep_shift1(agep, i, apos);
             }
     } else {
+        if (w) St.unp += thk_at(a, apos)[2] * thk_at(b, bpos)[0]; else nunp += thk_at(a, apos)[2] * thk_at(b, bpos)[0];
         for (int j = 0; j < bn; ++j)
             if (bs[j] > 1) {
                 double g = 0, l = 0;
@@ -994,16 +1165,17 @@ __device__ void sp_calcstat_ntv(const DevProb &P, const NtvState &N, int d3, int
                 if (gep) gep_shift1(bgep, j, bpos);
             }
     }
+    if (!w) { St.mch += nmch; St.mmc += nmmc; St.unp += nunp; }
     if (gep) gep_wave_sync();
 }
 __device__ void sp_calscr_ntv(const DevProb &P, const NtvState &N, int mi, int ni, int &apos, int &bpos, double &scr, double &tgap,
-                              const bool gep, const GepDev &agep, const GepDev &bgep, double &lunp)
+                              const bool gep, const GepDev &agep, const GepDev &bgep, double &lunp, SpStat &St)
 {
     const int an = P.a.many, bn = P.b.many;
     if (mi == ni) {
         while (mi--) {
             ++apos; ++bpos;
-            sp_calcstat_ntv(P, N, 0, apos, bpos, scr, tgap, gep, agep, bgep, lunp);
+            sp_calcstat_ntv(P, N, 0, apos, bpos, scr, tgap, gep, agep, bgep, lunp, St);
             if (N.unit == 1) { N.gla[0] = 0; N.glb[0] = 0; }
             else if (N.unit == 3) { sp_incrgap(N.gla, res_at(P.a, apos), an); N.glb[0] = 0; }
             else { sp_incrgap(N.gla, res_at(P.a, apos), an); sp_incrgap(N.glb, res_at(P.b, bpos), bn); }
@@ -1011,7 +1183,7 @@ __device__ void sp_calscr_ntv(const DevProb &P, const NtvState &N, int mi, int n
     } else if (mi) {
         while (mi--) {
             ++apos;
-            sp_calcstat_ntv(P, N, 1, apos, bpos, scr, tgap, gep, agep, bgep, lunp);
+            sp_calcstat_ntv(P, N, 1, apos, bpos, scr, tgap, gep, agep, bgep, lunp, St);
             if (N.unit == 1) { N.gla[0] = 0; ++N.glb[0]; }
             else if (N.unit == 3) { sp_incrgap(N.gla, res_at(P.a, apos), an); ++N.glb[0]; }
             else { sp_incrgap(N.gla, res_at(P.a, apos), an); sp_incrgap(N.glb, (const uint8_t *) 0, bn); }
@@ -1019,7 +1191,7 @@ __device__ void sp_calscr_ntv(const DevProb &P, const NtvState &N, int mi, int n
     } else if (ni) {
         while (ni--) {
             ++bpos;
-            sp_calcstat_ntv(P, N, -1, apos, bpos, scr, tgap, gep, agep, bgep, lunp);
+            sp_calcstat_ntv(P, N, -1, apos, bpos, scr, tgap, gep, agep, bgep, lunp, St);
             if (N.unit == 1) { ++N.gla[0]; N.glb[0] = 0; }
             else if (N.unit == 3) { sp_incrgap(N.gla, (const uint8_t *) 0, an); N.glb[0] = 0; }
             else { sp_incrgap(N.gla, (const uint8_t *) 0, an); sp_incrgap(N.glb, res_at(P.b, bpos), bn); }
@@ -1083,13 +1255,14 @@ __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *
     int m = skl[0].x, n = skl[0].y, glb = 0;
     int apos = m - 1, bpos = n - 1;
     double scr = 0, tgap = 0;
+    SpStat St; St.mch = St.mmc = St.unp = 0;
     IiDev II;
     ii_init(II, P);
     for (int k = 1; k < nskl; ++k) {
         const int mi = skl[k].x - m, ni = skl[k].y - n, i = mi - ni;
         auto run = [&](int mi_, int ni_) {
-            if (KIND == 3) sp_calscr_ntv(P, N, mi_, ni_, apos, bpos, scr, tgap, gep, agep, bgep, lunp);
-            else sp_calscr<(KIND == 3 ? 0 : KIND)>(P, sp, mi_, ni_, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp);
+            if (KIND == 3) sp_calscr_ntv(P, N, mi_, ni_, apos, bpos, scr, tgap, gep, agep, bgep, lunp, St);
+            else sp_calscr<(KIND == 3 ? 0 : KIND)>(P, sp, mi_, ni_, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp, St);
         };
         if (!i || !mi || !ni) run(mi, ni);
         else if (i > 0) { run(ni, ni); run(i, 0); }
@@ -1110,6 +1283,7 @@ __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *
     out[0] = scr / sp.vab;                                                       // rescale
     out[1] = tgap / sp.vab;
     out[2] = scr;
+    out[3] = St.mch / sp.vab; out[4] = St.mmc / sp.vab; out[5] = St.unp / sp.vab;     // PwdM::rescale, maln2.cc:249-250
 }
 extern "C" __global__ void __launch_bounds__(64)
 g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const int2 *skl, const int *skl_off, const int *nskl,
@@ -1118,16 +1292,16 @@ g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const
     const int ip = blockIdx.x;
     if (ip >= nprob) return;                                   // (all 64 lanes walk the chain in lockstep, see GepDev)
     const DevProb &P = probs[ip];
-    out[3 * ip] = 0; out[3 * ip + 1] = 0; out[3 * ip + 2] = 0;
+    for (int k = 0; k < 6; ++k) out[6 * ip + k] = 0;
     if (P.kind < 0) { status[ip] = -1; return; }
     int *ws = (gepws && gep_off[ip] >= 0) ? gepws + gep_off[ip] : (int *) 0;
     if (((P.noll == 3 && P.kind >= 1) || P.kind == 3) && !ws) { status[ip] = -2; return; }
     if (P.kind == 3 && (!P.a.gapdens || !P.b.gapdens)) { status[ip] = -1; return; }
     if (nskl[ip] < 2) { status[ip] = -1; return; }
     const int2 *s = skl + skl_off[ip];
-    if (P.kind == 0) sp_calcskl<0>(P, sp[ip], s, nskl[ip], out + 3 * ip, ws);
-    else if (P.kind == 1) sp_calcskl<1>(P, sp[ip], s, nskl[ip], out + 3 * ip, ws);
-    else if (P.kind == 2) sp_calcskl<2>(P, sp[ip], s, nskl[ip], out + 3 * ip, ws);
-    else sp_calcskl<3>(P, sp[ip], s, nskl[ip], out + 3 * ip, ws);
+    if (P.kind == 0) sp_calcskl<0>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws);
+    else if (P.kind == 1) sp_calcskl<1>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws);
+    else if (P.kind == 2) sp_calcskl<2>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws);
+    else sp_calcskl<3>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws);
     status[ip] = 0;
 }

@@ -138,6 +138,7 @@ class Batch:
         rc = lib().g2g_batch_spscore(self._h, sp, ptrs, cnt, out)
         if rc:
             raise G2GError("g2g_batch_spscore rc=%d: %s" % (rc, last_error()))
+        self.last_stats = [(out[i].mch, out[i].mmc, out[i].unp) for i in range(n)]      # FSTAT::mch / mmc / unp of the same call
         return [(out[i].val, out[i].gap, out[i].status) for i in range(n)]
 
     def free(self):

@@ -184,9 +184,9 @@ def spparams(pwd: PwdM) -> "_abi.SpParams":
     return sp
 
 
-def calcSpScore_batch(ctx, pwds: Sequence[PwdM], skls):
+def calcSpScore_batch(ctx, pwds: Sequence[PwdM], skls, stats: bool = False):
     """<-> PreSpScore::calcSpScore(GsI) (reference src/fspscore.cc:584): [(fstat.val, fstat.gap, status, raw score)] of the
-    alignments the standardised skeletons describe."""
+    alignments the standardised skeletons describe; with stats=True each tuple continues with (fstat.mch, fstat.mmc, fstat.unp)."""
     L = lib()
     n = len(pwds)
     hs = (C.c_void_p * n)(*[p._h for p in pwds])
@@ -195,4 +195,6 @@ def calcSpScore_batch(ctx, pwds: Sequence[PwdM], skls):
     rc = L.g2g_spscore_batch(ctx._h, n, hs, ptrs, cnt, out)
     if rc:
         raise G2GError("g2g_spscore_batch rc=%d: %s" % (rc, last_error()))
+    if stats:
+        return [(out[i].val, out[i].gap, out[i].status, out[i].raw, out[i].mch, out[i].mmc, out[i].unp) for i in range(n)]
     return [(out[i].val, out[i].gap, out[i].status, out[i].raw) for i in range(n)]

@@ -81,3 +81,16 @@ def spscore_raw(L, holder, sp: "_abi.SpParams", skl: np.ndarray):
     out = (C.c_double * 3)()
     rc = L.g2g_oracle_spscore(C.byref(holder.c), C.byref(sp), buf, n, out)
     return rc, out[0], out[1], out[2]
+
+
+def spscore_stats(L, holder, sp: "_abi.SpParams", skl: np.ndarray):
+    """the same with the FSTAT counters: (rc, val, gap, raw, mch, mmc, unp)"""
+    L.g2g_oracle_spscore6.restype = C.c_int
+    L.g2g_oracle_spscore6.argtypes = [C.POINTER(_abi.Problem), C.POINTER(_abi.SpParams), C.POINTER(_abi.Skl), C.c_int, C.POINTER(C.c_double)]
+    n = len(skl)
+    buf = (_abi.Skl * n)()
+    for i in range(n):
+        buf[i].m, buf[i].n = int(skl[i][0]), int(skl[i][1])
+    out = (C.c_double * 6)()
+    rc = L.g2g_oracle_spscore6(C.byref(holder.c), C.byref(sp), buf, n, out)
+    return (rc,) + tuple(out)

@@ -62,9 +62,11 @@ def test_calcspscore_matches_reference_goldens(ctx):
         ga, gb = groups_from_golden(d, alp)
         pws.append(op.PwdM([ga, gb], alp)); want.append(d); names.append(os.path.basename(f))
     res = op.align2_batch(ctx, pws)
-    fs = op.calcSpScore_batch(ctx, pws, [skl for (_, skl, _) in res])
+    fs = op.calcSpScore_batch(ctx, pws, [skl for (_, skl, _) in res], stats=True)
     n_ok = 0
-    for name, d, (val, gap, st, _raw) in zip(names, want, fs):
+    for name, d, (val, gap, st, _raw, mch, mmc, unp) in zip(names, want, fs):
+        # ... and the FSTAT counters mch / mmc / unp (PwdM::stt??, 14 variants, and the counters of the naive units)
+        assert (mch, mmc, unp) == (d["fstat_mch"][0], d["fstat_mmc"][0], d["fstat_unp"][0]), (name, mch, mmc, unp)
         # every mode of the path: plain / half / full profile units (Noll 2, and Noll 3 with the Gep1st long-gap
         # bookkeeping) and the naive units SPunit_nv / _w11 / _w22 of the NTV modes
         assert st == 0, name

@@ -85,8 +85,9 @@ def test_intron_position_bonus_goldens(ctx, L):
         assert st == 0 and scr == d["scr"][0] and np.array_equal(tr, d["vmf_trace"]), (os.path.basename(f), st, scr, float(d["scr"][0]))
     sps = [_abi.SpParams(float(d["Vab"][0]), float(d["BasicGEP"][0]), float(d["LongGEP"][0]) - float(d["BasicGEP"][0]), float(d["diff_u"][0])) for d in ds]
     fs = batch.spscore(sps, [d["align2_skl"] for d in ds])
-    for f, d, r in zip(gold, ds, fs):
+    for f, d, r, stt in zip(gold, ds, fs, batch.last_stats):
         assert r[2] == 0 and r[0] == d["fstat_val"][0] and r[1] == d["fstat_gap"][0], (os.path.basename(f), r, float(d["fstat_val"][0]))
+        assert stt == (d["fstat_mch"][0], d["fstat_mmc"][0], d["fstat_unp"][0]), (os.path.basename(f), stt)
     batch.free()
     plain = []
     for d in ds:

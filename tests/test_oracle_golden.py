@@ -64,6 +64,9 @@ def test_oracle_spscore(L, path):
     rc, val, gap = oraclelib.spscore(L, h, sp_from_golden(d), d["align2_skl"])
     assert rc == 0
     assert val == d["fstat_val"][0] and gap == d["fstat_gap"][0]
+    # the FSTAT counters (PwdM::stt?? / the naive calcstats): matched, mismatched, unpaired member pairs
+    rc, val, gap, raw, mch, mmc, unp = oraclelib.spscore_stats(L, h, sp_from_golden(d), d["align2_skl"])
+    assert rc == 0 and (mch, mmc, unp) == (d["fstat_mch"][0], d["fstat_mmc"][0], d["fstat_unp"][0])
 
 
 def test_oracle_spscore_scope(L):
