@@ -314,7 +314,7 @@ def main():
     if world == 1 and not args.shard_of and not args.limit and not args.no_cpu:
         try:
             from prrn_aln_amd.refine import KTree, refine_native, pairsum
-            f = json.load(open(os.path.join(ROOT, "tests", "golden", "refine_prot20x100_s11.json")))
+            f = json.load(open(os.path.join(ROOT, "tests", "golden", "refine_prot48x300_s5.json")))
             t = f["tree"]
             tree = KTree(t["left"], t["right"], t["parent"], t["vol"], t["cur"])
             ralp = op.AlnParam(ls=f["ls"], molc=f["molc"], max_code=25 if f["molc"] == 1 else 17)
@@ -324,7 +324,8 @@ def main():
             final, rsteps, rstats = refine_native(ctx, start, tree, ralp, seed=1, maxitr=10, window=16)
             rt = time.perf_counter() - t1
             same = bool(np.array_equal(final, op.encode(f["final_rows"], f["molc"])))
-            refinement = {"family": "20 proteins x 100 aa (tests/golden/refine_prot20x100_s11.json: trace of the reference's Prrn::rir)",
+            refinement = {"family": "48 proteins x 300 aa, start MSA %d columns (tests/golden/refine_prot48x300_s5.json: trace of the reference's Prrn::rir; "
+                                    "the reference's own serial `prrn5 -YH0 -R1` takes about 20-40 s for it on one core)" % len(f["rows"][0]),
                           "engine": "g2g_refine (C++ behind the C ABI): windows of speculative divisions batched on the GPU, in-order acceptance",
                           "wall_ms": 1e3 * rt, "divisions_evaluated": rstats["divisions"], "accepted_moves": rstats["accepted"],
                           "gpu_batches": rstats["batches"], "divisions_recomputed": rstats["divisions_wasted"],

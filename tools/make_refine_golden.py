@@ -22,6 +22,7 @@ CASES = [
     ("prot12x80_s3", dict(n_seq=12, length=80, seed=3, indel=0.03, max_indel=6), False, []),
     ("prot20x100_s11", dict(n_seq=20, length=100, seed=11, indel=0.03, max_indel=8), False, []),
     ("dna16x120_s8_ls3", dict(n_seq=16, length=120, seed=8, indel=0.03, max_indel=8), True, ["-yl3"]),
+    ("prot48x300_s5", dict(n_seq=48, length=300, seed=5, indel=0.03, max_indel=8), False, []),      # the size INTEGRATION.md times
 ]
 
 
@@ -38,11 +39,13 @@ def parse_msa(text):
     return [rows[k].rstrip() for k in order], order
 
 
-def main():
+def main(only=None):
     import refdump
     from prrn_aln_amd.synth import DNA, make_family
     env = dict(os.environ, ALN_TAB=os.path.join(REF, "table"))
     for name, kw, dna, extra in CASES:
+        if only and name != only:
+            continue
         if dna:
             kw = dict(kw, alphabet=DNA)
         fam = make_family(**kw)
@@ -86,4 +89,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)
