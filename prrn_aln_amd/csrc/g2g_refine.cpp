@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <thread>
 #include <atomic>
+#include <chrono>
 #include "../../include/g2g.h"
 #include "g2g_internal.h"
 
@@ -241,7 +242,11 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
     if (nthr > 16) nthr = 16;
     if (nthr < 1) nthr = 1;
 
+    double t_build = 0, t_align = 0, t_sp = 0, t_rest = 0;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
     while (it < maxi && rc_all == G2G_OK) {
+        const double t0 = now();
         while ((int) pending.size() < std::min(win, maxi - it)) pending.push_back(next_branch());
         const int nw = std::min(win, (int) pending.size());
         std::vector<Division> D((size_t) nw);
@@ -281,6 +286,7 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
             build();
             for (auto &t : th) t.join();
         }
+        t_build += now() - t0;
         if (fail) { g2g_set_error("%s", "g2g_refine: building a division's groups failed"); rc_all = G2G_ERR_ARG; for (auto &d : D) free_division(d); break; }
         // ---- score: my share of the window (largest rectangles first, round-robin), then the exchange ----
         std::vector<int> live;
@@ -297,7 +303,9 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
             std::vector<double> scr((size_t) nm);
             std::vector<g2g_skl *> skl((size_t) nm, (g2g_skl *) 0);
             std::vector<int> nskl((size_t) nm), st((size_t) nm);
+            const double t1 = now();
             int rc = g2g_align2_batch(ctx, nm, pw.data(), scr.data(), skl.data(), nskl.data(), st.data());
+            t_align += now() - t1;
             if (rc == G2G_OK) {
                 std::vector<g2g_pwdm *> pw2(pw); pw2.insert(pw2.end(), pw.begin(), pw.end());
                 std::vector<const g2g_skl *> sk2((size_t) 2 * nm);
@@ -308,7 +316,9 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
                     sk2[nm + i] = skl[i]; ns2[nm + i] = nskl[i];
                 }
                 std::vector<g2g_fstat> fs((size_t) 2 * nm);
+                const double t2 = now();
                 rc = g2g_spscore_batch(ctx, 2 * nm, pw2.data(), sk2.data(), ns2.data(), fs.data());
+                t_sp += now() - t2;
                 for (int i = 0; i < nm && rc == G2G_OK; ++i) {
                     Division &d = D[live[mine[i]]];
                     if (st[i] != 0 || fs[i].status != 0 || fs[nm + i].status != 0) { rc = st[i] ? st[i] : fs[i].status ? fs[i].status : fs[nm + i].status; break; }
@@ -395,6 +405,8 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
         win = accepted ? 2 : std::min(O.window, 2 * win);
     }
     if (rc_all != G2G_OK) return rc_all;
+    t_rest = now() - t_begin - t_build - t_align - t_sp;
+    if (getenv("G2G_REFINE_TIMES")) fprintf(stderr, "[g2g_refine] %d batches: build %.0f ms, align2 %.0f ms, calcSpScore %.0f ms, rest %.0f ms\n", S.batches, t_build, t_align, t_sp, t_rest);
     S.divisions = (int) log.size();
     *out_len = M.len;
     *out_codes = (uint8_t *) malloc(M.c.size() ? M.c.size() : 1);
