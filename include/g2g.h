@@ -230,7 +230,11 @@ typedef struct {
     double diffu;        /* PwdB::diffu = LongGEP - BasicGEP (src/aln2.cc:105)                      */
     double diff_u;       /* PwdM::diff_u = scale * (u - u1) (src/maln2.cc:233): weight of the long-gap count `lunp` in
                             PwdM::wgop (maln.h:321-325); only read when Noll = 3                                */
+    int32_t flags;       /* G2G_SP_NOSTATS: leave FSTAT's mch / mmc / unp at 0 (the statistics cost about a third of the walk;
+                            a refinement loop reads val and raw only)                                               */
+    int32_t reserved;
 } g2g_spparams;
+#define G2G_SP_NOSTATS 1
 typedef struct {
     double  val, gap;    /* FSTAT::val / gap after PwdM::rescale: per unit pair weight (what align2 leaves in Gsinfo.fstat)      */
     int32_t status, reserved;
@@ -247,6 +251,8 @@ int        g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g_skl
 int        g2g_pwdm_spparams(const g2g_pwdm *p, g2g_spparams *sp);
 int        g2g_spscore_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *p, const g2g_skl *const *skl, const int *nskl,
                              g2g_fstat *out);
+int        g2g_spscore_batch_flags(g2g_ctx *ctx, int n, g2g_pwdm *const *p, const g2g_skl *const *skl, const int *nskl,
+                                   int flags, g2g_fstat *out);       /* the same with g2g_spparams::flags set for every item */
 int        g2g_align2(g2g_ctx *ctx, g2g_pwdm *p, double *scr, g2g_skl **skl, int *nskl);
 /* <-> VTYPE HomScore(mSeq* seqs[], PwdM* pwdm, long rr[]) (src/maln2.cc:1837): score only; rr may be NULL. */
 int        g2g_homscore(g2g_ctx *ctx, g2g_pwdm *p, double *scr, int64_t rr[2]);

@@ -169,7 +169,8 @@ def problem_from_arrays(d: Dict[str, np.ndarray]) -> ProblemHolder:
 
 
 class SpParams(C.Structure):
-    _fields_ = [("vab", C.c_double), ("basic_gep", C.c_double), ("diffu", C.c_double), ("diff_u", C.c_double)]
+    _fields_ = [("vab", C.c_double), ("basic_gep", C.c_double), ("diffu", C.c_double), ("diff_u", C.c_double),
+                ("flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Fstat(C.Structure):

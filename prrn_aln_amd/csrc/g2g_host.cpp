@@ -650,13 +650,18 @@ extern "C" int g2g_pwdm_spparams(const g2g_pwdm *p, g2g_spparams *sp)
     return G2G_OK;
 }
 // <-> PreSpScore::calcSpScore(Gsinfo*) for every (PwdM, skeleton) pair, src/fspscore.cc:584-622
+extern "C" int g2g_spscore_batch_flags(g2g_ctx *ctx, int n, g2g_pwdm *const *p, const g2g_skl *const *skl, const int *nskl, int flags, g2g_fstat *out);
 extern "C" int g2g_spscore_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *p, const g2g_skl *const *skl, const int *nskl, g2g_fstat *out)
+{
+    return g2g_spscore_batch_flags(ctx, n, p, skl, nskl, 0, out);
+}
+extern "C" int g2g_spscore_batch_flags(g2g_ctx *ctx, int n, g2g_pwdm *const *p, const g2g_skl *const *skl, const int *nskl, int flags, g2g_fstat *out)
 {
     if (!ctx || n < 0 || (n && (!p || !skl || !nskl || !out))) return G2G_ERR_ARG;
     if (n == 0) return G2G_OK;
     std::vector<const g2g_problem *> pp(n);
     std::vector<g2g_spparams> sp(n);
-    for (int i = 0; i < n; ++i) { if (!p[i]) return G2G_ERR_ARG; pp[i] = &p[i]->prob; sp[i] = p[i]->sp; }
+    for (int i = 0; i < n; ++i) { if (!p[i]) return G2G_ERR_ARG; pp[i] = &p[i]->prob; sp[i] = p[i]->sp; sp[i].flags = flags; }
     g2g_batch *b = 0;
     int rc = g2g_batch_prepare(ctx, n, pp.data(), &b);
     if (rc) return rc;

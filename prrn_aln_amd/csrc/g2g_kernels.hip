@@ -687,7 +687,7 @@ extern "C" __global__ void __launch_bounds__(64) g2g_traceback_kernel(const DevP
 // PwdM::wgop + PwdM::rescale (maln.h:321-325, maln2.cc:245-252).  A dependent chain per alignment (every column
 // updates the dynamic gap lists the next one reads): one wave per alignment, lane 0 walks; alignments run in parallel.
 // The lists live in the first slot of the v1 state arrays of the problem (free once the forward sweep is over).
-struct SpParamsDev { double vab, basic_gep, diffu, diff_u; };      // = g2g_spparams
+struct SpParamsDev { double vab, basic_gep, diffu, diff_u; int flags, reserved; };      // = g2g_spparams
 // Gep1st (reference src/mseq.h:355-373, src/mseq.cc:658-758): per member a ring of the last k1 positions that held a
 // residue; counts the "long" part of unpaired runs (`lunp`) when Noll = 3.  Rings live in a zeroed workspace in HBM
 // ((many) x (k1 + 1) ints per side).  The whole wave executes the chain in lockstep (every lane replays the scalar part:
@@ -755,6 +755,21 @@ __device__ double gep_longup_both(const GepDev &g, const SList df, const DList d
     gep_shift(g, res, pos);
     return lunp;
 }
+// The static lists of the current columns, staged in LDS by the whole wave (one parallel load round) before the merges walk them
+// entry by entry: a dependent global load per entry made the chain of a _pf alignment cost ~16 us per column.
+#define SP_STAGE 64
+struct SpStage { int *gl; double *fq; };                          // 6 slots x SP_STAGE entries in LDS (NULL: read the lists in place)
+__device__ __forceinline__ SList sp_staged(const SpStage &G, const DevSide &sd, const int view, const int pos, const int slot)
+{
+    const int o = sd.off[view][pos + 1], len = sd.off[view][pos + 2] - o;       // entries incl. the terminator
+    SList l; l.glen = sd.glen[view] + o; l.freq = sd.freq[view] + o;
+    if (!G.gl || len > SP_STAGE) return l;
+    int *dg = G.gl + slot * SP_STAGE; double *df = G.fq + slot * SP_STAGE;
+    for (int k = threadIdx.x & 63; k < len; k += 64) { dg[k] = l.glen[k]; df[k] = l.freq[k]; }
+    l.glen = dg; l.freq = df;
+    return l;
+}
+__device__ __forceinline__ void sp_stage_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 // ---- PwdM::stt?? (src/maln2.cc:627-850, 1300-1450): matched / mismatched / unpaired member pairs of a column pair -> FSTAT.
 // ha / hb false: the "zero" iterator of a gap segment (res = vss = NULL, thickness {sumwt, 0, sumwt}).  Every lane replays it.
 struct SpStat { double mch, mmc, unp; };
@@ -907,12 +922,12 @@ __device__ void sp_stt2(const DevProb &P, const int apos, const int bpos, const 
 template <int KIND>
 __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int ni, int &apos, int &bpos, int &glb,
                           const DList dla, const DList dlb, double &scr, double &tgap,
-                          const bool gep, const GepDev &agep, const GepDev &bgep, double &lunp, SpStat &St)
+                          const bool gep, const GepDev &agep, const GepDev &bgep, double &lunp, SpStat &St, const SpStage &G)
 {
     const DevSide &a = P.a, &b = P.b;
     if (KIND == 0) {
         if (mi == ni) {
-            while (mi--) { ++apos; ++bpos; scr += sim2(P, apos, bpos); sp_stt2(P, apos, bpos, true, true, St); }
+            while (mi--) { ++apos; ++bpos; scr += sim2(P, apos, bpos); if (!(sp.flags & 1)) sp_stt2(P, apos, bpos, true, true, St); }
         } else if (mi) {
             St.unp += mi;
             const double efq = thk_at(b, bpos)[2];
@@ -934,67 +949,88 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
         if (mi == ni) {
             while (mi--) {
                 ++apos; ++bpos;
+                const SList at = sp_staged(G, a, 1, apos, 1);
+                sp_stage_sync();
                 scr += sim2(P, apos, bpos);
-                tgap += newgap_di(gfq_at(a, 1, apos), glb, dla);
-                sp_stt2(P, apos, bpos, true, true, St);
-                newdelta(dla, gfq_at(a, 1, apos), dla);
-                if (gep) { lunp += gep_longup_half(bgep, gfq_at(a, 1, apos), dla, bpos); gep_shift(agep, res_at(a, apos), apos); }
+                tgap += newgap_di(at, glb, dla);
+                if (!(sp.flags & 1)) sp_stt2(P, apos, bpos, true, true, St);
+                newdelta(dla, at, dla);
+                if (gep) { lunp += gep_longup_half(bgep, at, dla, bpos); gep_shift(agep, res_at(a, apos), apos); }
                 glb = 0;
+                sp_stage_sync();
             }
         } else if (mi) {
             while (mi--) {
                 ++apos;
+                const SList as = sp_staged(G, a, 0, apos, 0), at = sp_staged(G, a, 1, apos, 1);
+                sp_stage_sync();
                 scr += unpa(P, apos, bpos);
-                tgap += newgap_cj(gfq_at(a, 0, apos), dla, glb);
-                sp_stt2(P, apos, bpos, true, false, St);
-                newdelta(dla, gfq_at(a, 1, apos), dla);
+                tgap += newgap_cj(as, dla, glb);
+                if (!(sp.flags & 1)) sp_stt2(P, apos, bpos, true, false, St);
+                newdelta(dla, at, dla);
                 ++glb;
                 if (gep) lunp += gep_longup_res(agep, res_at(a, apos), apos, glb, true);
+                sp_stage_sync();
             }
         } else if (ni) {
+            const SList ar = sp_staged(G, a, 2, apos, 2);      // (apos does not move in this segment)
+            sp_stage_sync();
             while (ni--) {
                 ++bpos;
                 scr += unpb(P, bpos, apos);
-                tgap += newgap_di(gfq_at(a, 2, apos), glb, dla);
-                sp_stt2(P, apos, bpos, false, true, St);
+                tgap += newgap_di(ar, glb, dla);
+                if (!(sp.flags & 1)) sp_stt2(P, apos, bpos, false, true, St);
                 incdelta2(dla, dla);
-                if (gep) lunp += gep_longup_half(bgep, gfq_at(a, 2, apos), dla, bpos);
+                if (gep) lunp += gep_longup_half(bgep, ar, dla, bpos);
             }
+            sp_stage_sync();
         }
     } else {
         if (mi == ni) {
             while (mi--) {
                 ++apos; ++bpos;
+                const SList as = sp_staged(G, a, 0, apos, 0), at = sp_staged(G, a, 1, apos, 1);
+                const SList bs = sp_staged(G, b, 0, bpos, 3), bt = sp_staged(G, b, 1, bpos, 4);
+                sp_stage_sync();
                 scr += sim2(P, apos, bpos);
-                tgap += newgap4(gfq_at(a, 0, apos), dla, gfq_at(b, 1, bpos), dlb)
-                      + newgap4(gfq_at(b, 0, bpos), dlb, gfq_at(a, 1, apos), dla);
-                sp_stt2(P, apos, bpos, true, true, St);
-                newdelta(dla, gfq_at(a, 1, apos), dla);
-                newdelta(dlb, gfq_at(b, 1, bpos), dlb);
+                tgap += newgap4(as, dla, bt, dlb)
+                      + newgap4(bs, dlb, at, dla);
+                if (!(sp.flags & 1)) sp_stt2(P, apos, bpos, true, true, St);
+                newdelta(dla, at, dla);
+                newdelta(dlb, bt, dlb);
                 if (gep) {
-                    lunp += gep_longup_both(agep, gfq_at(b, 1, bpos), dlb, res_at(a, apos), apos);
-                    lunp += gep_longup_both(bgep, gfq_at(a, 1, apos), dla, res_at(b, bpos), bpos);
+                    lunp += gep_longup_both(agep, bt, dlb, res_at(a, apos), apos);
+                    lunp += gep_longup_both(bgep, at, dla, res_at(b, bpos), bpos);
                 }
+                sp_stage_sync();
             }
         } else if (mi) {
+            const SList br = sp_staged(G, b, 2, bpos, 5);      // (bpos does not move in this segment)
             while (mi--) {
                 ++apos;
+                const SList as = sp_staged(G, a, 0, apos, 0), at = sp_staged(G, a, 1, apos, 1);
+                sp_stage_sync();
                 scr += unpa(P, apos, bpos);
-                tgap += newgap4(gfq_at(a, 0, apos), dla, gfq_at(b, 2, bpos), dlb);
-                sp_stt2(P, apos, bpos, true, false, St);
-                newdelta(dla, gfq_at(a, 1, apos), dla);
+                tgap += newgap4(as, dla, br, dlb);
+                if (!(sp.flags & 1)) sp_stt2(P, apos, bpos, true, false, St);
+                newdelta(dla, at, dla);
                 incdelta2(dlb, dlb);
-                if (gep) lunp += gep_longup_both(agep, gfq_at(b, 2, bpos), dlb, res_at(a, apos), apos);
+                if (gep) lunp += gep_longup_both(agep, br, dlb, res_at(a, apos), apos);
+                sp_stage_sync();
             }
         } else if (ni) {
+            const SList ar = sp_staged(G, a, 2, apos, 2);
             while (ni--) {
                 ++bpos;
+                const SList bs = sp_staged(G, b, 0, bpos, 3), bt = sp_staged(G, b, 1, bpos, 4);
+                sp_stage_sync();
                 scr += unpb(P, bpos, apos);
-                tgap += newgap4(gfq_at(b, 0, bpos), dlb, gfq_at(a, 2, apos), dla);
-                sp_stt2(P, apos, bpos, false, true, St);
-                newdelta(dlb, gfq_at(b, 1, bpos), dlb);
+                tgap += newgap4(bs, dlb, ar, dla);
+                if (!(sp.flags & 1)) sp_stt2(P, apos, bpos, false, true, St);
+                newdelta(dlb, bt, dlb);
                 incdelta2(dla, dla);
-                if (gep) lunp += gep_longup_both(bgep, gfq_at(a, 2, apos), dla, res_at(b, bpos), bpos);
+                if (gep) lunp += gep_longup_both(bgep, ar, dla, res_at(b, bpos), bpos);
+                sp_stage_sync();
             }
         }
     }
@@ -1228,8 +1264,9 @@ __device__ double ii_store(IiDev &I, int m, int n)
     }
     return I.spb * scr;
 }
+#define SP_FAST_LIST 192
 template <int KIND>
-__device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *skl, int nskl, double *out, int *gepws)
+__device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *skl, int nskl, double *out, int *gepws, int2 *fast_lists, const SpStage &G)
 {
     // Gep1st of both sides (fspscore.h:146-147: alprm.ls > 2); the workspace arrives zeroed
     const bool gep = KIND >= 1 && P.noll == 3 && gepws != 0;
@@ -1250,6 +1287,9 @@ __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *
     double lunp = 0;
     DList dla, dlb;
     dla.p = P.dla[XH]; dla.s = P.spw; dlb.p = P.dlb[XH]; dlb.s = P.spw;
+    // the two running lists are touched several times per column by a dependent chain: in LDS (the kernel's 2 x SP_FAST_LIST
+    // entries) when they fit -- a global round trip per access made a _pf alignment cost 17 us per column
+    if (fast_lists && P.capa + 1 <= SP_FAST_LIST && P.capb + 1 <= SP_FAST_LIST) { dla.p = fast_lists; dla.s = 1; dlb.p = fast_lists + SP_FAST_LIST; dlb.s = 1; }
     if (KIND == 1 || KIND == 2) cleardelta(dla);
     if (KIND == 2) cleardelta(dlb);
     int m = skl[0].x, n = skl[0].y, glb = 0;
@@ -1262,7 +1302,7 @@ __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *
         const int mi = skl[k].x - m, ni = skl[k].y - n, i = mi - ni;
         auto run = [&](int mi_, int ni_) {
             if (KIND == 3) sp_calscr_ntv(P, N, mi_, ni_, apos, bpos, scr, tgap, gep, agep, bgep, lunp, St);
-            else sp_calscr<(KIND == 3 ? 0 : KIND)>(P, sp, mi_, ni_, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp, St);
+            else sp_calscr<(KIND == 3 ? 0 : KIND)>(P, sp, mi_, ni_, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp, St, G);
         };
         if (!i || !mi || !ni) run(mi, ni);
         else if (i > 0) { run(ni, ni); run(i, 0); }
@@ -1299,9 +1339,14 @@ g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const
     if (P.kind == 3 && (!P.a.gapdens || !P.b.gapdens)) { status[ip] = -1; return; }
     if (nskl[ip] < 2) { status[ip] = -1; return; }
     const int2 *s = skl + skl_off[ip];
-    if (P.kind == 0) sp_calcskl<0>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws);
-    else if (P.kind == 1) sp_calcskl<1>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws);
-    else if (P.kind == 2) sp_calcskl<2>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws);
-    else sp_calcskl<3>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws);
+    __shared__ int2 sp_lists[2 * SP_FAST_LIST];
+    __shared__ int sp_sgl[6 * SP_STAGE];
+    __shared__ double sp_sfq[6 * SP_STAGE];
+    int2 *fl = (int2 *) sp_lists;
+    SpStage G; G.gl = (int *) sp_sgl; G.fq = (double *) sp_sfq;
+    if (P.kind == 0) sp_calcskl<0>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G);
+    else if (P.kind == 1) sp_calcskl<1>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G);
+    else if (P.kind == 2) sp_calcskl<2>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G);
+    else sp_calcskl<3>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G);
     status[ip] = 0;
 }

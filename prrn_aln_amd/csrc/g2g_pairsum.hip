@@ -243,7 +243,7 @@ extern "C" int g2g_pairsum(g2g_ctx *ctx, const g2g_params *prm, int many, int le
             std::vector<g2g_fstat> fs((size_t) nj);
             for (int k = 0; k < nj; ++k) {
                 g2g_pwdm_spparams(pw[k], &sp[k]);
-                sp[k].diff_u = 0;
+                sp[k].diff_u = 0; sp[k].flags = G2G_SP_NOSTATS;
                 sk[2 * k].m = probs[k]->a.left; sk[2 * k].n = probs[k]->b.left;
                 sk[2 * k + 1].m = probs[k]->a.right; sk[2 * k + 1].n = probs[k]->b.right;
                 skp[k] = &sk[2 * k];

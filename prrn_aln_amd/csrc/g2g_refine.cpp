@@ -317,7 +317,7 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
                 }
                 std::vector<g2g_fstat> fs((size_t) 2 * nm);
                 const double t2 = now();
-                rc = g2g_spscore_batch(ctx, 2 * nm, pw2.data(), sk2.data(), ns2.data(), fs.data());
+                rc = g2g_spscore_batch_flags(ctx, 2 * nm, pw2.data(), sk2.data(), ns2.data(), G2G_SP_NOSTATS, fs.data());
                 t_sp += now() - t2;
                 for (int i = 0; i < nm && rc == G2G_OK; ++i) {
                     Division &d = D[live[mine[i]]];
