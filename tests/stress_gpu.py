@@ -14,7 +14,7 @@ ctx=engine.Context(); L=oraclelib.load()
 rng=random.Random(int(sys.argv[1]) if len(sys.argv)>1 else 7)
 tot=0; bad=0; t0=time.time()
 for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 14):
-    n=rng.choice([6,9,14,20,33,48,64]); ln=rng.choice([60,120,250,420]); ind=rng.choice([0.005,0.02,0.05,0.09]); mi=rng.choice([3,8,20,45])
+    n=rng.choice([2,3,4,5,6,9,14,20,33,48,64]); ln=rng.choice([60,120,250,420]); ind=rng.choice([0.005,0.02,0.05,0.09]); mi=rng.choice([3,8,20,45])
     dna=rng.random()<0.3; ls=rng.choice([1,1,3]); tg=rng.choice([1.0,1.0,0.5])
     kw=dict(n_seq=n,length=ln,seed=rng.randrange(10**6),indel=ind,max_indel=mi)
     if dna: kw['alphabet']=DNA
@@ -23,15 +23,17 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 14):
     akw=dict(ls=ls,tgapf=tg)
     if dna: akw.update(molc=op.DNA,max_code=17)
     sw=sweep.Sweep(fam, op.AlnParam(**akw), weighted=rng.random()<0.7)
+    ctx.reset_options()
+    if it % 2: ctx.set_option("V6_MIN_STRIPS", 0)                           # every other family: v6 for _pf whatever the batch size
     res=op.align2_batch(ctx, sw.pwds)
-    fs=op.calcSpScore_batch(ctx, sw.pwds, [skl for (_,skl,_) in res])      # f1: sum-of-pairs score along the new path
+    fs=op.calcSpScore_batch(ctx, sw.pwds, [skl for (_,skl,_) in res], stats=True)      # f1: sum-of-pairs score + FSTAT counters along the new path
     modes=set()
-    for pw,(scr,skl,st),(val,gap,fst) in zip(sw.pwds,res,fs):
+    for pw,(scr,skl,st),(val,gap,fst,raw,mch,mmc,unp) in zip(sw.pwds,res,fs):
         class H: c=pw.problem
         oscr,oc,otr=oraclelib.forward(L,H)
         ok = st==0 and scr==oscr and np.array_equal(skl, oraclelib.stdskl(L,otr))
-        rc,oval,ogap=oraclelib.spscore(L,H,op.spparams(pw),skl)
-        ok = ok and ((fst==0)==(rc==0)) and (rc!=0 or (val==oval and gap==ogap))
+        rc,oval,ogap,oraw,omch,ommc,ounp=oraclelib.spscore_stats(L,H,op.spparams(pw),skl)
+        ok = ok and ((fst==0)==(rc==0)) and (rc!=0 or (val==oval and gap==ogap and raw==oraw and (mch,mmc,unp)==(omch,ommc,ounp)))
         tot+=1; bad+= (not ok); modes.add((pw.alnmode,pw.problem.noll))
         if not ok: print('MISMATCH', kw, akw, pw.alnmode, st, scr, oscr, fst, rc, val, oval)
     print(it, kw, akw, 'divisions', len(sw.pwds), 'modes', sorted(modes), 'bad so far', bad, flush=True)
