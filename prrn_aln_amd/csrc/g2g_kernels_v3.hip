@@ -779,7 +779,13 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
     const bool own_sim = prog_self != 0 && simscr != 0;    // sweep mode: the strip makes its column scores block by block
     const double *simrow = (row_ok && !own_sim) ? P.v2_sim + P.v2_rowoff[m - a.left] - nlo : 0;
     SimBlk SB; SB.buf = (GLBV3 double *) simscr; SB.cbase = cbase;
-    if (own_sim) { simblk_fill(P, SB, 0, m0, lane); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    // sim31 (a profile row against ONE residue of b, maln.h:168): the score of a cell is a single entry of the row's profile,
+    // picked by b's residue -- read it where it is (the row's 200 bytes stay in cache along the row) instead of writing a block
+    // of scores to scratch and reading it back (16 bytes of fabric traffic per cell)
+    const bool sim_direct = own_sim && P.sim2_kind == 31 && b.many == 1 && a.pseq != 0;
+    const double *sim_arow = (sim_direct && row_ok) ? vss_at(a, m) + a.felm : 0;
+    const uint8_t *sim_bres = b.seq + 1;                   // residue of column n at sim_bres[n]
+    if (own_sim && !sim_direct) { simblk_fill(P, SB, 0, m0, lane); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     double sim_cur = 0, bc_cur = 0;
     bool have = false;
     RS hu = rs_black(), gu = rs_black(), g2u = rs_black(), hd;
@@ -827,7 +833,7 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
         if (p_act) P.trace[p_tri] = (uint8_t) p_trb;
         if (wr_rows && s > 0) flush_rows(n0 - 1 - llast);
         if (prog_self && s > 0 && (s & (pint - 1)) == 0) publish(n0 - llast);
-        if (own_sim && (s & 63) == 0) { simblk_fill(P, SB, (s >> 6) + 1, m0, lane); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if (own_sim && !sim_direct && (s & 63) == 0) { simblk_fill(P, SB, (s >> 6) + 1, m0, lane); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         // -- hand-over from the row above: what lane t-1 produced one step ago is my upper neighbour, what it
         // produced two steps ago (= my previous upper neighbour) is my diagonal neighbour
         hd = hu;
@@ -852,8 +858,8 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
         // -- loads for the next step: next column's score/thickness; the strip above's records two columns ahead
         double sim_nx = 0, bc_nx = 0;
         if (active) {
-            if (!have) { sim_cur = own_sim ? (double) *simblk_at(SB, lane, n) : simrow[n]; bc_cur = thk_at(b, n)[0]; }
-            if (n + 1 < hi) { sim_nx = own_sim ? (double) *simblk_at(SB, lane, n + 1) : simrow[n + 1]; bc_nx = thk_at(b, n + 1)[0]; }
+            if (!have) { sim_cur = sim_direct ? sim_arow[sim_bres[n]] : own_sim ? (double) *simblk_at(SB, lane, n) : simrow[n]; bc_cur = thk_at(b, n)[0]; }
+            if (n + 1 < hi) { sim_nx = sim_direct ? sim_arow[sim_bres[n + 1]] : own_sim ? (double) *simblk_at(SB, lane, n + 1) : simrow[n + 1]; bc_nx = thk_at(b, n + 1)[0]; }
         }
         st_prev = n0 + 1 < hi0 && n0 + 2 <= c1;
         if (st_prev) { need(n0 + 2); stage_load(n0 + 2, vert0, st_h, st_g, st_g2); }
