@@ -389,6 +389,10 @@ def main():
                                       sum(1 for p in sw.pwds if p.alnmode == 9), total_cells),
                        "divisions": len(sw), "cells_per_step": total_cells, "parallelism": "divisions round-robin by size over %d GPU(s)" % world,
                        "failed_items": bad, "align2_batch_from_host_ms": e2e_ms,
+                       # checksum of the last timed step's results (this rank's divisions): the same workload must give the same
+                       # two numbers in every run, with or without a recovered time-out in it
+                       "score_sum": float(sum(scr for (scr, _, st) in out if st == 0)),
+                       "skeleton_corners": int(sum(len(skl) for (_, skl, st) in out if st == 0)),
                        "arena_bytes_per_cell": (batch.arena_bytes() / my_cells) if (batch is not None and my_cells) else None},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

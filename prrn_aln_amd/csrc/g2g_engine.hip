@@ -253,13 +253,14 @@ struct g2g_batch {
     float fwd_ms, tb_ms;
     double *simscr[24]; size_t simscr_cap[24];
     bool v6_on;                     // this batch is large enough for v6 (else its _pf DPs go to v2: shorter critical path)
-    int hdr_img[G2G_HDR + 4];       // host image of the queue heads + wait header of the current run
+    int hdr_img[G2G_HDR + G2G_HDRN];       // host image of the queue heads + wait header of the current run
     std::vector<const g2g_problem *> src;        // the caller's problems (kept alive by the caller until the batch is freed): a DP
                                                  // that lost a wait is re-run from here on the non-polling kernel
     int fail_off;                                // offset of the per-DP fail flags in d_flags
     int n_recovered;                             // DPs re-run after a time-out, over the life of the batch
     std::vector<g2g_result> recovered;           // results of re-run DPs (trace owned by the batch until fetched)
     std::vector<char> was_recovered;
+    bool is_retry;                               // a batch of DPs that lost a wait, re-run on the ordinary kernels; ITS time-outs go to v1
     bool force_v1;                               // recovery batches: everything on g2g_forward_kernel   // per sweep-mode launch: strip-local column-score blocks (3 x 32 KB per workgroup)
 };
 
@@ -551,7 +552,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
     g2g_batch *b = new g2g_batch();
     b->ctx = ctx; b->n = n; b->d_arena = 0; b->d_probs = 0; b->fwd_ms = b->tb_ms = 0;
     for (int k = 0; k < 24; ++k) { b->simscr[k] = 0; b->simscr_cap[k] = 0; }
-    b->src.assign(prob, prob + n); b->fail_off = 0; b->force_v1 = force_v1; b->n_recovered = 0;
+    b->src.assign(prob, prob + n); b->fail_off = 0; b->force_v1 = force_v1; b->is_retry = false; b->n_recovered = 0;
     b->recovered.assign(n, g2g_result()); b->was_recovered.assign(n, 0);
     b->v3_cols = 128; b->v2_cols = G2G_V2_TILE_COLS;
 
@@ -811,7 +812,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
     b->d_tiles = 0; b->d_idxp = 0; b->np = 0; b->ntiles = 0; b->lds2p = 0; b->v2_maxrows = 1; b->v2_maxcols = 1; b->simtile_lds = 0; b->d_flags = 0; b->nflags = 0; b->gen = 0;
     {
         std::vector<std::vector<std::vector<V2Tile> > > q(G2G_HDR);   // [variant][wavefront] -> tiles
-        std::vector<int> flags(G2G_HDR + 4, 0);           // queue heads, then the header of the waits (g2g_wait_ge)
+        std::vector<int> flags(G2G_HDR + G2G_HDRN, 0);           // queue heads, then the header of the waits (g2g_wait_ge)
         std::vector<V2Tile> pre[G2G_HDR];                 // boundary chains of sweep-mode DPs: they head their variant's queue
         std::vector<int> ip;                              // the other DPs: chains in the prologue kernel
         const bool chainq = !g2g_opt(ctx, "NO_CHAINQ");
@@ -991,8 +992,8 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             int *hdr = b->hdr_img;
             memset(hdr, 0, sizeof b->hdr_img);
             // a legitimate wait lasts as long as the strip above needs for one publish interval, or a boundary chain for its
-            // sequential walk: milliseconds.  3 s of wall clock means the producer is not running.
-            double limit_ms = 3000.;
+            // sequential walk: milliseconds.  One second of wall clock means the producer is not running.
+            double limit_ms = 1000.;
             if (const char *e = g2g_opt(ctx, "WAIT_LIMIT_MS")) { const double v = atof(e); if (v > 0) limit_ms = v; }
             hdr[G2G_HDR + 2] = b->fail_off;
             hdr[G2G_HDR + 3] = (int) std::min(2.0e9, limit_ms * ctx->rt_ticks_per_ms / 65536.) + 1;
@@ -1131,7 +1132,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (b->d_flags) {
-        int rep[G2G_HDR + 4];
+        int rep[G2G_HDR + G2G_HDRN];
         HIPCHK(hipMemcpy(rep, b->d_flags, sizeof rep, hipMemcpyDeviceToHost));
         if (rep[G2G_HDR]) {
             // Some wait ran into the wall-clock limit.  Only the DPs marked in the fail array are lost; they are re-run here, in
@@ -1142,16 +1143,25 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             for (int i = 0; i < b->n; ++i) if (fail[i] && !b->status[i]) lost.push_back(i);
             if (g2g_opt(ctx, "DEBUG") || g2g_opt(ctx, "WARN")) {
                 fprintf(stderr, "[g2g] s_memrealtime: %.0f ticks/ms; ", ctx->rt_ticks_per_ms);
-                fprintf(stderr, "[g2g] %d waits timed out (first: queue slot %d, gen %d): re-running %zu DP(s) on g2g_forward_kernel:", rep[G2G_HDR], rep[G2G_HDR + 1], b->gen, lost.size());
+                fprintf(stderr, "[g2g] %d waits timed out (first: queue slot %d, gen %d): re-running %zu DP(s) %s:", rep[G2G_HDR], rep[G2G_HDR + 1], b->gen, lost.size(), b->is_retry ? "on g2g_forward_kernel" : "(first on the ordinary kernels)");
                 for (size_t k = 0; k < lost.size() && k < 12; ++k) fprintf(stderr, " %d(kernel %d, %d x %d)", lost[k], b->dp[lost[k]].v2_ok, b->dp[lost[k]].a.right - b->dp[lost[k]].a.left, b->dp[lost[k]].b.right - b->dp[lost[k]].b.left);
+                fprintf(stderr, "\n");
+                const int *x = rep + G2G_HDR;                 // the first time-out's snapshot (g2g_wait_ge)
+                fprintf(stderr, "[g2g] first time-out: DP %d, wanted gen %d col %d of word %d, saw gen %d col %d; the words at and below it (gen:col):",
+                        x[7] - b->fail_off, (x[4] >> 20) & 0x7FF, x[4] & 0xFFFFF, x[6], (x[5] >> 20) & 0x7FF, x[5] & 0xFFFFF);
+                for (int k = 0; k < 8; ++k) fprintf(stderr, " %d:%d", (x[8 + k] >> 20) & 0x7FF, x[8 + k] & 0xFFFFF);
+                fprintf(stderr, "; by RMW %d:%d, loaded again %d:%d", (x[46] >> 20) & 0x7FF, x[46] & 0xFFFFF, (x[47] >> 20) & 0x7FF, x[47] & 0xFFFFF);
                 fprintf(stderr, "\n"); fflush(stderr);
             }
             if (b->force_v1 || lost.empty()) { g2g_set_error("%s", "scheduler: a wait timed out and no DP could be singled out"); return G2G_ERR_DEVICE; }
             std::vector<const g2g_problem *> pp;
             for (int i : lost) pp.push_back(b->src[i]);
             g2g_batch *rb = 0;
-            int rc = batch_prepare_impl(ctx, (int) pp.size(), pp.data(), &rb, true);
+            // a time-out is a rare accident of scheduling, not a property of the DP: the lost DPs first run again on the ordinary
+            // kernels (a small batch: tens of ms); only if THAT run loses a wait too do its DPs go to v1, which polls nothing
+            int rc = batch_prepare_impl(ctx, (int) pp.size(), pp.data(), &rb, b->is_retry);
             if (!rc) {
+                rb->is_retry = true;
                 rc = g2g_batch_run(rb);
                 std::vector<g2g_result> rr(pp.size());
                 if (!rc) rc = g2g_batch_fetch(rb, rr.data());

@@ -38,22 +38,37 @@ __device__ unsigned long long g2g_stamp_acc[16];
 // batch's fail array, every other wait of that DP gives up at its next check, its remaining strips are skipped, and
 // g2g_batch_run re-runs the marked DPs on the non-polling kernel (g2g_forward_kernel).  hdr = done + G2G_HDR:
 // [0] time-outs, [1] queue slot of the first, [2] offset of the fail array from `done`, [3] the limit.
-#define G2G_HDR 24                   // d_flags: [0, 24) queue heads of the kernel variants, [24, 28) this header, tile flags behind
+#define G2G_HDR 24                   // d_flags: [0, 24) queue heads of the kernel variants, [24, 28) this header, [28, 72) snapshot of the first time-out, tile flags behind
+#define G2G_HDRN 48                  // header words: 4 + the snapshot (want, seen, offset of the polled word, the 40 words at and below it)
 __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hdr, int *failp, const int slot)
 {
     int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v >= want) return v;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (unsigned it = 1; ; ++it) {
-        __builtin_amdgcn_s_sleep(8);
+        // back off: the first polls come 0.2 us apart, later ones 2-3 us with a phase that differs from wave to wave.  A standing,
+        // strictly periodic stream of reads of one word was seen to hold up the STORE to that word (the producer's
+        // next publish never became visible, by load or by read-modify-write, until the readers gave up -- and then at once).
+        const unsigned nap = it < 16 ? 1 : it < 64 ? 2 + (it & 1) : 8 + ((it * 5 + (unsigned) slot) & 7);
+        for (unsigned j = 0; j < nap; ++j) __builtin_amdgcn_s_sleep(8);
         v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v >= want) return v;
-        if ((it & 255) == 0) {
+        if ((it & 63) == 0) {
+            // drop this XCD's copy of the polled line (buffer_inv sc1): see DESIGN.md 4.2 -- a producer's store to a word was seen to
+            // stay pending for as long as a reader kept re-reading that word, and to complete the moment the reader went away
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (__hip_atomic_load(failp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 0x7fffffff;      // this DP is lost already
             const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
             if ((dt >> 16) > (unsigned long long) (unsigned) __hip_atomic_load(hdr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 __hip_atomic_store(failp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (atomicAdd(hdr, 1) == 0) hdr[1] = slot;
+                if (atomicAdd(hdr, 1) == 0) {             // the first one leaves a snapshot for the host's report
+                    hdr[1] = slot; hdr[4] = want; hdr[5] = v;
+                    const int off = (int) (p - (hdr - G2G_HDR));
+                    hdr[6] = off; hdr[7] = (int) (failp - (hdr - G2G_HDR));
+                    for (int k = 0; k < 38 && off - k >= G2G_HDR + G2G_HDRN; ++k) hdr[8 + k] = __hip_atomic_load(p - k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hdr[8 + 38] = atomicAdd((int *) p, 0);          // the same word through a read-modify-write (executes at the coherent point)
+                    hdr[8 + 39] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 return 0x7fffffff;
             }
         }
