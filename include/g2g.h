@@ -168,7 +168,9 @@ int      g2g_forward_batch(g2g_ctx *ctx, int n, const g2g_problem *const *prob, 
 
 /* The same in three steps, for callers that keep a sweep resident in HBM (bench.py times g2g_batch_run
    only: inputs are already in device memory when it starts).  g2g_batch_times() reports the HIP-event
-   durations of the forward and backtrack kernels of the last run, measured on the context's stream. */
+   durations of the forward and backtrack kernels of the last run, measured on the context's stream.
+   The problem descriptions (and every array they point to) must stay valid until g2g_batch_free: a DP that loses
+   a scheduler wait is packed again from them and re-run inside g2g_batch_run. */
 typedef struct g2g_batch g2g_batch;
 int       g2g_batch_prepare(g2g_ctx *ctx, int n, const g2g_problem *const *prob, g2g_batch **out);
 int       g2g_batch_run(g2g_batch *b);

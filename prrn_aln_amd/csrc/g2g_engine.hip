@@ -856,15 +856,15 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
             const bool cq = (chainq && (swp2 || swp3)) || d.v2_ok >= 7;      // (v7's and v8's chains always run as queue entries: the prologue kernel knows the gap-profile kinds only)
             int ftop = -1, fleft = -1;
             if (cq) {
-                ftop = (int) flags.size(); fleft = ftop + 1;
-                flags.push_back(0); flags.push_back(0);
+                ftop = (int) flags.size(); fleft = ftop + G2G_FSTRIDE;
+                flags.resize(flags.size() + 2 * G2G_FSTRIDE, 0);
                 V2Tile T;
                 T.prob = i; T.tj = 0; T.nsteps = 0; T.dep_up = T.dep_left = T.dep_diag = T.dep_war = -1;
                 T.ti = -1; T.self = ftop; pre[var].push_back(T);
                 T.ti = -2; T.self = fleft; pre[var].push_back(T);
             } else ip.push_back(i);
             const int fbase = (int) flags.size();
-            flags.resize(flags.size() + (size_t) nstrip * nblk, 0x7fffffff);
+            flags.resize(flags.size() + (size_t) nstrip * nblk * G2G_FSTRIDE, 0x7fffffff);
             for (int ti = 0; ti < nstrip; ++ti) {
                 const int m0 = al + ti * R;
                 for (int tj = 0; tj < nblk; ++tj) {
@@ -879,11 +879,11 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
                     if (!nsteps) continue;
                     V2Tile T;
                     T.prob = i; T.ti = ti; T.tj = tj; T.nsteps = nsteps;
-                    T.self = fbase + ti * nblk + tj;
-                    T.dep_up = ti > 0 ? T.self - nblk : ftop;             // sweep mode: the top chain is strip 0's "strip above"
-                    T.dep_left = tj > 0 ? T.self - 1 : fleft;
-                    T.dep_diag = (ti > 0 && tj > 0) ? T.self - nblk - 1 : -1;
-                    T.dep_war = (ti > 1 && tj + 1 < nblk) ? T.self - 2 * nblk + 1 : -1;
+                    T.self = fbase + (ti * nblk + tj) * G2G_FSTRIDE;
+                    T.dep_up = ti > 0 ? T.self - nblk * G2G_FSTRIDE : ftop;             // sweep mode: the top chain is strip 0's "strip above"
+                    T.dep_left = tj > 0 ? T.self - G2G_FSTRIDE : fleft;
+                    T.dep_diag = (ti > 0 && tj > 0) ? T.self - (nblk + 1) * G2G_FSTRIDE : -1;
+                    T.dep_war = (ti > 1 && tj + 1 < nblk) ? T.self - (2 * nblk - 1) * G2G_FSTRIDE : -1;
                     flags[T.self] = 0;
                     const int k = ti + tj;
                     if ((int) q[var].size() <= k) q[var].resize(k + 1);
@@ -904,7 +904,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         if (const char *e = g2g_opt(ctx, "INJECT_STALL")) {
             const int victim = atoi(e);
             const int never = (int) flags.size();
-            flags.push_back(0);
+            flags.resize(flags.size() + G2G_FSTRIDE, 0);
             for (size_t k = 0; k < all.size(); ++k)
                 if (all[k].prob == victim && all[k].ti >= 0) { all[k].dep_up = never; break; }
         }
@@ -1150,6 +1150,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                 fprintf(stderr, "[g2g] first time-out: DP %d, wanted gen %d col %d of word %d, saw gen %d col %d; the words at and below it (gen:col):",
                         x[7] - b->fail_off, (x[4] >> 20) & 0x7FF, x[4] & 0xFFFFF, x[6], (x[5] >> 20) & 0x7FF, x[5] & 0xFFFFF);
                 for (int k = 0; k < 8; ++k) fprintf(stderr, " %d:%d", (x[8 + k] >> 20) & 0x7FF, x[8 + k] & 0xFFFFF);
+                fprintf(stderr, "; producer's heartbeat: step %d place %d, 50 us later step %d place %d", x[16], x[17], x[18], x[19]);
                 fprintf(stderr, "; by RMW %d:%d, loaded again %d:%d", (x[46] >> 20) & 0x7FF, x[46] & 0xFFFFF, (x[47] >> 20) & 0x7FF, x[47] & 0xFFFFF);
                 fprintf(stderr, "\n"); fflush(stderr);
             }

@@ -39,6 +39,8 @@ __device__ unsigned long long g2g_stamp_acc[16];
 // g2g_batch_run re-runs the marked DPs on the non-polling kernel (g2g_forward_kernel).  hdr = done + G2G_HDR:
 // [0] time-outs, [1] queue slot of the first, [2] offset of the fail array from `done`, [3] the limit.
 #define G2G_HDR 24                   // d_flags: [0, 24) queue heads of the kernel variants, [24, 28) this header, [28, 72) snapshot of the first time-out, tile flags behind
+#define G2G_FSTRIDE 32               // ints between two tile flags / progress words: one 128-byte line each, so that no two workgroups (in
+                                     // different XCDs, behind different L2s) ever store into the same line
 #define G2G_HDRN 48                  // header words: 4 + the snapshot (want, seen, offset of the polled word, the 40 words at and below it)
 __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hdr, int *failp, const int slot)
 {
@@ -65,7 +67,14 @@ __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hd
                     hdr[1] = slot; hdr[4] = want; hdr[5] = v;
                     const int off = (int) (p - (hdr - G2G_HDR));
                     hdr[6] = off; hdr[7] = (int) (failp - (hdr - G2G_HDR));
-                    for (int k = 0; k < 38 && off - k >= G2G_HDR + G2G_HDRN; ++k) hdr[8 + k] = __hip_atomic_load(p - k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int k = 0; k < 8 && off - k * G2G_FSTRIDE >= G2G_HDR + G2G_HDRN; ++k) hdr[8 + k] = __hip_atomic_load(p - k * G2G_FSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // the producer's heartbeat (v6 strips: step counter and a marker of the place in the step, stored next to the
+                    // progress word), read twice 50 us apart: is the producer running, and where?
+                    hdr[16] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hdr[17] = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int k = 0; k < 256; ++k) __builtin_amdgcn_s_sleep(8);
+                    hdr[18] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hdr[19] = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     hdr[8 + 38] = atomicAdd((int *) p, 0);          // the same word through a read-modify-write (executes at the coherent point)
                     hdr[8 + 39] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }

@@ -520,12 +520,17 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     };
+#define V6_MARK(k) { if (prog_self) __hip_atomic_store(prog_self + 2, (k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     auto publish = [&](const int col) {                    // corners <= col of this strip's last row are in HBM
         if (prog_self) {
+            V6_MARK(9)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            V6_MARK(10)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            V6_MARK(11)
             __hip_atomic_store(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            V6_MARK(12)
         }
     };
     if (lane < 28) stsc[lane] = 0;
@@ -588,6 +593,8 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
 #endif
     for (int s = 0; s < nsteps; ++s) {
         V6_STAMP(9)
+        if (prog_self) __hip_atomic_store(prog_self + 1, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // heartbeat
+        V6_MARK(1)
         const int n = cbase + s - lane;
         const int n0 = cbase + s;                          // lane 0's column
         const bool active = row_ok && n >= lo && n < hi;
@@ -596,8 +603,8 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
         if (p_act) trace[p_tri] = (uint8_t) p_trb;
         if (wr_rows && s > 0) flush_rows(n0 - 1 - llast);
         if (prog_self && s > 0 && (s & (pint - 1)) == 0) publish(n0 - llast);
-        if ((s & (V6_FEED - 1)) == 0) { refill(n0 + V6_AHEAD); team_sync(); }
-        if ((s & 63) == 0) { simblk_fill(P, SB, (s >> 6) + 1, m0, lane); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if ((s & (V6_FEED - 1)) == 0) { V6_MARK(2) refill(n0 + V6_AHEAD); team_sync(); }
+        if ((s & 63) == 0) { V6_MARK(3) simblk_fill(P, SB, (s >> 6) + 1, m0, lane); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         // -- hand-over from the row above
         hd = hu;
         hu = rs_up(oH); gu = rs_up(oG);
@@ -632,7 +639,8 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
             }
         }
         st_prev = n0 + 1 < hi0 && n0 + 2 <= c1;
-        if (st_prev) { need(n0 + 2); stage_load(n0 + 2, vert0, st_h, st_g, st_g2); }
+        if (st_prev) { V6_MARK(4) need(n0 + 2); stage_load(n0 + 2, vert0, st_h, st_g, st_g2); }
+        V6_MARK(5)
         RS myH = oH, myG = oG, myG2 = oG2;                 // (the produced records of this step)
         V6_STAMP(0)
         if (active) {                                      // (loops inside are uniform over the ACTIVE lanes: ballots see only them)
@@ -681,14 +689,17 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
         }
         p_act = active;
         oH = myH; oG = myG; oG2 = myG2;
+        V6_MARK(6)
         team_sync();
     }
+    V6_MARK(7)
 #ifdef G2G_V6_STAMP
     if (lane == 0) { for (int k = 0; k < 12; ++k) atomicAdd(&g2g_v6_stamp_acc[k], st_acc[k]); atomicAdd(&g2g_v6_stamp_acc[12], (unsigned long long) nsteps); }
 #endif
     if (p_act) trace[p_tri] = (uint8_t) p_trb;
     if (wr_rows) flush_rows(cbase + nsteps - 1 - llast);
     publish(0xFFFFF);
+    V6_MARK(8)
 #undef V6_L
 }
 

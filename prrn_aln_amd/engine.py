@@ -87,14 +87,15 @@ class Context:
         rc = L.g2g_batch_prepare(self._h, len(holders), self._pp(holders), C.byref(h))
         if rc:
             raise G2GError("g2g_batch_prepare rc=%d: %s" % (rc, last_error()))
-        return Batch(self, h, len(holders))
+        return Batch(self, h, len(holders), keep=list(holders))
 
 
 class Batch:
     """A sweep resident in HBM (inputs uploaded once); run() launches the kernels."""
 
-    def __init__(self, ctx: Context, h, n: int):
+    def __init__(self, ctx: Context, h, n: int, keep=None):
         self.ctx, self._h, self.n = ctx, h, n
+        self._keep = keep                       # the library re-reads the problem descriptions when it re-runs a DP (g2g.h)
 
     def run(self):
         rc = lib().g2g_batch_run(self._h)
