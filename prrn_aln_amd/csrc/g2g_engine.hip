@@ -1150,7 +1150,12 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                 fprintf(stderr, "[g2g] first time-out: DP %d, wanted gen %d col %d of word %d, saw gen %d col %d; the words at and below it (gen:col):",
                         x[7] - b->fail_off, (x[4] >> 20) & 0x7FF, x[4] & 0xFFFFF, x[6], (x[5] >> 20) & 0x7FF, x[5] & 0xFFFFF);
                 for (int k = 0; k < 8; ++k) fprintf(stderr, " %d:%d", (x[8 + k] >> 20) & 0x7FF, x[8 + k] & 0xFFFFF);
-                fprintf(stderr, "; producer's heartbeat: step %d place %d, 50 us later step %d place %d", x[16], x[17], x[18], x[19]);
+                if (x[16] == 0x7fffffff || (x[16] == 0 && x[17] == 0)) fprintf(stderr, "; no heartbeat (build with G2G_EXTRA_FLAGS=-DG2G_V6_HEARTBEAT to have the v6 strips keep one)");
+                else fprintf(stderr, "; producer's heartbeat: step %d place %d, 50 us later step %d place %d", x[16], x[17], x[18], x[19]);
+                fprintf(stderr, "; producer HW_ID %08x XCC %d, waiter HW_ID %08x XCC %d; waiters per XCC:", x[20], x[21] & 15, x[22], x[23] & 15);
+                for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", x[24 + k] / 64);
+                fprintf(stderr, "; their producers per XCC:");
+                for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", x[32 + k] / 64);
                 fprintf(stderr, "; by RMW %d:%d, loaded again %d:%d", (x[46] >> 20) & 0x7FF, x[46] & 0xFFFFF, (x[47] >> 20) & 0x7FF, x[47] & 0xFFFFF);
                 fprintf(stderr, "\n"); fflush(stderr);
             }

@@ -36,8 +36,9 @@ __device__ unsigned long long g2g_stamp_acc[16];
 // bound is therefore WALL CLOCK (s_memrealtime: 100 MHz, keeps running while a wave is descheduled), set per launch by the
 // host (hdr[3], units of 65536 ticks = 0.655 ms), and a time-out costs ONE DP, not the batch: the DP is marked in the
 // batch's fail array, every other wait of that DP gives up at its next check, its remaining strips are skipped, and
-// g2g_batch_run re-runs the marked DPs on the non-polling kernel (g2g_forward_kernel).  hdr = done + G2G_HDR:
-// [0] time-outs, [1] queue slot of the first, [2] offset of the fail array from `done`, [3] the limit.
+// g2g_batch_run re-runs the marked DPs (on the ordinary kernels once more, then on the non-polling g2g_forward_kernel).
+// hdr = done + G2G_HDR: [0] time-outs, [1] strip index of the first, [2] offset of the fail array from `done`, [3] the limit,
+// [4..47] what the first wave to give up saw (the host prints it under G2G_WARN; DESIGN.md 4.2 reads such reports).
 #define G2G_HDR 24                   // d_flags: [0, 24) queue heads of the kernel variants, [24, 28) this header, [28, 72) snapshot of the first time-out, tile flags behind
 #define G2G_FSTRIDE 32               // ints between two tile flags / progress words: one 128-byte line each, so that no two workgroups (in
                                      // different XCDs, behind different L2s) ever store into the same line
@@ -48,22 +49,28 @@ __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hd
     if (v >= want) return v;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (unsigned it = 1; ; ++it) {
-        // back off: the first polls come 0.2 us apart, later ones 2-3 us with a phase that differs from wave to wave.  A standing,
-        // strictly periodic stream of reads of one word was seen to hold up the STORE to that word (the producer's
-        // next publish never became visible, by load or by read-modify-write, until the readers gave up -- and then at once).
+        // back off: the first polls come 0.2 us apart, later ones 2-3 us with a phase that differs from wave to wave (hundreds of
+        // waits per sweep last tens of ms -- strips pulled long before their producers get going: no point in hammering the fabric)
         const unsigned nap = it < 16 ? 1 : it < 64 ? 2 + (it & 1) : 8 + ((it * 5 + (unsigned) slot) & 7);
         for (unsigned j = 0; j < nap; ++j) __builtin_amdgcn_s_sleep(8);
         v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v >= want) return v;
         if ((it & 63) == 0) {
-            // drop this XCD's copy of the polled line (buffer_inv sc1): see DESIGN.md 4.2 -- a producer's store to a word was seen to
-            // stay pending for as long as a reader kept re-reading that word, and to complete the moment the reader went away
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (__hip_atomic_load(failp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 0x7fffffff;      // this DP is lost already
             const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
             if ((dt >> 16) > (unsigned long long) (unsigned) __hip_atomic_load(hdr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 __hip_atomic_store(failp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (atomicAdd(hdr, 1) == 0) {             // the first one leaves a snapshot for the host's report
+                {   // where the waves that gave up sit, and where their producers sit (v6 strips leave HW_ID / XCC_ID next to their progress word)
+                    const int my_xcc = (int) __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15;
+                    const int pr_xcc = __hip_atomic_load(p + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicAdd(hdr + 24 + (my_xcc & 7), 1);
+                    if ((pr_xcc & ~15) == 0x100) atomicAdd(hdr + 32 + (pr_xcc & 7), 1);
+                }
+                if (atomicAdd(hdr, 1) == 0) {
+                    hdr[20] = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hdr[21] = __hip_atomic_load(p + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hdr[22] = (int) __builtin_amdgcn_s_getreg((31 << 11) | 4);
+                    hdr[23] = (int) __builtin_amdgcn_s_getreg((31 << 11) | 20);             // the first one leaves a snapshot for the host's report
                     hdr[1] = slot; hdr[4] = want; hdr[5] = v;
                     const int off = (int) (p - (hdr - G2G_HDR));
                     hdr[6] = off; hdr[7] = (int) (failp - (hdr - G2G_HDR));

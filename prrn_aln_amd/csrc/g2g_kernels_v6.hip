@@ -520,7 +520,16 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     };
+// diagnostic heartbeat (build with -DG2G_V6_HEARTBEAT): step counter and a marker of the place in the step, stored next to the
+// strip's progress word; the report of a time-out reads them (g2g_wait_ge).  Off by default: ten 4-byte write-through stores
+// per step are ~30 GB/s of fabric traffic for nothing.
+#ifdef G2G_V6_HEARTBEAT
 #define V6_MARK(k) { if (prog_self) __hip_atomic_store(prog_self + 2, (k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define V6_BEAT(s) { if (prog_self) __hip_atomic_store(prog_self + 1, (s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+#define V6_MARK(k)
+#define V6_BEAT(s)
+#endif
     auto publish = [&](const int col) {                    // corners <= col of this strip's last row are in HBM
         if (prog_self) {
             V6_MARK(9)
@@ -591,9 +600,13 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
     unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_t = __builtin_amdgcn_s_memtime();
 #endif
+    if (prog_self) {                                       // where this strip runs (read by the report of a time-out, g2g_wait_ge)
+        __hip_atomic_store(prog_self + 3, (int) __builtin_amdgcn_s_getreg((31 << 11) | 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(prog_self + 4, 0x100 | ((int) __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     for (int s = 0; s < nsteps; ++s) {
         V6_STAMP(9)
-        if (prog_self) __hip_atomic_store(prog_self + 1, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // heartbeat
+        V6_BEAT(s)
         V6_MARK(1)
         const int n = cbase + s - lane;
         const int n0 = cbase + s;                          // lane 0's column
