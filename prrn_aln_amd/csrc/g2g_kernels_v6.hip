@@ -377,6 +377,20 @@ __device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, cons
 }
 
 // ---- one STRIP (64 rows x all columns) by one wave, pipelined behind the strip above on progress counters -----------
+// Strip-boundary records cross XCDs (each XCD has its own L2).  With G2G_V6_NOFENCE they are written with agent-scope
+// (write-through) stores and read with agent-scope loads, so that publishing / consuming progress needs no buffer_wbl2 /
+// buffer_inv of the whole L2; without it they are plain accesses ordered by release / acquire fences.
+#ifdef G2G_V6_NOFENCE
+#define V6_XLD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define V6_XST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define V6_ACQUIRE()
+#define V6_RELEASE()
+#else
+#define V6_XLD(p) (*(p))
+#define V6_XST(p, v) (*(p) = (v))
+#define V6_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define V6_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#endif
 template <bool NOLL3, int NA>
 __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const V6Lds LO, const int ti, const int nsteps,
                                          const int *prog_up, int *prog_self, int *dbg, const int pgen, const int pint, const int *prog_left,
@@ -412,7 +426,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
         const int rows_ = m0 + 64 - a.left;
         const int wantl = ((pgen & 0x7FF) << 20) | (rows_ < 0xFFFFF ? rows_ : 0xFFFFF);
         (void) g2g_wait_ge(prog_left, wantl, dbg, failp, ti);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        V6_ACQUIRE();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     const int mend = (m0 + 64 < a.right) ? m0 + 64 : a.right;
@@ -486,16 +500,16 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
     if (row_ok && m + 1 < a.right && m + 1 <= m_left_last && m + 1 + P.lw <= b.left) {      // left boundary corner (m+1, b.left)
         lu32 *p = V6_L(lane + 1, SLOT_H(c0));
         const GLB unsigned *src = colH + (size_t) (m + 1 - a.left) * ndw;
-        oH.val = *(const GLB double *) src; oH.dir = (int) src[2]; oH.glb = (int) src[3];
-        for (int k = 0; k < capa; ++k) p[k] = src[4 + k];
-        for (int k = 0; k < capb; ++k) p[ca4 + k] = src[4 + capa + k];
+        oH.val = __hiloint2double((int) V6_XLD(src + 1), (int) V6_XLD(src)); oH.dir = (int) V6_XLD(src + 2); oH.glb = (int) V6_XLD(src + 3);
+        for (int k = 0; k < capa; ++k) p[k] = V6_XLD(src + 4 + k);
+        for (int k = 0; k < capb; ++k) p[ca4 + k] = V6_XLD(src + 4 + capa + k);
     }
     // ---- staging row: records of the strip above for lane 0's columns, one dword per lane --------------
     auto stage_load = [&](int col, bool wantG, unsigned &rh, unsigned &rg, unsigned &rg2) {
         if (lane < ndw) {
             const GLB unsigned *s = (col == b.left && vert0) ? colH + (size_t) (m0 - a.left) * ndw : rowHp + (size_t) col * ndw;
-            rh = s[lane];
-            if (wantG) { rg = rowGp[(size_t) col * ndw + lane]; if (NOLL3) rg2 = rowG2p[(size_t) col * ndw + lane]; }
+            rh = V6_XLD(s + lane);
+            if (wantG) { rg = V6_XLD(rowGp + (size_t) col * ndw + lane); if (NOLL3) rg2 = V6_XLD(rowG2p + (size_t) col * ndw + lane); }
         }
     };
     auto stage_put = [&](int slot, int sid, unsigned v) {
@@ -516,7 +530,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
         const int want = penc | (col < 0xFFFFF ? col : 0xFFFFF);
         if (prog_up && want > avail) {
             avail = g2g_wait_ge(prog_up, want, dbg, failp, ti);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            V6_ACQUIRE();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     };
@@ -535,7 +549,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
             V6_MARK(9)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             V6_MARK(10)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            V6_RELEASE();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             V6_MARK(11)
             __hip_atomic_store(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -592,7 +606,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
                     v = (j < capa) ? p[j] : (j < capa + capb) ? p[ca4 + j - capa] : 0;
                 }
                 GLB unsigned *dst = (x == 0) ? rowHc : (x == 1) ? rowGc : rowG2c;
-                if (lane < ndw) dst[(size_t) col * ndw + lane] = v;
+                if (lane < ndw) V6_XST(dst + (size_t) col * ndw + lane, v);
             }
         }
     };
