@@ -992,8 +992,9 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             int *hdr = b->hdr_img;
             memset(hdr, 0, sizeof b->hdr_img);
             // a legitimate wait lasts as long as the strip above needs for one publish interval, or a boundary chain for its
-            // sequential walk: milliseconds.  One second of wall clock means the producer is not running.
-            double limit_ms = 1000.;
+            // sequential walk: milliseconds, tens of ms for a strip pulled long before its producer gets going (under 180 ms in every
+            // ordinary sweep observed).  Half a second of wall clock means the producer is not running; a false alarm only costs a re-run.
+            double limit_ms = 500.;
             if (const char *e = g2g_opt(ctx, "WAIT_LIMIT_MS")) { const double v = atof(e); if (v > 0) limit_ms = v; }
             hdr[G2G_HDR + 2] = b->fail_off;
             hdr[G2G_HDR + 3] = (int) std::min(2.0e9, limit_ms * ctx->rt_ticks_per_ms / 65536.) + 1;
