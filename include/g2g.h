@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define G2G_ABI_VERSION 3
+#define G2G_ABI_VERSION 4
 
 /* error codes (negative) */
 enum {
@@ -178,6 +178,14 @@ int       g2g_batch_fetch(g2g_batch *b, g2g_result *res);
 void      g2g_batch_times(const g2g_batch *b, float *fwd_ms, float *tb_ms);
 long long g2g_batch_cells(const g2g_batch *b);
 size_t    g2g_batch_arena_bytes(const g2g_batch *b);
+/* The scheduler's waits are bounded by wall clock: a wait that runs into the limit costs its DP a re-run
+   inside g2g_batch_run, and the results stay complete.  These two make every such event visible: for the LAST run of a
+   batch the number of waits that gave up and of DPs re-run (and the DPs re-run over the batch's life); for a context
+   out[0] = batch runs, out[1] = waits that gave up, out[2] = DPs re-run, out[3] = of those, DPs that needed the
+   non-polling kernel -- counted over every entry point that runs DPs (g2g_align2_batch, g2g_refine, ...).  An ordinary
+   run reports zeros. */
+void      g2g_batch_recovery(const g2g_batch *b, int *timeouts_last_run, int *recovered_last_run, int *recovered_total);
+void      g2g_ctx_counters(const g2g_ctx *ctx, long long out[4]);
 void      g2g_batch_free(g2g_batch *b);
 
 /* stdskl(): sort + normalise a raw traceback into ascending unique corners (reference src/gaps.cc:139).
@@ -283,18 +291,36 @@ typedef struct g2g_tree {
     const double  *vol, *cur;
 } g2g_tree;
 typedef int (*g2g_exchange_fn)(void *user, const int32_t *mine, int n_ints, int32_t *all);
+/* Optional: the caller scores the divisions of a window instead of the GPU (ctx may then be NULL).  For each of the n PwdMs:
+   scr[i] = the DP score and skl[i] / nskl[i] = the standardised skeleton of align2() (malloc'ed, the library frees it),
+   raw_cur[i] = calcSpScore(SKL*) of the CURRENT alignment cur[i] (not rescaled), val_new[i] = fstat.val of the new one.
+   The tests drive the loop -- window logic, sharding, exchange, error paths -- on a machine without a GPU this way, with the
+   CPU checker in the scorer's seat; the product never sets it.  Return 0. */
+typedef int (*g2g_score_fn)(void *user, int n, g2g_pwdm *const *pw, const g2g_skl *const *cur, const int *ncur,
+                            double *scr, g2g_skl **skl, int *nskl, double *raw_cur, double *val_new);
+/* An accepted move: the two member lists of the division (larger group first, as Prrn::divideseq orders them) and the new
+   skeleton in that order (corners over the two groups' columns with their all-gap columns dropped). */
+typedef void (*g2g_accept_fn)(void *user, int branch, int na, const int32_t *la, int nb, const int32_t *lb, int nskl, const g2g_skl *skl);
 typedef struct g2g_refine_opts {
     int32_t seed, maxitr, window;
     int32_t rank, world, slot_cap;  /* slot_cap: most corners of a skeleton an exchange slot holds (default 4096) */
-    g2g_exchange_fn exchange;
+    g2g_exchange_fn exchange;       /* A rank that fails locally still enters the exchange: its error code travels in the first
+                                       word of its buffer and EVERY rank returns it after the gather (no rank is left waiting in
+                                       the collective).  The callback itself must fail on all ranks or on none.                */
     void   *exchange_user;
+    g2g_score_fn scorer;            /* NULL: g2g_align2_batch + g2g_spscore_batch on the GPU                                   */
+    void   *scorer_user;
+    g2g_accept_fn on_accept;        /* optional: told about every accepted move, in order (what synthgap applies, src/prrn5.cc:536-541) */
+    void   *on_accept_user;
+    int32_t window_min, reserved;   /* window after an accepted move (default 2); it doubles up to `window` while nothing is accepted */
 } g2g_refine_opts;
 typedef struct g2g_refine_step {
     int32_t branch, na, nb, swp, accepted, skipped;   /* skipped: neither group had a column to drop -- no DP (prrn5.cc:497) */
     double  scr, val_new, val_old, delta;             /* DP score; fstat.val of the new alignment; raw score of the current one */
 } g2g_refine_step;
 typedef struct g2g_refine_stats {
-    int32_t divisions, accepted, batches, divisions_scored_here, divisions_wasted, reserved;
+    int32_t divisions, accepted, batches, divisions_scored_here, divisions_wasted;
+    int32_t wait_timeouts, recovered_dps, reserved;   /* scheduler waits that ran into their limit during the call / DPs re-run (g2g_ctx_counters) */
 } g2g_refine_stats;
 int        g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len, const uint8_t *codes, const g2g_tree *tree,
                       const g2g_refine_opts *opts, uint8_t **out_codes, int *out_len, g2g_refine_step **steps, int *nsteps,

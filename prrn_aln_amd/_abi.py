@@ -79,9 +79,18 @@ class Tree(C.Structure):
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32))
 
 
+SCORE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(Skl)), C.POINTER(C.c_int),
+                       C.POINTER(C.c_double), C.POINTER(C.POINTER(Skl)), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
+ACCEPT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(Skl))
+
+
 class RefineOpts(C.Structure):
     _fields_ = [("seed", C.c_int32), ("maxitr", C.c_int32), ("window", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
-                ("slot_cap", C.c_int32), ("exchange", EXCHANGE_FN), ("exchange_user", C.c_void_p)]
+                ("slot_cap", C.c_int32), ("exchange", EXCHANGE_FN), ("exchange_user", C.c_void_p),
+                ("scorer", SCORE_FN), ("scorer_user", C.c_void_p), ("on_accept", ACCEPT_FN), ("on_accept_user", C.c_void_p),
+                ("window_min", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RefineStep(C.Structure):
@@ -91,7 +100,7 @@ class RefineStep(C.Structure):
 
 class RefineStats(C.Structure):
     _fields_ = [("divisions", C.c_int32), ("accepted", C.c_int32), ("batches", C.c_int32), ("divisions_scored_here", C.c_int32),
-                ("divisions_wasted", C.c_int32), ("reserved", C.c_int32)]
+                ("divisions_wasted", C.c_int32), ("wait_timeouts", C.c_int32), ("recovered_dps", C.c_int32), ("reserved", C.c_int32)]
 
 
 def _ptr(arr: np.ndarray, typ):

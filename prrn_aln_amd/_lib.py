@@ -44,6 +44,10 @@ def lib():
     L.g2g_batch_arena_bytes.restype = C.c_size_t
     L.g2g_batch_arena_bytes.argtypes = [C.c_void_p]
     L.g2g_batch_free.argtypes = [C.c_void_p]
+    L.g2g_batch_recovery.restype = None
+    L.g2g_batch_recovery.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.g2g_ctx_counters.restype = None
+    L.g2g_ctx_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     L.g2g_batch_spscore.argtypes = [C.c_void_p, C.POINTER(_abi.SpParams), C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int), C.POINTER(_abi.Fstat)]
     L.g2g_free.argtypes = [C.c_void_p]
     L.g2g_stdskl.restype = C.POINTER(_abi.Skl)

@@ -48,6 +48,7 @@ struct g2g_ctx {
     std::map<std::string, std::pair<bool, std::string>> opt;   // g2g_set_option: name -> (present, value); see g2g_opt
     char *spare; size_t spare_bytes; // one device arena kept from the last freed batch (hipMalloc/hipFree of tens of GB per
                                     // call cost up to a second); contents are as undefined as a fresh allocation's
+    long long n_runs, n_timeouts, n_recovered, n_v1;   // g2g_ctx_counters: batch runs, waits that ran into the limit, DPs re-run, of those on v1
 };
 
 // Tuning and diagnostic switches belong to a context (g2g_set_option / g2g_get_option); a name a context has not set
@@ -106,6 +107,7 @@ extern "C" g2g_ctx *g2g_create(int device)
     c->ok = 0;
     c->stage = 0; c->stage_cap = 0;
     c->spare = 0; c->spare_bytes = 0;
+    c->n_runs = c->n_timeouts = c->n_recovered = c->n_v1 = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; g2g_set_error("%s", "stream"); return NULL; }
     for (int i = 0; i < 4; ++i) hipEventCreate(&c->ev[i]);
     for (int i = 0; i < 6; ++i) hipStreamCreateWithFlags(&c->vstream[i], hipStreamNonBlocking);
@@ -258,6 +260,7 @@ struct g2g_batch {
                                                  // that lost a wait is re-run from here on the non-polling kernel
     int fail_off;                                // offset of the per-DP fail flags in d_flags
     int n_recovered;                             // DPs re-run after a time-out, over the life of the batch
+    int last_timeouts, last_recovered;           // the same for the last g2g_batch_run: waits that gave up, DPs re-run
     std::vector<g2g_result> recovered;           // results of re-run DPs (trace owned by the batch until fetched)
     std::vector<char> was_recovered;
     bool is_retry;                               // a batch of DPs that lost a wait, re-run on the ordinary kernels; ITS time-outs go to v1
@@ -554,6 +557,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
     for (int k = 0; k < 24; ++k) { b->simscr[k] = 0; b->simscr_cap[k] = 0; }
     b->src.assign(prob, prob + n); b->fail_off = 0; b->force_v1 = force_v1; b->is_retry = false; b->n_recovered = 0;
     b->recovered.assign(n, g2g_result()); b->was_recovered.assign(n, 0);
+    b->last_timeouts = b->last_recovered = 0;
     b->v3_cols = 128; b->v2_cols = G2G_V2_TILE_COLS;
 
     b->dp.resize(n); b->status.assign(n, G2G_OK); b->cells.assign(n, 0); b->out_off.assign(n, 0); b->tcap.assign(n, 0); b->rr1.assign(n, 0);
@@ -942,6 +946,8 @@ extern "C" int g2g_batch_run(g2g_batch *b)
     HIPCHK(hipSetDevice(ctx->device));
     if (b->n == 0) return G2G_OK;
     std::fill(b->was_recovered.begin(), b->was_recovered.end(), 0);
+    b->last_timeouts = b->last_recovered = 0;
+    if (!b->is_retry) ++ctx->n_runs;
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     if (b->n2) {
         const int T2 = b->v2_threads;
@@ -1142,6 +1148,9 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipMemcpy(fail.data(), b->d_flags + b->fail_off, sizeof(int) * (size_t) b->n, hipMemcpyDeviceToHost));
             std::vector<int> lost;
             for (int i = 0; i < b->n; ++i) if (fail[i] && !b->status[i]) lost.push_back(i);
+            b->last_timeouts = rep[G2G_HDR]; b->last_recovered = (int) lost.size();
+            ctx->n_timeouts += rep[G2G_HDR]; ctx->n_recovered += (long long) lost.size();
+            if (b->is_retry) ctx->n_v1 += (long long) lost.size();
             if (g2g_opt(ctx, "DEBUG") || g2g_opt(ctx, "WARN")) {
                 fprintf(stderr, "[g2g] s_memrealtime: %.0f ticks/ms; ", ctx->rt_ticks_per_ms);
                 fprintf(stderr, "[g2g] %d waits timed out (first: queue slot %d, gen %d): re-running %zu DP(s) %s:", rep[G2G_HDR], rep[G2G_HDR + 1], b->gen, lost.size(), b->is_retry ? "on g2g_forward_kernel" : "(first on the ordinary kernels)");
@@ -1234,6 +1243,18 @@ extern "C" long long g2g_batch_cells(const g2g_batch *b)
 }
 
 extern "C" size_t g2g_batch_arena_bytes(const g2g_batch *b) { return b ? b->arena_bytes : 0; }
+
+extern "C" void g2g_batch_recovery(const g2g_batch *b, int *timeouts_last_run, int *recovered_last_run, int *recovered_total)
+{
+    if (timeouts_last_run) *timeouts_last_run = b ? b->last_timeouts : 0;
+    if (recovered_last_run) *recovered_last_run = b ? b->last_recovered : 0;
+    if (recovered_total) *recovered_total = b ? b->n_recovered : 0;
+}
+extern "C" void g2g_ctx_counters(const g2g_ctx *c, long long out[4])
+{
+    if (!out) return;
+    out[0] = c ? c->n_runs : 0; out[1] = c ? c->n_timeouts : 0; out[2] = c ? c->n_recovered : 0; out[3] = c ? c->n_v1 : 0;
+}
 
 extern "C" void g2g_batch_free(g2g_batch *b)
 {

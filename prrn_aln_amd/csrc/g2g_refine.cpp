@@ -21,7 +21,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <math.h>
+#include <cmath>
+#include <string>
 #include <vector>
 #include <algorithm>
 #include <thread>
@@ -117,6 +118,38 @@ struct Tree {
     }
 };
 
+// The tree comes from the caller through the C ABI: every walk below follows its indices, so they are checked once -- index
+// ranges, leaves 0 .. many-1 childless and every inner node with two children, parent / child links consistent, exactly one
+// root, every node reached from it exactly once (no cycle, no shared subtree), vol > 0 where it divides.
+const char *check_tree(const g2g_tree *t, int many)
+{
+    const int nn = t->n_nodes;
+    int root = -1;
+    for (int k = 0; k < nn; ++k) {
+        const int l = t->left[k], r = t->right[k], p = t->parent[k];
+        if (l < -1 || l >= nn || r < -1 || r >= nn || p < -1 || p >= nn) return "an index is out of range";
+        if (k < many) { if (l != -1 || r != -1) return "nodes 0 .. many-1 must be leaves"; }
+        else if (l < 0 || r < 0 || l == r || l == k || r == k) return "an inner node needs two different children";
+        if (l >= 0 && t->parent[l] != k) return "a left child does not name its parent";
+        if (r >= 0 && t->parent[r] != k) return "a right child does not name its parent";
+        if (p < 0) { if (root >= 0) return "more than one root"; root = k; }
+        else if (t->left[p] != k && t->right[p] != k) return "a node is not a child of its parent";
+        if (!(t->vol[k] > 0) || !std::isfinite(t->vol[k]) || !std::isfinite(t->cur[k])) return "vol must be positive and finite, cur finite";
+    }
+    if (root < 0) return "no root";
+    std::vector<char> seen((size_t) nn, 0);
+    std::vector<int> st(1, root);
+    int cnt = 0;
+    while (!st.empty()) {
+        const int k = st.back(); st.pop_back();
+        if (seen[k]) return "a node is reachable twice";
+        seen[k] = 1; ++cnt;
+        if (t->left[k] >= 0) { st.push_back(t->left[k]); st.push_back(t->right[k]); }
+    }
+    if (cnt != nn) return "not every node hangs below the root";
+    return 0;
+}
+
 // lt(0, delta), src/cmn.h:63
 inline bool lt0(double d) { return 0.0 < d - FEPS * std::max(1.0, fabs(d)); }
 
@@ -135,6 +168,7 @@ struct Division {
     int swp;
     double scr, val_old, val_new, delta;
     int status;
+    std::string err;                                          // what a builder thread reported (g2g_last_error is per thread)
     Division() : branch(0), skip(false), pwt(0), ra(0), rb(0), ga(0), gb(0), pw(0), swp(0), scr(0), val_old(0), val_new(0), delta(0), status(0) {}
 };
 
@@ -171,6 +205,8 @@ bool join_columns(const Division &d, const Skl &skl, int many, Msa &out)
     const int na = (int) d.la.size(), nb = (int) d.lb.size();
     out.many = many; out.c.clear();
     int rows = 0;
+    // a skeleton may have crossed a process boundary: first corner (0, 0), last corner (ra, rb), monotone in between
+    if (skl.size() < 2 || skl.front().m != 0 || skl.front().n != 0 || skl.back().m != d.ra || skl.back().n != d.rb) return false;
     for (size_t k = 0; k + 1 < skl.size(); ++k) {
         const int m0 = skl[k].m, n0 = skl[k].n, dm = skl[k + 1].m - m0, dn = skl[k + 1].n - n0;
         if (!(dm == dn || dm == 0 || dn == 0) || dm < 0 || dn < 0) return false;
@@ -199,24 +235,31 @@ void free_division(Division &d)
 
 }   // namespace
 
+extern "C" void g2g_ctx_counters(const g2g_ctx *c, long long out[4]);
+
 extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len, const uint8_t *codes, const g2g_tree *tree,
                           const g2g_refine_opts *opts, uint8_t **out_codes, int *out_len, g2g_refine_step **steps, int *nsteps,
                           g2g_refine_stats *stats)
 {
-    if (!ctx || !prm || !codes || !tree || !out_codes || !out_len || many < 2 || len < 1) return G2G_ERR_ARG;
+    if (!prm || !codes || !tree || !out_codes || !out_len || many < 2 || len < 1) return G2G_ERR_ARG;
+    if (!ctx && !(opts && opts->scorer)) return G2G_ERR_ARG;               // the DPs run on the GPU unless the caller scores them
     if (tree->n_nodes != 2 * many - 1 || !tree->left || !tree->right || !tree->parent || !tree->vol || !tree->cur) {
         g2g_set_error("%s", "g2g_refine: the tree must have 2 * many - 1 nodes (leaves 0 .. many - 1 = the members)");
         return G2G_ERR_ARG;
     }
+    if (const char *why = check_tree(tree, many)) { g2g_set_error("g2g_refine: malformed tree: %s", why); return G2G_ERR_ARG; }
     g2g_refine_opts O;
     memset(&O, 0, sizeof O);
     if (opts) O = *opts;
     if (O.seed == 0) O.seed = 1;
     if (O.maxitr <= 0) O.maxitr = 10;
     if (O.window <= 0) O.window = 32;
+    if (O.window_min <= 0) O.window_min = 2;
+    if (O.window_min > O.window) O.window_min = O.window;
     if (O.world <= 0) { O.world = 1; O.rank = 0; }
     if (O.slot_cap <= 0) O.slot_cap = 4096;
     const bool sharded = O.exchange && O.world > 1;
+    if (sharded && (O.rank < 0 || O.rank >= O.world)) { g2g_set_error("%s", "g2g_refine: rank outside [0, world)"); return G2G_ERR_ARG; }
     const int slot_ints = 9 + 2 * O.slot_cap;
 
     Tree T;
@@ -234,9 +277,11 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
     g2g_refine_stats S;
     memset(&S, 0, sizeof S);
     int rc_all = G2G_OK;
+    long long cnt0[4] = {0, 0, 0, 0};
+    if (ctx) g2g_ctx_counters(ctx, cnt0);
 
     const int maxi = O.maxitr * cycle;
-    int nrep = 0, it = 0, win = 2;
+    int nrep = 0, it = 0, win = O.window_min;
     std::vector<int> pending;
     unsigned nthr = std::thread::hardware_concurrency();
     if (nthr > 16) nthr = 16;
@@ -250,8 +295,13 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
         while ((int) pending.size() < std::min(win, maxi - it)) pending.push_back(next_branch());
         const int nw = std::min(win, (int) pending.size());
         std::vector<Division> D((size_t) nw);
+        // A failure of THIS rank (a builder, a kernel, a skeleton too long for a slot) must not keep it out of the exchange: the
+        // other ranks would wait in the collective for ever.  It is carried through the exchange as this rank's status word and
+        // every rank leaves the loop with the same code after the gather.
+        int local_rc = G2G_OK;
+        std::string local_err;
         // ---- build the window's divisions from the current MSA (host threads: the builders touch only their own objects) ----
-        std::atomic<int> nextd(0), fail(0);
+        std::atomic<int> nextd(0);
         auto build = [&]() {
             std::vector<int> inside;
             std::vector<double> w;
@@ -275,7 +325,7 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
                 d.ga = g2g_group_create(ctx, prm, (int) d.la.size(), d.ra, d.a.data(), wa.data());
                 d.gb = g2g_group_create(ctx, prm, (int) d.lb.size(), d.rb, d.b.data(), wb.data());
                 if (d.ga && d.gb) d.pw = g2g_pwdm_create(ctx, prm, d.ga, d.gb, &d.swp);
-                if (!d.pw) { fail = 1; continue; }
+                if (!d.pw) { d.status = G2G_ERR_ARG; d.err = g2g_last_error(); continue; }      // (this thread's error string: kept for the caller's thread)
                 if (d.swp) { Skl t; swap_skl(d.old, t); d.old.swap(t); }
             }
         };
@@ -287,7 +337,8 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
             for (auto &t : th) t.join();
         }
         t_build += now() - t0;
-        if (fail) { g2g_set_error("%s", "g2g_refine: building a division's groups failed"); rc_all = G2G_ERR_ARG; for (auto &d : D) free_division(d); break; }
+        for (int k = 0; k < nw && local_rc == G2G_OK; ++k)
+            if (D[k].status) { local_rc = D[k].status; local_err = "g2g_refine: building a division's groups failed: " + D[k].err; }
         // ---- score: my share of the window (largest rectangles first, round-robin), then the exchange ----
         std::vector<int> live;
         for (int k = 0; k < nw; ++k) if (!D[k].skip) live.push_back(k);
@@ -297,69 +348,115 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
         std::vector<int> mine;
         for (size_t i = (size_t) (sharded ? O.rank : 0); i < order.size(); i += (size_t) (sharded ? O.world : 1)) mine.push_back(order[i]);
         const int nm = (int) mine.size();
-        if (nm) {
+        if (nm && local_rc == G2G_OK) {
             std::vector<g2g_pwdm *> pw((size_t) nm);
             for (int i = 0; i < nm; ++i) pw[i] = D[live[mine[i]]].pw;
             std::vector<double> scr((size_t) nm);
             std::vector<g2g_skl *> skl((size_t) nm, (g2g_skl *) 0);
-            std::vector<int> nskl((size_t) nm), st((size_t) nm);
-            const double t1 = now();
-            int rc = g2g_align2_batch(ctx, nm, pw.data(), scr.data(), skl.data(), nskl.data(), st.data());
-            t_align += now() - t1;
-            if (rc == G2G_OK) {
-                std::vector<g2g_pwdm *> pw2(pw); pw2.insert(pw2.end(), pw.begin(), pw.end());
-                std::vector<const g2g_skl *> sk2((size_t) 2 * nm);
-                std::vector<int> ns2((size_t) 2 * nm);
-                for (int i = 0; i < nm; ++i) {
-                    Division &d = D[live[mine[i]]];
-                    sk2[i] = d.old.data(); ns2[i] = (int) d.old.size();
-                    sk2[nm + i] = skl[i]; ns2[nm + i] = nskl[i];
-                }
-                std::vector<g2g_fstat> fs((size_t) 2 * nm);
-                const double t2 = now();
-                rc = g2g_spscore_batch_flags(ctx, 2 * nm, pw2.data(), sk2.data(), ns2.data(), G2G_SP_NOSTATS, fs.data());
-                t_sp += now() - t2;
+            std::vector<int> nskl((size_t) nm, 0), st((size_t) nm, 0);
+            int rc;
+            if (O.scorer) {
+                // the caller scores (tests drive the loop on a CPU with the checker in this seat): same inputs, same outputs
+                std::vector<const g2g_skl *> cur((size_t) nm);
+                std::vector<int> ncur((size_t) nm);
+                std::vector<double> raw((size_t) nm), val((size_t) nm);
+                for (int i = 0; i < nm; ++i) { const Division &d = D[live[mine[i]]]; cur[i] = d.old.data(); ncur[i] = (int) d.old.size(); }
+                const double t1 = now();
+                rc = O.scorer(O.scorer_user, nm, pw.data(), cur.data(), ncur.data(), scr.data(), skl.data(), nskl.data(), raw.data(), val.data());
+                t_align += now() - t1;
+                if (rc != G2G_OK) g2g_set_error("%s", "g2g_refine: the scorer callback failed");
                 for (int i = 0; i < nm && rc == G2G_OK; ++i) {
                     Division &d = D[live[mine[i]]];
-                    if (st[i] != 0 || fs[i].status != 0 || fs[nm + i].status != 0) { rc = st[i] ? st[i] : fs[i].status ? fs[i].status : fs[nm + i].status; break; }
-                    d.scr = scr[i]; d.val_old = fs[i].raw; d.val_new = fs[nm + i].val;
+                    if (!skl[i] || nskl[i] < 2) { rc = G2G_ERR_DEVICE; g2g_set_error("%s", "g2g_refine: the scorer callback returned no skeleton"); break; }
+                    d.scr = scr[i]; d.val_old = raw[i]; d.val_new = val[i];
                     d.neu.assign(skl[i], skl[i] + nskl[i]);
+                }
+            } else {
+                const double t1 = now();
+                rc = g2g_align2_batch(ctx, nm, pw.data(), scr.data(), skl.data(), nskl.data(), st.data());
+                t_align += now() - t1;
+                if (rc == G2G_OK) {
+                    std::vector<g2g_pwdm *> pw2(pw); pw2.insert(pw2.end(), pw.begin(), pw.end());
+                    std::vector<const g2g_skl *> sk2((size_t) 2 * nm);
+                    std::vector<int> ns2((size_t) 2 * nm);
+                    for (int i = 0; i < nm; ++i) {
+                        Division &d = D[live[mine[i]]];
+                        sk2[i] = d.old.data(); ns2[i] = (int) d.old.size();
+                        sk2[nm + i] = skl[i]; ns2[nm + i] = nskl[i];
+                    }
+                    std::vector<g2g_fstat> fs((size_t) 2 * nm);
+                    const double t2 = now();
+                    rc = g2g_spscore_batch_flags(ctx, 2 * nm, pw2.data(), sk2.data(), ns2.data(), G2G_SP_NOSTATS, fs.data());
+                    t_sp += now() - t2;
+                    for (int i = 0; i < nm && rc == G2G_OK; ++i) {
+                        Division &d = D[live[mine[i]]];
+                        if (st[i] != 0 || fs[i].status != 0 || fs[nm + i].status != 0) {
+                            rc = st[i] ? st[i] : fs[i].status ? fs[i].status : fs[nm + i].status;
+                            g2g_set_error("%s", "g2g_refine: a division's DP or its sum-of-pairs score failed");
+                            break;
+                        }
+                        d.scr = scr[i]; d.val_old = fs[i].raw; d.val_new = fs[nm + i].val;
+                        d.neu.assign(skl[i], skl[i] + nskl[i]);
+                    }
                 }
             }
             for (int i = 0; i < nm; ++i) g2g_free(skl[i]);
-            if (rc != G2G_OK) { rc_all = rc; for (auto &d : D) free_division(d); break; }
-            S.divisions_scored_here += nm;
+            if (rc != G2G_OK) { local_rc = rc; local_err = g2g_last_error(); }
+            else S.divisions_scored_here += nm;
         }
         ++S.batches;
         if (sharded) {
-            // fixed-size slots {index in the window's live list, 0, corners, DP score, raw current score, new fstat.val, corners...}
+            // per rank: {status, 0} + fixed-size slots {index in the window's live list, 0, corners, DP score, raw current score, new
+            // fstat.val, corners...}
             const int ntot = (int) live.size();
             const int nslots = (ntot + O.world - 1) / O.world;
-            std::vector<int32_t> mybuf((size_t) nslots * slot_ints, -1), all((size_t) nslots * O.world * slot_ints, -1);
-            bool ok = true;
-            for (int i = 0; i < nm && ok; ++i) {
+            const int rank_ints = 2 + nslots * slot_ints;
+            std::vector<int32_t> mybuf((size_t) rank_ints, -1), all((size_t) rank_ints * O.world, -1);
+            for (int i = 0; i < nm && local_rc == G2G_OK; ++i) {
                 const Division &d = D[live[mine[i]]];
-                int32_t *s = &mybuf[(size_t) i * slot_ints];
-                if ((int) d.neu.size() > O.slot_cap) { ok = false; break; }
+                int32_t *s = &mybuf[2 + (size_t) i * slot_ints];
+                if ((int) d.neu.size() > O.slot_cap) { local_rc = G2G_ERR_ARG; local_err = "g2g_refine: a skeleton exceeds the exchange slot capacity"; break; }
                 s[0] = mine[i]; s[1] = 0; s[2] = (int32_t) d.neu.size();
                 memcpy(s + 3, &d.scr, 8); memcpy(s + 5, &d.val_old, 8); memcpy(s + 7, &d.val_new, 8);
                 for (size_t k = 0; k < d.neu.size(); ++k) { s[9 + 2 * k] = d.neu[k].m; s[10 + 2 * k] = d.neu[k].n; }
             }
-            if (!ok) { g2g_set_error("%s", "g2g_refine: a skeleton exceeds the exchange slot capacity"); rc_all = G2G_ERR_ARG; for (auto &d : D) free_division(d); break; }
-            const int rc = O.exchange(O.exchange_user, mybuf.data(), nslots * slot_ints, all.data());
-            if (rc != 0) { g2g_set_error("%s", "g2g_refine: the exchange callback failed"); rc_all = G2G_ERR_DEVICE; for (auto &d : D) free_division(d); break; }
-            int seen = 0;
-            for (int q = 0; q < nslots * O.world; ++q) {
-                const int32_t *s = &all[(size_t) q * slot_ints];
-                if (s[0] < 0 || s[0] >= ntot) continue;
-                Division &d = D[live[s[0]]];
-                memcpy(&d.scr, s + 3, 8); memcpy(&d.val_old, s + 5, 8); memcpy(&d.val_new, s + 7, 8);
-                d.neu.resize((size_t) s[2]);
-                for (int k = 0; k < s[2]; ++k) { d.neu[k].m = s[9 + 2 * k]; d.neu[k].n = s[10 + 2 * k]; }
-                ++seen;
+            mybuf[0] = local_rc; mybuf[1] = 0;
+            if (local_rc != G2G_OK) for (size_t q = 2; q < mybuf.size(); ++q) mybuf[q] = -1;       // a failed rank hands over no slot
+            const int xrc = O.exchange(O.exchange_user, mybuf.data(), rank_ints, all.data());
+            if (xrc != 0) {       // (the callback is the caller's collective: when it fails it must fail on every rank)
+                g2g_set_error("%s", "g2g_refine: the exchange callback failed"); rc_all = G2G_ERR_DEVICE;
+            } else {
+                for (int r = 0; r < O.world && rc_all == G2G_OK; ++r) {
+                    const int32_t st_r = all[(size_t) r * rank_ints];
+                    if (st_r == G2G_OK) continue;
+                    rc_all = st_r < 0 ? st_r : G2G_ERR_DEVICE;
+                    if (r == O.rank && !local_err.empty()) g2g_set_error("%s", local_err.c_str());
+                    else { char who[96]; snprintf(who, sizeof who, "g2g_refine: rank %d failed (its code is this call's return value)", r); g2g_set_error("%s", who); }
+                }
             }
-            if (seen != ntot) { g2g_set_error("%s", "g2g_refine: the exchange did not return every division of the window"); rc_all = G2G_ERR_DEVICE; for (auto &d : D) free_division(d); break; }
+            int seen = 0;
+            std::vector<char> got((size_t) (ntot > 0 ? ntot : 1), 0);
+            for (int r = 0; r < O.world && rc_all == G2G_OK; ++r)
+                for (int q = 0; q < nslots && rc_all == G2G_OK; ++q) {
+                    const int32_t *s = &all[(size_t) r * rank_ints + 2 + (size_t) q * slot_ints];
+                    if (s[0] < 0) continue;                                                     // an unused slot
+                    // slot contents crossed a process boundary: nothing in them is trusted
+                    if (s[0] >= ntot || got[s[0]] || s[2] < 2 || s[2] > O.slot_cap) {
+                        g2g_set_error("%s", "g2g_refine: the exchange returned a malformed slot"); rc_all = G2G_ERR_DEVICE; break;
+                    }
+                    got[s[0]] = 1;
+                    Division &d = D[live[s[0]]];
+                    memcpy(&d.scr, s + 3, 8); memcpy(&d.val_old, s + 5, 8); memcpy(&d.val_new, s + 7, 8);
+                    d.neu.resize((size_t) s[2]);
+                    for (int k = 0; k < s[2]; ++k) { d.neu[k].m = s[9 + 2 * k]; d.neu[k].n = s[10 + 2 * k]; }
+                    ++seen;
+                }
+            if (rc_all == G2G_OK && seen != ntot) { g2g_set_error("%s", "g2g_refine: the exchange did not return every division of the window"); rc_all = G2G_ERR_DEVICE; }
+        } else if (local_rc != G2G_OK) {
+            g2g_set_error("%s", local_err.c_str());
+            rc_all = local_rc;
         }
+        if (rc_all != G2G_OK) { for (auto &d : D) free_division(d); break; }
         for (int k : live) {
             Division &d = D[k];
             bool same = d.neu.size() == d.old.size();
@@ -390,8 +487,9 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
             log.push_back(e);
             if (ok) {
                 Msa N;
-                if (!join_columns(d, d.neu_ab, many, N)) { g2g_set_error("%s", "g2g_refine: a skeleton segment is neither diagonal nor a gap"); rc_all = G2G_ERR_DEVICE; break; }
+                if (!join_columns(d, d.neu_ab, many, N)) { g2g_set_error("%s", "g2g_refine: a skeleton does not describe an alignment of its two groups"); rc_all = G2G_ERR_DEVICE; break; }
                 M.len = N.len; M.c.swap(N.c);
+                if (O.on_accept) O.on_accept(O.on_accept_user, d.branch, (int) d.la.size(), d.la.data(), (int) d.lb.size(), d.lb.data(), (int) d.neu_ab.size(), d.neu_ab.data());
                 nrep = 1; accepted = true; ++S.accepted;
                 break;
             }
@@ -402,12 +500,17 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
         for (auto &d : D) free_division(d);
         pending.erase(pending.begin(), pending.begin() + consumed);
         if (rc_all != G2G_OK || nrep >= cycle) break;
-        win = accepted ? 2 : std::min(O.window, 2 * win);
+        win = accepted ? O.window_min : std::min(O.window, 2 * win);
     }
     if (rc_all != G2G_OK) return rc_all;
     t_rest = now() - t_begin - t_build - t_align - t_sp;
     if (getenv("G2G_REFINE_TIMES")) fprintf(stderr, "[g2g_refine] %d batches: build %.0f ms, align2 %.0f ms, calcSpScore %.0f ms, rest %.0f ms\n", S.batches, t_build, t_align, t_sp, t_rest);
     S.divisions = (int) log.size();
+    if (ctx) {        // waits of the DP scheduler that ran into their limit during this call, and the DPs re-run for it (0 in an ordinary run)
+        long long cnt1[4] = {0, 0, 0, 0};
+        g2g_ctx_counters(ctx, cnt1);
+        S.wait_timeouts = (int) (cnt1[1] - cnt0[1]); S.recovered_dps = (int) (cnt1[2] - cnt0[2]);
+    }
     *out_len = M.len;
     *out_codes = (uint8_t *) malloc(M.c.size() ? M.c.size() : 1);
     if (!*out_codes) return G2G_ERR_NOMEM;

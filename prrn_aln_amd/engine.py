@@ -38,6 +38,12 @@ class Context:
         v = lib().g2g_get_option(self._h, name.encode())
         return None if v is None else v.decode()
 
+    def counters(self) -> dict:
+        """g2g_ctx_counters: batch runs, waits that ran into the wall-clock limit, DPs re-run after one, DPs that needed v1"""
+        out = (C.c_longlong * 4)()
+        lib().g2g_ctx_counters(self._h, out)
+        return {"runs": out[0], "wait_timeouts": out[1], "recovered_dps": out[2], "recovered_on_v1": out[3]}
+
     def close(self):
         if self._h:
             lib().g2g_destroy(self._h)
@@ -109,6 +115,12 @@ class Batch:
 
     def cells(self) -> int:
         return lib().g2g_batch_cells(self._h)
+
+    def recovery(self) -> Tuple[int, int, int]:
+        """(waits that gave up in the last run, DPs re-run in the last run, DPs re-run over the batch's life)"""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        lib().g2g_batch_recovery(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
 
     def arena_bytes(self) -> int:
         return lib().g2g_batch_arena_bytes(self._h)

@@ -27,20 +27,21 @@ def test_exports_every_declared_symbol(built):
 
 def test_abi_version(built):
     L = C.CDLL(built)
-    assert L.g2g_abi_version() == 3
+    assert L.g2g_abi_version() == 4
 
 
 def test_struct_sizes_match_header(built):
     # guards the ctypes mirror against drift: compile a probe against the header
     import subprocess, tempfile
-    src = '#include <stdio.h>\n#include "g2g.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(g2g_problem), sizeof(g2g_side), sizeof(g2g_gapprof), sizeof(g2g_result), sizeof(g2g_params));}'
+    src = '#include <stdio.h>\n#include "g2g.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(g2g_problem), sizeof(g2g_side), sizeof(g2g_gapprof), sizeof(g2g_result), sizeof(g2g_params)); printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(g2g_refine_opts), sizeof(g2g_refine_step), sizeof(g2g_refine_stats), sizeof(g2g_tree), sizeof(g2g_spparams), sizeof(g2g_fstat));}'
     with tempfile.TemporaryDirectory() as td:
         open(os.path.join(td, "p.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(td, "p"), os.path.join(td, "p.c")])
         out = subprocess.check_output([os.path.join(td, "p")]).decode().split()
     from prrn_aln_amd import _abi
     assert [int(x) for x in out] == [C.sizeof(_abi.Problem), C.sizeof(_abi.Side), C.sizeof(_abi.GapProf),
-                                     C.sizeof(_abi.Result), C.sizeof(_abi.Params)]
+                                     C.sizeof(_abi.Result), C.sizeof(_abi.Params), C.sizeof(_abi.RefineOpts), C.sizeof(_abi.RefineStep),
+                                     C.sizeof(_abi.RefineStats), C.sizeof(_abi.Tree), C.sizeof(_abi.SpParams), C.sizeof(_abi.Fstat)]
 
 
 def test_stdskl_host_matches_reference(built):

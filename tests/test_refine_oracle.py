@@ -1,61 +1,66 @@
-"""The refinement trajectory of the reference (tests/golden/refine_*.json) re-walked on the CPU with the ORACLE doing the DPs
-and the sum-of-pairs scores: host builders + oracle forwardB / stdskl / calcSpScore + the division logic of
-prrn_aln_amd.refine must give bit-identical (DP score, fstat.val) at every align2() of the reference's loop, accept exactly
-the moves it accepted and end in its final MSA.  (The GPU walks the same trajectory in tests/test_gpu_refine.py.)"""
-import glob
-import json
-import os
-
+"""The refinement trajectory of the reference (tests/golden/refine_*.json) re-walked on the CPU: g2g_refine -- the product's
+C++ loop behind the C ABI (csrc/g2g_refine.cpp: Randiv order, divisions read off the MSA matrix, windows of speculative
+divisions, in-order acceptance) with the host builders -- and the ORACLE in the scorer's seat (forwardB / stdskl / calcSpScore
+on the CPU; the GPU needs a GPU).  It must give bit-identical (DP score, fstat.val) at every align2() of the reference's loop,
+accept exactly the moves it accepted (member lists and skeletons) and end in its final MSA.  The GPU walks the same
+trajectories in tests/test_gpu_refine.py."""
 import numpy as np
 import pytest
 
-import oraclelib
-from prrn_aln_amd import operator as op
-from prrn_aln_amd.refine import KTree, TreeDivisions, join_columns, lt0, split_columns
+import refinelib
+from prrn_aln_amd._lib import G2GError
+from prrn_aln_amd.refine import KTree, refine_native
 
-FIX = [p for p in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "refine_*.json"))) if "48x300" not in p]      # (the 48 x 300 trace is the GPU tests': 930 DPs are minutes on the CPU oracle)
+FIX = refinelib.fixtures(small_only=True)      # (the 48 x 300 and 256 x 1024 traces are the GPU tests': minutes to hours on the CPU oracle)
 
 
-@pytest.mark.parametrize("path", FIX, ids=[os.path.basename(p)[7:-5] for p in FIX])
-def test_oracle_walks_the_reference_trajectory(path):
-    L = oraclelib.load()
-    f = json.load(open(path))
-    t = f["tree"]
-    tree = KTree(t["left"], t["right"], t["parent"], t["vol"], t["cur"])
-    alp = op.AlnParam(ls=f["ls"], molc=f["molc"], max_code=25 if f["molc"] == 1 else 17)
-    codes = op.encode(f["rows"], f["molc"])
-    td = TreeDivisions(tree, 1)
-    calls, acc = 0, 0
-    for br in f["branches"]:
-        assert td.next() == br
-        la, lb = td.members(br)
-        pwt, w = tree.calcfact(br)
-        a, b, skl0 = split_columns(codes, la, lb)
-        if len(a) == len(codes) and len(b) == len(codes):
-            continue                                          # nothing to re-align: the reference makes no align2 call
-        wa = w[la] if len(la) > 1 else np.ones(1)
-        wb = w[lb] if len(lb) > 1 else np.ones(1)
-        pw = op.PwdM([op.mSeq(a, alp, wa), op.mSeq(b, alp, wb)], alp)
+@pytest.mark.parametrize("path", FIX, ids=[refinelib.fixture_id(p) for p in FIX])
+def test_native_loop_with_oracle_scorer_walks_the_reference_trajectory(path):
+    f, tree, alp, start = refinelib.load(path)
+    final, steps, stats = refine_native(None, start, tree, alp, seed=1, maxitr=10, window=8, scorer=refinelib.oracle_scorer(), want_moves=True)
+    refinelib.check_against_trace(f, final, steps, stats)
+    assert stats["batches"] < len(f["align2"])                        # the DPs really were evaluated in windows
+    assert stats["wait_timeouts"] == 0 and stats["recovered_dps"] == 0
 
-        class H:
-            c = pw.problem
-        scr, cells, tr = oraclelib.forward(L, H)
-        skl = oraclelib.stdskl(L, tr)
-        old = skl0[:, ::-1].copy() if pw.swp else skl0
-        sp = op.spparams(pw)
-        rc0, _, _, raw_old = oraclelib.spscore_raw(L, H, sp, old)
-        rc1, val_new, _ = oraclelib.spscore(L, H, sp, skl)
-        assert rc0 == 0 and rc1 == 0
-        ref = f["align2"][calls]
-        calls += 1
-        assert scr == ref["scr"] and val_new == ref["val"] and int(pw.swp) == ref["swp"], (br, scr, ref)
-        same = skl.shape == old.shape and np.array_equal(skl, old)
-        delta = 0.0 if same else pwt * (val_new - raw_old)    # Prrn::onecycle, src/prrn5.cc:535 (the old score is not rescaled)
-        if lt0(delta):
-            skl1 = skl[:, ::-1].copy() if pw.swp else skl
-            mv = f["accepted"][acc]
-            acc += 1
-            assert mv["lst0"] == list(la) and mv["lst1"] == list(lb) and np.array_equal(np.asarray(mv["skl"]), skl1)
-            codes = join_columns(a, b, skl1, la, lb, codes.shape[1])
-    assert calls == len(f["align2"]) and acc == len(f["accepted"])
-    assert np.array_equal(codes, op.encode(f["final_rows"], f["molc"]))
+
+def test_window_policy_does_not_change_the_trajectory():
+    """Speculation only decides how many divisions are evaluated together: any (window_min, window) walks the same trajectory."""
+    f, tree, alp, start = refinelib.load(FIX[0])
+    for wmin, wmax in ((1, 1), (4, 4), (2, 32)):
+        final, steps, stats = refine_native(None, start, tree, alp, window=wmax, window_min=wmin, scorer=refinelib.oracle_scorer())
+        refinelib.check_against_trace(f, final, steps, stats)
+        if wmax == 1:
+            assert stats["divisions_wasted"] == 0
+
+
+def _bad(tree, **kw):
+    d = dict(left=list(tree.left), right=list(tree.right), parent=list(tree.parent), vol=list(tree.vol), cur=list(tree.cur))
+    for k, (i, v) in kw.items():
+        d[k][i] = v
+    return KTree(**d)
+
+
+def test_malformed_trees_are_refused():
+    """The tree crosses the C ABI: index ranges, leaf / inner shape, parent-child consistency, a single root, no cycle, vol > 0."""
+    f, tree, alp, start = refinelib.load(FIX[0])
+    n = tree.n_leaves
+    root = tree.parent.index(-1)
+    inner = next(k for k in range(n, len(tree.left)) if k != root)
+    cases = [
+        _bad(tree, left=(inner, len(tree.left) + 5)),              # child index out of range
+        _bad(tree, left=(0, 1)),                                    # a leaf with a child
+        _bad(tree, parent=(inner, inner)),                          # a node that is its own parent (cycle)
+        _bad(tree, parent=(inner, -1)),                             # two roots
+        _bad(tree, vol=(inner, 0.0)),                               # a volume that would divide by zero
+        _bad(tree, right=(inner, tree.left[inner])),                # both children the same node
+    ]
+    for t in cases:
+        with pytest.raises(G2GError) as e:
+            refine_native(None, start, t, alp, scorer=refinelib.oracle_scorer())
+        assert "rc=-" in str(e.value)
+
+
+def test_a_failing_scorer_fails_the_call():
+    f, tree, alp, start = refinelib.load(FIX[0])
+    with pytest.raises(G2GError):
+        refine_native(None, start, tree, alp, window=4, scorer=refinelib.oracle_scorer(fail_after=3))

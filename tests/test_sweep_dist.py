@@ -73,49 +73,43 @@ def test_two_rank_gloo_allgather():
         assert r["ok"], r
 
 
-# ---- a sharded refinement: two gloo ranks, each scoring half of every window, must hold the same MSA at the end --------
-REFINE_WORKER = r'''
+# ---- a sharded refinement: two gloo ranks run g2g_refine (the product's C++ loop) with the exchange callback on
+# torch.distributed; each scores half of every window (the CPU checker in the scorer's seat: no GPU here) and both must hold
+# the reference's final MSA at the end.  With FAIL_RANK set, that rank's scorer fails in its third window: BOTH ranks must
+# come back with the same error code -- a rank that fails locally still enters the collective (g2g.h).
+REFINE_WORKER = r"""
 import os, sys, json, hashlib
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
 import numpy as np, torch.distributed as dist
-import oraclelib
-from prrn_aln_amd import operator as op
-from prrn_aln_amd.refine import KTree, Refiner, Exchange
-dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
-f = json.load(open({fixture!r})); t = f["tree"]
-tree = KTree(t["left"], t["right"], t["parent"], t["vol"], t["cur"])
-alp = op.AlnParam(ls=f["ls"], molc=f["molc"], max_code=25 if f["molc"] == 1 else 17)
-L = oraclelib.load()
-def oracle_scorer(divs):          # (the DP needs a GPU: in this CPU test the CHECKER stands in for it)
-    out = []
-    for d in divs:
-        class H: c = d["pw"].problem
-        scr, cells, tr = oraclelib.forward(L, H)
-        skl = oraclelib.stdskl(L, tr)
-        sp = op.spparams(d["pw"])
-        raw_old = oraclelib.spscore_raw(L, H, sp, d["old"])[3]
-        val_new = oraclelib.spscore(L, H, sp, skl)[1]
-        out.append((scr, skl, raw_old, val_new))
-    return out
-r = Refiner(None, op.encode(f["rows"], f["molc"]), tree, alp, window=8, scorer=oracle_scorer, exchange=Exchange(cap=1024))
-final = r.run()
-want = op.encode(f["final_rows"], f["molc"])
-acc = [s for s in r.steps if s.accepted]
-dps = sum(1 for s in r.steps if s.delta != float("-inf"))
+import refinelib
+from prrn_aln_amd._lib import G2GError
+from prrn_aln_amd.refine import refine_native, torch_exchange
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", rank=rank, world_size=int(os.environ["WORLD_SIZE"]))
+f, tree, alp, start = refinelib.load({fixture!r})
+fail = int(os.environ.get("FAIL_RANK", "-1")) == rank
+res = {{"rank": rank}}
+try:
+    final, steps, stats = refine_native(None, start, tree, alp, window=8, exchange=torch_exchange(), slot_cap=1024,
+                                        scorer=refinelib.oracle_scorer(fail_after=2 if fail else -1))
+    refinelib.check_against_trace(f, final, steps, stats)
+    res.update(ok=True, digest=hashlib.sha1(final.tobytes()).hexdigest(), scored_here=stats["divisions_scored_here"],
+               dps=sum(1 for s in steps if not s["skipped"]))
+except G2GError as e:
+    res.update(ok=False, error=str(e))
 dist.barrier(); dist.destroy_process_group()
-print(json.dumps({{"rank": int(os.environ["RANK"]), "same_as_reference": bool(np.array_equal(final, want)), "accepted": len(acc),
-                  "want_accepted": len(f["accepted"]), "digest": hashlib.sha1(final.tobytes()).hexdigest(), "scored_here": r.scored_here, "dps": dps}}))
-'''
+print(json.dumps(res))
+"""
 
 
-def test_two_rank_sharded_refinement_same_msa_on_every_rank():
+def _run_ranks(extra_env):
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     fixture = os.path.join(root, "tests", "golden", "refine_prot12x80_s3.json")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **extra_env)
         procs.append(subprocess.Popen([sys.executable, "-c", REFINE_WORKER.format(root=root, fixture=fixture)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE))
     outs = []
@@ -123,6 +117,19 @@ def test_two_rank_sharded_refinement_same_msa_on_every_rank():
         out, err = p.communicate(timeout=600)
         assert p.returncode == 0, err.decode()[-2000:]
         outs.append(json.loads(out.decode().strip().splitlines()[-1]))
-    assert all(o["same_as_reference"] and o["accepted"] == o["want_accepted"] for o in outs), outs
+    return outs
+
+
+def test_two_rank_sharded_refinement_same_msa_on_every_rank():
+    outs = _run_ranks({})
+    assert all(o["ok"] for o in outs), outs
     assert outs[0]["digest"] == outs[1]["digest"]
-    assert all(0 < o["scored_here"] < o["dps"] + 200 for o in outs) and outs[0]["scored_here"] != 0 and outs[1]["scored_here"] != 0
+    assert all(0 < o["scored_here"] < o["dps"] for o in outs), outs          # the work really was split
+
+
+def test_a_rank_local_failure_ends_every_rank_with_the_same_code():
+    outs = _run_ranks({"FAIL_RANK": "1"})
+    assert not any(o["ok"] for o in outs), outs                               # nobody hangs in the collective, nobody "succeeds"
+    codes = [o["error"].split("rc=")[1].split(":")[0] for o in outs]
+    assert codes[0] == codes[1] != "0", outs
+    assert "rank 1 failed" in outs[0]["error"]                                # rank 0 knows who
