@@ -317,6 +317,7 @@ typedef struct g2g_refine_opts {
 typedef struct g2g_refine_step {
     int32_t branch, na, nb, swp, accepted, skipped;   /* skipped: neither group had a column to drop -- no DP (prrn5.cc:497) */
     double  scr, val_new, val_old, delta;             /* DP score; fstat.val of the new alignment; raw score of the current one */
+    double  t_ms;                                     /* wall clock since the call began when this division's window had been scored */
 } g2g_refine_step;
 typedef struct g2g_refine_stats {
     int32_t divisions, accepted, batches, divisions_scored_here, divisions_wasted;

@@ -95,7 +95,8 @@ class RefineOpts(C.Structure):
 
 class RefineStep(C.Structure):
     _fields_ = [("branch", C.c_int32), ("na", C.c_int32), ("nb", C.c_int32), ("swp", C.c_int32), ("accepted", C.c_int32),
-                ("skipped", C.c_int32), ("scr", C.c_double), ("val_new", C.c_double), ("val_old", C.c_double), ("delta", C.c_double)]
+                ("skipped", C.c_int32), ("scr", C.c_double), ("val_new", C.c_double), ("val_old", C.c_double), ("delta", C.c_double),
+                ("t_ms", C.c_double)]
 
 
 class RefineStats(C.Structure):

@@ -12,6 +12,20 @@
 #define G2G_DEVICE_H_
 #include <stdint.h>
 
+// The library is built from several translation units (prrn_aln_amd/build.py compiles them side by side): every unit sees every
+// device function, but EMITS only the kernels of its own group and merely declares the others -- the host stubs are ordinary
+// symbols, resolved at link time.  G2G_TU_ALL puts everything into one unit (what a one-off resource listing wants).
+//   G2G_TU_V1  g2g_forward_kernel, g2g_traceback_kernel, g2g_spscore_kernel + the f3 / pairsum kernels (the engine's own unit)
+//   G2G_TU_V2  the 8-lanes-per-cell strips and the tile-mode helpers     G2G_TU_V3  _hf strips
+//   G2G_TU_V6  _pf strips                                               G2G_TU_V78 strips of the records without gap profiles
+#ifdef G2G_TU_ALL
+#define G2G_TU_V1 1
+#define G2G_TU_V2 1
+#define G2G_TU_V3 1
+#define G2G_TU_V6 1
+#define G2G_TU_V78 1
+#endif
+
 struct DevSide {
     int many, len, left, right, nils, nelm, felm, hetero;
     int maxlist;         // longest static gap-profile list incl. its terminator (any view, any position)

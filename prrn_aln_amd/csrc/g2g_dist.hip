@@ -32,6 +32,70 @@ __device__ __forceinline__ void dist_sync()
     if (INLDS) team_sync();
     else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __builtin_amdgcn_wave_barrier(); }
 }
+// ---- the boundary: a terminal gap of k residues in front of the other sequence --------------------------------------------
+// The reference prices it by accumulation: start at -v * lt, add -u * lt once per residue (Fwd2d::Fwd2d, fwd2d1.cc:58-93; lt =
+// tgapf where the gap hangs over the sequence's true end, 1 inside a larger sequence), so slot k holds the k-fold ROUNDED sum.
+// When no partial sum can round -- both terms are multiples of some 2^q and the largest sum stays below 2^(q+52) -- the k-th
+// value is exactly start + k * step and every lane writes its own slots (the ordinary case: u, v small dyadic numbers, tgapf
+// 1, 0.5 or 0); otherwise one lane accumulates in order, which is the only way to reproduce the rounding.
+__device__ __forceinline__ int dist_low_bit(const double x)              // binary weight of the lowest set bit of x (large when x == 0)
+{
+    const long long bits = __double_as_longlong(x);
+    const int ex = (int) ((bits >> 52) & 0x7FF);
+    const long long frac = bits & ((1LL << 52) - 1);
+    if (ex == 0) return frac ? -100000 : 100000;                          // subnormal: never "exact"; zero: no constraint
+    return ex - 1075 + __ffsll((frac | (1LL << 52))) - 1;
+}
+__device__ __forceinline__ bool dist_sums_exact(const double start, const double step, const int count)
+{
+    const int q = min(dist_low_bit(start), dist_low_bit(step));
+    if (q <= -100000) return false;
+    if (q >= 100000) return true;                                         // both zero
+    const double reach = fabs(start) + (double) (count + 1) * fabs(step);
+    return reach < ldexp(1.0, q + 52);
+}
+template <class PTR>
+__device__ __forceinline__ void dist_edge(PTR hh, const int r0, const int count, const int dir, const double lt, const double uu,
+                                          const double vv, const int lane)
+{
+    const double start = -vv * lt, step = -uu * lt;
+    if (dist_sums_exact(start, step, count)) {
+        for (int k = 1 + lane; k <= count; k += 64) hh[r0 + dir * k] = start + (double) k * step;
+    } else if (lane == 0) {
+        double acc = start;
+        for (int k = 1; k <= count; ++k) { acc += step; hh[r0 + dir * k] = acc; }
+    }
+}
+
+// ---- the end: a terminal gap BEHIND one of the sequences, discounted by tgapf (Fwd2d::lastD, fwd2d1.cc:100-134) --------------
+// Along the last column (and, mirrored, the last row) the best score may end in a terminal gap: walking towards the end corner,
+// the candidate carried so far pays rt * (v + u) for the first residue of such a gap and rt * u for each further one, and a
+// cell replaces it when its own score is at least as good (which also ends the gap: the next residue opens a new one).  The
+// walk is a chain of rounded additions with a data-dependent restart, so it cannot be reassociated; what CAN be wave-wide is
+// the memory side: 64 cells are loaded with one access, the chain runs through them in registers (readlane of the cell, the
+// carried pair (value, in-gap) is wave-uniform), nothing is written back -- the reference's stores into the neighbour slot are
+// only ever read by the next step of the same walk.  Returns the carried value after the last cell of [from, to] (to = the
+// cell next to the end corner), starting from the value at `origin`.
+struct DistCarry { double val; bool in_gap; };
+template <class PTR>
+__device__ __forceinline__ DistCarry dist_tail_walk(PTR hh, const int origin, const int ncell, const int dir, const double first, const double more, const int lane)
+{
+    DistCarry c;
+    c.val = hh[origin]; c.in_gap = false;
+    for (int base = 0; base < ncell; base += 64) {
+        const int cnt = ncell - base < 64 ? ncell - base : 64;
+        const double x = lane < cnt ? hh[origin + dir * (base + lane + 1)] : 0.;
+        const int xlo = __double2loint(x), xhi = __double2hiint(x);
+        for (int j = 0; j < cnt; ++j) {
+            const double cell = __hiloint2double(__builtin_amdgcn_readlane(xhi, j), __builtin_amdgcn_readlane(xlo, j));
+            const double ext = c.val + (c.in_gap ? more : first);
+            c.in_gap = cell < ext;                                        // (a tie goes to the cell: the gap ends)
+            c.val = c.in_gap ? ext : cell;
+        }
+    }
+    return c;
+}
+
 template <class PTR, bool INLDS>
 __device__ __forceinline__ void dist_pair(const DistArgs &A, const int pair, PTR base, const lf64 *mtx, const int lane)
 {
@@ -49,22 +113,13 @@ __device__ __forceinline__ void dist_pair(const DistArgs &A, const int pair, PTR
     const int width = up - lw + 3;
     PTR hh = base - lw + 1, ff = hh + width, gg = ff + width;
     const double uu = A.uu, vv = A.vv;
-    // Fwd2d::Fwd2d :58-93: the two boundary ramps are running sums -> one lane each
+    // the state before the first anti-diagonal: no gap record anywhere, the start diagonal at 0, leading terminal gaps on either
+    // side of it, "never" just outside the band
     const int r0 = bl - al;
     for (int r = lw - 1 + lane; r < lw - 1 + width; r += 64) { ff[r] = NEVSEL; gg[r] = NEVSEL; }
-    if (lane == 0) {
-        hh[r0] = 0;
-        const double lt = al ? 1. : A.tgapf;
-        double gp = -vv * lt; const double ge = -uu * lt;
-        for (int r = r0 + 1; r <= up; ++r) hh[r] = gp += ge;
-        hh[up + 1] = DIST_NEG_INT;
-    }
-    if (lane == 1) {
-        const double lt = bl ? 1. : A.tgapf;
-        double gp = -vv * lt; const double ge = -uu * lt;
-        for (int r = r0 - 1; r >= lw; --r) hh[r] = gp += ge;
-        hh[lw - 1] = DIST_NEG_INT;
-    }
+    if (lane == 0) { hh[r0] = 0; hh[up + 1] = DIST_NEG_INT; hh[lw - 1] = DIST_NEG_INT; }
+    dist_edge(hh, r0, up - r0, +1, al ? 1. : A.tgapf, uu, vv, lane);
+    dist_edge(hh, r0, r0 - lw, -1, bl ? 1. : A.tgapf, uu, vv, lane);
     dist_sync<INLDS>();
     // forwardD :136-158
     const int simdim = A.simdim;
@@ -90,36 +145,31 @@ __device__ __forceinline__ void dist_pair(const DistArgs &A, const int pair, PTR
         }
         dist_sync<INLDS>();
     }
-    // lastD :100-134
-    if (lane == 0) {
-        PTR h9 = hh + (br - ar);
+    // the end corner, with discounted terminal gaps behind either sequence when tgapf < 1
+    {
+        const int rend = br - ar;
         const double rt = A.tgapf;
-        if (br == sb.len && rt < 1) {
-            int dm = 0, rw = up + 1;
-            if (br - al < rw) rw = br - al;
-            PTR h = hh + rw;
-            while (--h >= h9) {
-                ++dm;
-                const double gpn = dm == 1 ? vv + uu : uu;
-                PTR g = h + 1;
-                *g += gpn * rt;
-                if (*h < *g) *h = *g; else dm = 0;
+        const double first = (vv + uu) * rt, more = uu * rt;
+        double best = hh[rend];
+        if (br == sb.len && rt < 1) {                              // b is used up: the rest of a hangs over (the last column, towards larger m)
+            int from = up + 1;
+            if (br - al < from) from = br - al;
+            if (from > rend) {
+                const DistCarry c = dist_tail_walk(hh, from, from - 1 - rend, -1, first, more, lane);
+                const double ext = c.val + (c.in_gap ? more : first);
+                if (best < ext) best = ext;
             }
         }
-        if (ar == sa.len && rt < 1) {
-            int dn = 0, rw = lw;
-            if (bl - ar + 1 > rw) rw = bl - ar + 1;
-            PTR h = hh + rw;
-            while (++h <= h9) {
-                ++dn;
-                const double gpn = dn == 1 ? vv + uu : uu;
-                PTR f = h - 1;
-                *f += gpn * rt;
-                if (*h < *f) *h = *f; else dn = 0;
+        if (ar == sa.len && rt < 1) {                              // a is used up: the rest of b hangs over (the last row)
+            int from = lw;
+            if (bl - ar + 1 > from) from = bl - ar + 1;
+            if (from < rend) {
+                const DistCarry c = dist_tail_walk(hh, from, rend - 1 - from, +1, first, more, lane);
+                const double ext = c.val + (c.in_gap ? more : first);
+                if (best < ext) best = ext;
             }
         }
-        A.score[pair] = *h9;
-        A.status[pair] = 0;
+        if (lane == 0) { A.score[pair] = best; A.status[pair] = 0; }
     }
     dist_sync<INLDS>();
 }

@@ -12,6 +12,9 @@
 #include <atomic>
 #include <algorithm>
 #include <chrono>
+#ifndef G2G_TU_ALL
+#define G2G_TU_V1 1                 // this unit emits the v1 / traceback / calcSpScore kernels and the f3 / pairsum kernels; the strip
+#endif                              // kernels come from the g2g_tu_*.hip units (g2g_device.h)
 #include "../../include/g2g.h"
 #include "g2g_device.h"
 #include "g2g_internal.h"
@@ -234,6 +237,7 @@ struct g2g_batch {
     int *d_idx1, *d_idx2;           // problems run by the v1 / v2 forward kernel
     int *d_idxp; int np;            // problems whose boundary chains run in the prologue kernel (the others: as queue entries)
     int n1, n2;
+    int nsimmat;                    // DPs that read a column-score matrix (tile-mode test configurations): only then the matrix kernels run
     size_t lds2;                    // dynamic LDS bytes of the v2 launch
     size_t lds2p;                   // ... of the v2 prologue launch
     int v2_maxrows;                 // longest a-range among the v2 problems
@@ -557,6 +561,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
     for (int k = 0; k < 24; ++k) { b->simscr[k] = 0; b->simscr_cap[k] = 0; }
     b->src.assign(prob, prob + n); b->fail_off = 0; b->force_v1 = force_v1; b->is_retry = false; b->n_recovered = 0;
     b->recovered.assign(n, g2g_result()); b->was_recovered.assign(n, 0);
+    b->nsimmat = 0;
     b->last_timeouts = b->last_recovered = 0;
     b->v3_cols = 128; b->v2_cols = G2G_V2_TILE_COLS;
 
@@ -711,9 +716,9 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         }
         if ((d.kind == 1 || d.kind == 2) && !force_v1 && !g2g_opt(ctx, "FORCE_V1") && p->a.len + p->b.len < 65000) {
             // _pf: one lane per cell with rank-form merges (v6) when the rows' static lists fit the register file
-            if (b->v6_on && !g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_V6") && !g2g_opt(ctx, "V3_PF") && d.kind == 2 && d.a.maxlist <= G2G_V6_NA && d.a.r_from_t &&
+            if (b->v6_on && !g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_V6") && d.kind == 2 && d.a.maxlist <= G2G_V6_NA && d.a.r_from_t &&
                 v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(p)).total <= std::max(V6_SMALL_LDS, V6_LARGE_LDS)) d.v2_ok = 6;
-            else if (!g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_AREG") && (d.kind == 1 || g2g_opt(ctx, "V3_PF")) && d.a.maxlist <= G2G_V3_NA &&
+            else if (!g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_AREG") && d.kind == 1 && d.a.maxlist <= G2G_V3_NA &&
                 v3_need(d, p, b->v3_cols, true).total <= (int) V2_LDS_MAX) d.v2_ok = 3;
             else {
                 // lists too long for registers: the LDS-list one-lane-per-cell kernel, unless its LDS footprint leaves fewer than
@@ -723,7 +728,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
                 // group has columns, so sides of 32768 columns or more are not eligible -- they stay on v3 / v1, which keep 32 bits)
                 const bool v2fit = std::max(p->a.len, p->b.len) < 32768 &&
                     v2_lds_bytes(d.kind, d.noll, d.capa, d.capb, d.a.maxlist, d.b.maxlist, b->v2_threads) + 4 * b->v2_threads <= V2_LDS_MAX;
-                const int v3tot = (!g2g_opt(ctx, "FORCE_V2") && (d.kind == 1 || g2g_opt(ctx, "V3_PF"))) ? v3_need(d, p, b->v3_cols).total : (int) V2_LDS_MAX + 1;
+                const int v3tot = (!g2g_opt(ctx, "FORCE_V2") && d.kind == 1) ? v3_need(d, p, b->v3_cols).total : (int) V2_LDS_MAX + 1;
                 if (v3tot <= (int) V2_LDS_MAX && (v3tot <= (int) V2_LDS_MAX / 3 || !v2fit || g2g_opt(ctx, "NO_AREG"))) d.v2_ok = 2;
                 else if (v2fit) d.v2_ok = 1;
             }
@@ -748,7 +753,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
             d.v2_rowoff = OFF<long long>(take(sizeof(long long) * ((size_t) (ar - al) + 2)));
             // the column-score matrix: only for DPs whose kernel reads one (strips in sweep mode make their own, block by block)
             const bool own_sim = !g2g_opt(ctx, "NO_SIMBLK") && (d.v2_ok >= 6 || (d.v2_ok == 1 && b->v2_sweep) || ((d.v2_ok == 2 || d.v2_ok == 3) && d.kind == 1 && b->v3_sweep));
-            if (!own_sim) d.v2_sim = OFF<double>(take(sizeof(double) * (size_t) cells + 64));
+            if (!own_sim) { d.v2_sim = OFF<double>(take(sizeof(double) * (size_t) cells + 64)); ++b->nsimmat; }
         }
         b->rr1[i] = (long long) (bl_ - al) + (br - ar);
         d.tcap = (ar - al) + (br - bl_) + 4;
@@ -957,36 +962,43 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_pf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * T2));
             HIPCHK(hipFuncSetAttribute((const void *) g2g_v2_pf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->lds2 + 4 * T2));
         }
-        // row offsets first (tiny), then the boundary chains (single-lane, latency-bound) on a side stream while the
-        // score kernel (fully parallel) fills the GPU on the main one
-        hipLaunchKernelGGL(g2g_v2_rowoff_kernel, dim3((b->n2 + 63) / 64), dim3(64), 0, ctx->stream,
-                           (const DevProb *) b->d_probs, (const int *) b->d_idx2, b->n2);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(ctx->vev[4], ctx->stream));
-        HIPCHK(hipStreamWaitEvent(ctx->vstream[3], ctx->vev[4], 0));
+        // Tile-mode DPs (test configurations; sweep mode, the default, needs none of this) read a column-score matrix and take
+        // their boundary chains from a prologue kernel: row offsets first (tiny), then the chains (single-lane, latency-bound) on
+        // a side stream while the score kernels (fully parallel) fill the GPU on the main one
         const int pro_off = g2g_opt(ctx, "NO_PROSTAGE") ? 0 : (int) ((b->lds2p + 15) & ~(size_t) 15);
-        if (b->np) {
-            hipLaunchKernelGGL(g2g_v2_prologue_kernel, dim3(b->np), dim3(128), pro_off ? pro_off + 2 * PRO_LDS_BYTES : b->lds2p, ctx->vstream[3],
-                               (const DevProb *) b->d_probs, (const int *) b->d_idxp, pro_off);
-            HIPCHK(hipGetLastError());
+        if (b->nsimmat || b->np) {
+            if (b->nsimmat) {
+                hipLaunchKernelGGL(g2g_v2_rowoff_kernel, dim3((b->n2 + 63) / 64), dim3(64), 0, ctx->stream,
+                                   (const DevProb *) b->d_probs, (const int *) b->d_idx2, b->n2);
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(hipEventRecord(ctx->vev[4], ctx->stream));
+            HIPCHK(hipStreamWaitEvent(ctx->vstream[3], ctx->vev[4], 0));
+            if (b->np) {
+                hipLaunchKernelGGL(g2g_v2_prologue_kernel, dim3(b->np), dim3(128), pro_off ? pro_off + 2 * PRO_LDS_BYTES : b->lds2p, ctx->vstream[3],
+                                   (const DevProb *) b->d_probs, (const int *) b->d_idxp, pro_off);
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(hipEventRecord(ctx->vev[3], ctx->vstream[3]));
+            if (b->nsimmat) {
+                const int simtiled = (!g2g_opt(ctx, "NO_SIMTILE") && b->simtile_lds && b->simtile_lds <= 64 * 1024) ? 1 : 0;
+                if (simtiled) {
+                    hipLaunchKernelGGL(g2g_v2_sim_tile_kernel, dim3((b->v2_maxcols + SIM_TC - 1) / SIM_TC, (b->v2_maxrows + SIM_TR - 1) / SIM_TR, b->n2), dim3(256),
+                                       b->simtile_lds, ctx->stream, (const DevProb *) b->d_probs, (const int *) b->d_idx2);
+                    HIPCHK(hipGetLastError());
+                }
+                hipLaunchKernelGGL(g2g_v2_sim_kernel, dim3(b->v2_maxrows, b->n2), dim3(256), 0, ctx->stream,
+                                   (const DevProb *) b->d_probs, (const int *) b->d_idx2, simtiled);
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[3], 0));
         }
-        HIPCHK(hipEventRecord(ctx->vev[3], ctx->vstream[3]));
-        const int simtiled = (!g2g_opt(ctx, "NO_SIMTILE") && b->simtile_lds && b->simtile_lds <= 64 * 1024) ? 1 : 0;
-        if (simtiled) {
-            hipLaunchKernelGGL(g2g_v2_sim_tile_kernel, dim3((b->v2_maxcols + SIM_TC - 1) / SIM_TC, (b->v2_maxrows + SIM_TR - 1) / SIM_TR, b->n2), dim3(256),
-                               b->simtile_lds, ctx->stream, (const DevProb *) b->d_probs, (const int *) b->d_idx2);
-            HIPCHK(hipGetLastError());
-        }
-        hipLaunchKernelGGL(g2g_v2_sim_kernel, dim3(b->v2_maxrows, b->n2), dim3(256), 0, ctx->stream,
-                           (const DevProb *) b->d_probs, (const int *) b->d_idx2, simtiled);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[3], 0));
         if (g2g_opt(ctx, "DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[g2g] prologue+sim done: %s\n", hipGetErrorString(e3)); fflush(stderr); }
         // persistent tile / strip kernels: one launch per kernel variant, each on its own stream (they are independent)
         typedef void (*v2k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int, int, int, int, double *);
         static const v2k_t v2k[4] = {g2g_v2_hf2, g2g_v2_hf3, g2g_v2_pf2, g2g_v2_pf3};
         typedef void (*v3k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V3Lds, int, int, int, double *);
-        static const v3k_t v3k[8] = {g2g_v3_hf2, g2g_v3_hf3, g2g_v3_pf2, g2g_v3_pf3, g2g_v3r_hf2, g2g_v3r_hf3, g2g_v3r_pf2, g2g_v3r_pf3};
+        static const v3k_t v3k[8] = {g2g_v3_hf2, g2g_v3_hf3, 0, 0, g2g_v3r_hf2, g2g_v3r_hf3, 0, 0};       // (_pf strips: g2g_v6_*, below)
         // one persistent launch per variant, each on its own stream (they are independent of each other)
         ++b->gen;
         if ((b->gen & 0x7FF) == 0 && b->d_flags) {             // sweep-mode progress counters carry gen & 0x7FF: start over
@@ -1357,7 +1369,7 @@ static size_t problem_bytes(const g2g_ctx *ctx, const g2g_problem *p)
     }
     // trace (1 B per cell) + the column-score matrix (8 B per cell) where a kernel reads one: strips in sweep mode (the
     // default of every tiled kernel) make their own scores
-    const bool matrix = g2g_opt(ctx, "NO_SIMBLK") || g2g_opt(ctx, "V2_SWEEP") || g2g_opt(ctx, "V3_SWEEP") || g2g_opt(ctx, "V3_PF");   // (tile-mode test configurations)
+    const bool matrix = g2g_opt(ctx, "NO_SIMBLK") || g2g_opt(ctx, "V2_SWEEP") || g2g_opt(ctx, "V3_SWEEP");   // (tile-mode test configurations)
     size_t bytes = (size_t) (ar - al + br - bl + 2) * tmax + (matrix ? 8 * (size_t) cells : 0);
     const g2g_side *sd[2] = {&p->a, &p->b};
     for (int k = 0; k < 2; ++k) {

@@ -567,6 +567,7 @@ __device__ void run_forward(const DevProb &P)
     }
 }
 
+#ifdef G2G_TU_V1
 extern "C" __global__ void __launch_bounds__(G2G_FWD_THREADS)
 g2g_forward_kernel(const DevProb *probs, const int *idx)
 {
@@ -588,6 +589,9 @@ g2g_forward_kernel(const DevProb *probs, const int *idx)
         }
     }
 }
+#else
+extern "C" __global__ void g2g_forward_kernel(const DevProb *probs, const int *idx);
+#endif
 
 // ---- backtrack: rebuild what Vmf::traceback(-1) returns (src/vmf.cc:105-120) --------------------
 // The reference appends a record {m, n, ptr} whenever the final H of a cell has dir NEWD/NEWV/NEWH
@@ -607,6 +611,7 @@ __device__ __forceinline__ uint8_t trace_at(const DevProb &P, int m, int n)
 // diagonal's segment), and lane 0 walks inside it until the path leaves the window.  (One lane per DP with 64 DPs
 // in a wave took 30 ms per sweep: every step was an HBM/L2 round trip, serialised over divergent lanes.)
 #define TB_W 64
+#ifdef G2G_TU_V1
 extern "C" __global__ void __launch_bounds__(64) g2g_traceback_kernel(const DevProb *probs, int nprob)
 {
     __shared__ uint8_t win[TB_W][TB_W + 4];
@@ -680,6 +685,9 @@ extern "C" __global__ void __launch_bounds__(64) g2g_traceback_kernel(const DevP
         P.ntrace[1] = rr0;
     }
 }
+#else
+extern "C" __global__ void g2g_traceback_kernel(const DevProb *probs, int nprob);
+#endif
 
 // ---- f1: SpScore<recd_t>::calcSkl (reference src/fspscore.h:202-254; calscr src/fspscore.cc:346-363, 472-541) --------
 // The sum-of-pairs score of the alignment a standardised skeleton describes, re-evaluated along the path: column scores
@@ -1325,6 +1333,7 @@ __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *
     out[2] = scr;
     out[3] = St.mch / sp.vab; out[4] = St.mmc / sp.vab; out[5] = St.unp / sp.vab;     // PwdM::rescale, maln2.cc:249-250
 }
+#ifdef G2G_TU_V1
 extern "C" __global__ void __launch_bounds__(64)
 g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const int2 *skl, const int *skl_off, const int *nskl,
                    double *out, int *status, int *gepws, const long long *gep_off)
@@ -1350,3 +1359,7 @@ g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const
     else sp_calcskl<3>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G);
     status[ip] = 0;
 }
+#else
+extern "C" __global__ void g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const int2 *skl, const int *skl_off, const int *nskl,
+                                              double *out, int *status, int *gepws, const long long *gep_off);
+#endif

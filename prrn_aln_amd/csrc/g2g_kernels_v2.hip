@@ -1165,6 +1165,7 @@ __device__ __forceinline__ void v2_chain_tile(const DevProb &Pmem, lchar *lds, c
 }
 
 // row offsets of the column-score matrix (needed by the score kernel, which then runs beside the chains)
+#ifdef G2G_TU_V2
 extern "C" __global__ void __launch_bounds__(64)
 g2g_v2_rowoff_kernel(const DevProb *probs, const int *idx, int n)
 {
@@ -1180,7 +1181,11 @@ g2g_v2_rowoff_kernel(const DevProb *probs, const int *idx, int n)
     }
     P.v2_rowoff[P.a.right - P.a.left] = o;
 }
+#else
+extern "C" __global__ void g2g_v2_rowoff_kernel(const DevProb *probs, const int *idx, int n);
+#endif
 
+#ifdef G2G_TU_V2
 extern "C" __global__ void __launch_bounds__(128)
 g2g_v2_prologue_kernel(const DevProb *probs, const int *idx, int pro_off)
 {   // pro_off: byte offset of the two list-staging areas in dynamic LDS (0: lists straight from HBM)
@@ -1189,10 +1194,14 @@ g2g_v2_prologue_kernel(const DevProb *probs, const int *idx, int pro_off)
     const DevProb &P = probs[idx[blockIdx.x]];
     if (P.kind == 1) v2_prologue<1>(P, lds, pro_off); else if (P.kind == 2) v2_prologue<2>(P, lds, pro_off);
 }
+#else
+extern "C" __global__ void g2g_v2_prologue_kernel(const DevProb *probs, const int *idx, int pro_off);
+#endif
 
 __host__ __device__ __forceinline__ bool sim_tiled_kind(int k) { return k == 31 || k == 320 || k == 321 || k == 33 || k == 330; }
 // PwdM::sim2 for every in-band cell of the gap-profile DPs (maln.h:160-172, maln2.cc:534-623,1230-1296):
 // independent of the recurrence, so it is computed ahead of it, fully parallel, row-major per DP
+#ifdef G2G_TU_V2
 extern "C" __global__ void __launch_bounds__(256)
 g2g_v2_sim_kernel(const DevProb *probs, const int *idx, int tiled)
 {
@@ -1206,6 +1215,9 @@ g2g_v2_sim_kernel(const DevProb *probs, const int *idx, int tiled)
     double *out = P.v2_sim + P.v2_rowoff[m - P.a.left] - nlo;
     for (int n = nlo + threadIdx.x; n < nhi; n += blockDim.x) out[n] = sim2(P, m, n);
 }
+#else
+extern "C" __global__ void g2g_v2_sim_kernel(const DevProb *probs, const int *idx, int tiled);
+#endif
 
 // The same for the scorers of the gap-profile engines -- sim31, sim32i/w (profile of a x residues of b) and sim33/33_n
 // (profile of a . frequency vector of b) -- TILED: a block owns 32 rows x 128 columns, stages the 32 profile rows of a
@@ -1238,6 +1250,7 @@ __device__ __forceinline__ void sim_tile_vec(const DevProb &P, const lf64 *Ap, c
         if (n >= nlo && n < nhi) P.v2_sim[P.v2_rowoff[m - a.left] + (n - nlo)] = sc;
     }
 }
+#ifdef G2G_TU_V2
 extern "C" __global__ void __launch_bounds__(256)
 g2g_v2_sim_tile_kernel(const DevProb *probs, const int *idx)
 {
@@ -1282,6 +1295,9 @@ g2g_v2_sim_tile_kernel(const DevProb *probs, const int *idx)
         P.v2_sim[P.v2_rowoff[m - a.left] + (n - nlo)] = sc;
     }
 }
+#else
+extern "C" __global__ void g2g_v2_sim_tile_kernel(const DevProb *probs, const int *idx);
+#endif
 
 // self / dep_*: indices into the batch's tile-completion flags (-1: no such neighbour)
 struct V2Tile { int prob, ti, tj, nsteps, self, dep_up, dep_left, dep_diag, dep_war; };
@@ -1368,7 +1384,12 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         }                                                                                           \
     }                                                                                               \
 }
+#ifdef G2G_TU_V2
 V2_KERNEL(g2g_v2_hf2, 1, false)
 V2_KERNEL(g2g_v2_hf3, 1, true)
 V2_KERNEL(g2g_v2_pf2, 2, false)
 V2_KERNEL(g2g_v2_pf3, 2, true)
+#else
+#define V2_KERNEL_DECL(NAME) extern "C" __global__ void NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, int lds_tile_off, int C, int sweep, int pro_off, double *simscr);
+V2_KERNEL_DECL(g2g_v2_hf2) V2_KERNEL_DECL(g2g_v2_hf3) V2_KERNEL_DECL(g2g_v2_pf2) V2_KERNEL_DECL(g2g_v2_pf3)
+#endif

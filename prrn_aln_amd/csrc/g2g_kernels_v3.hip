@@ -985,11 +985,12 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
 #ifndef G2G_V3_NA
 #define G2G_V3_NA 16                 // register-resident static lists: up to this many entries (incl. terminator)
 #endif
+#ifdef G2G_TU_V3
 V3_KERNEL(g2g_v3_hf2, 1, false, 0, 2)
 V3_KERNEL(g2g_v3_hf3, 1, true, 0, 2)
-V3_KERNEL(g2g_v3_pf2, 2, false, 0, 2)
-V3_KERNEL(g2g_v3_pf3, 2, true, 0, 2)
 V3_KERNEL(g2g_v3r_hf2, 1, false, G2G_V3_NA, G2G_V3R_WPE)
 V3_KERNEL(g2g_v3r_hf3, 1, true, G2G_V3_NA, 1)
-V3_KERNEL(g2g_v3r_pf2, 2, false, G2G_V3_NA, 1)
-V3_KERNEL(g2g_v3r_pf3, 2, true, G2G_V3_NA, 1)
+#else
+#define V3_KERNEL_DECL(NAME) extern "C" __global__ void NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V3Lds LO, int C, int sweep, int pro_off, double *simscr);
+V3_KERNEL_DECL(g2g_v3_hf2) V3_KERNEL_DECL(g2g_v3_hf3) V3_KERNEL_DECL(g2g_v3r_hf2) V3_KERNEL_DECL(g2g_v3r_hf3)
+#endif

@@ -770,5 +770,10 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
 #ifndef G2G_V6_NA
 #define G2G_V6_NA 16
 #endif
+#ifdef G2G_TU_V6
 V6_KERNEL(g2g_v6_pf2, false, G2G_V6_NA, 1)
 V6_KERNEL(g2g_v6_pf3, true, G2G_V6_NA, 1)
+#else
+#define V6_KERNEL_DECL(NAME) extern "C" __global__ void NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V6Lds LO, int pint, int pro_off, double *simscr);
+V6_KERNEL_DECL(g2g_v6_pf2) V6_KERNEL_DECL(g2g_v6_pf3)
+#endif

@@ -285,5 +285,9 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         __syncthreads();                                                                            \
     }                                                                                               \
 }
+#ifdef G2G_TU_V78
 V7_KERNEL(g2g_v7_ngp2, false)
 V7_KERNEL(g2g_v7_ngp3, true)
+#else
+extern "C" __global__ void g2g_v7_ngp2(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, int pint, double *simscr); extern "C" __global__ void g2g_v7_ngp3(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, int pint, double *simscr);
+#endif

@@ -464,5 +464,9 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         __syncthreads();                                                                            \
     }                                                                                               \
 }
+#ifdef G2G_TU_V78
 V8_KERNEL(g2g_v8_ntv2, false)
 V8_KERNEL(g2g_v8_ntv3, true)
+#else
+extern "C" __global__ void g2g_v8_ntv2(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, int pint, double *simscr); extern "C" __global__ void g2g_v8_ntv3(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, int pint, double *simscr);
+#endif

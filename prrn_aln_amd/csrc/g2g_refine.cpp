@@ -469,11 +469,13 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
         // ---- look at the window in generator order ----
         int consumed = 0;
         bool accepted = false;
+        const double t_window = now() - t_begin;
         for (int k = 0; k < nw; ++k) {
             Division &d = D[k];
             ++consumed; ++it;
             g2g_refine_step e;
             memset(&e, 0, sizeof e);
+            e.t_ms = t_window;
             e.branch = d.branch; e.na = (int) d.la.size(); e.nb = (int) d.lb.size();
             if (d.skip) {
                 e.skipped = 1; e.delta = -INFINITY;

@@ -96,7 +96,7 @@ def refine_native(ctx, codes: np.ndarray, tree: KTree, alp: op.AlnParam, seed: i
     final = np.ctypeslib.as_array(out, shape=(olen.value * many,)).reshape(olen.value, many).copy()
     L.g2g_free(out)
     log = [dict(branch=s.branch, na=s.na, nb=s.nb, swp=bool(s.swp), accepted=bool(s.accepted), skipped=bool(s.skipped), scr=s.scr,
-                val_new=s.val_new, val_old=s.val_old, delta=s.delta) for s in (steps[i] for i in range(ns.value))]
+                val_new=s.val_new, val_old=s.val_old, delta=s.delta, t_ms=s.t_ms) for s in (steps[i] for i in range(ns.value))]
     L.g2g_free(steps)
     stats = {k: getattr(st, k) for k, _ in _abi.RefineStats._fields_ if k != "reserved"}
     if want_moves:

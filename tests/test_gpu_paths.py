@@ -26,9 +26,8 @@ CONFIGS = {
     "v2_chainq_hbm": {"G2G_FORCE_V2": "1", "G2G_NO_PROSTAGE": "1"},
     "v3r_cols32": {"G2G_V3_COLS": "32", "G2G_V3_SWEEP": "0"},
     "v3r_tiles": {"G2G_V3_SWEEP": "0"},
-    "v3lds_all": {"G2G_NO_AREG": "1", "G2G_V3_PF": "1"},
-    "v3lds_all_cols32": {"G2G_NO_AREG": "1", "G2G_V3_PF": "1", "G2G_V3_COLS": "32", "G2G_V3_SWEEP": "0"},   # tile mode
-    "v3_pf": {"G2G_V3_PF": "1", "G2G_V3_COLS": "64"},
+    "v3lds_all": {"G2G_NO_AREG": "1"},
+    "v3lds_all_cols32": {"G2G_NO_AREG": "1", "G2G_V3_COLS": "32", "G2G_V3_SWEEP": "0"},   # tile mode
     "no_v7": {"G2G_NO_V7": "1"},                                     # DPunit on v1 instead of the strip kernel
     "no_v8": {"G2G_NO_V8": "1"},                                     # DPunit_nv on v1 instead of the strip kernel
     "no_v6": {"G2G_NO_V6": "1"},                                     # _pf on the 8-lanes-per-cell kernel instead of v6
@@ -94,7 +93,7 @@ FAMILIES = [
 ]
 
 
-@pytest.mark.parametrize("name", ["default", "v6", "v6_publish4", "v6_class_c", "no_v6", "v3r_cols32", "v3r_tiles", "v3lds_all", "v3_pf", "v2", "v2_t128", "v2_tiles", "v2_tiles_t128"])
+@pytest.mark.parametrize("name", ["default", "v6", "v6_publish4", "v6_class_c", "no_v6", "v3r_cols32", "v3r_tiles", "v3lds_all", "v2", "v2_t128", "v2_tiles", "v2_tiles_t128"])
 @pytest.mark.parametrize("fam", FAMILIES, ids=[f[0] for f in FAMILIES])
 def test_large_divisions_every_path(ctx, L, monkeypatch, name, fam):
     """Group-vs-rest divisions of a 650-700 column family (many strips and blocks) per forced path."""

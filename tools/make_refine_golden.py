@@ -18,6 +18,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 REF = os.path.join(ROOT, "oracle", "_ref")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
+# the headline workload itself (BASELINE.json configs[2]): 256 proteins x 1024 aa, refinement-only entry
+# from the reference's own serial progressive MSA (tests/golden/msa/prog256x1024.npz, tools/make_progressive_fixture.py).  Takes
+# the reference the better part of an hour on one core; the fixture is stored gzip-compressed.
+BIG = ("prot256x1024_prog", os.path.join("msa", "prog256x1024.npz"))
+
 CASES = [
     ("prot12x80_s3", dict(n_seq=12, length=80, seed=3, indel=0.03, max_indel=6), False, []),
     ("prot20x100_s11", dict(n_seq=20, length=100, seed=11, indel=0.03, max_indel=8), False, []),
@@ -39,25 +44,42 @@ def parse_msa(text):
     return [rows[k].rstrip() for k in order], order
 
 
-def main(only=None):
-    import refdump
+def start_rows(name, kw, dna):
+    """rows of the start MSA: a seeded synthetic family's true alignment, or (BIG) the reference's progressive MSA of the bench family"""
     from prrn_aln_amd.synth import DNA, make_family
+    if name == BIG[0]:
+        import numpy as np
+        from prrn_aln_amd import operator as op
+        codes = np.load(os.path.join(GOLD, BIG[1]))["codes"]
+        inv = {v: k for k, v in op._AA.items() if k.isupper() or k == "-"}
+        return ["".join(inv.get(int(c), "X") for c in codes[:, j]) for j in range(codes.shape[1])]
+    if dna:
+        kw = dict(kw, alphabet=DNA)
+    return list(make_family(**kw).msa)
+
+
+def main(only=None):
+    import gzip
+    import time
+    import refdump
     env = dict(os.environ, ALN_TAB=os.path.join(REF, "table"))
-    for name, kw, dna, extra in CASES:
+    cases = CASES + ([(BIG[0], {}, False, [])] if only == BIG[0] else [])
+    for name, kw, dna, extra in cases:
         if only and name != only:
             continue
-        if dna:
-            kw = dict(kw, alphabet=DNA)
-        fam = make_family(**kw)
-        names = ["s%02d" % i for i in range(len(fam.msa))]
+        rows = start_rows(name, kw, dna)
+        fam = type("Fam", (), {"msa": rows})
+        names = [("s%03d" if len(rows) > 99 else "s%02d") % i for i in range(len(rows))]
         with tempfile.TemporaryDirectory() as tmp:
             refdump.write_multi(os.path.join(tmp, "fam.msa"), names, list(fam.msa), "fam")
             tr = os.path.join(tmp, "trace.txt")
             opts = ["-YH0", "-R1"] + extra
             subprocess.run([os.path.join(REF, "prrn5_trace")] + opts + ["-O4", "fam.msa"], cwd=tmp, env=dict(env, G2G_TRACE=tr),
                            check=True, capture_output=True)
+            t0 = time.time()
             out = subprocess.run([os.path.join(REF, "prrn5")] + opts + ["fam.msa"], cwd=tmp, env=env, check=True,
                                  capture_output=True, text=True).stdout
+            ref_seconds = time.time() - t0          # the reference's own serial refinement, one core of the build container
             L = [l.rstrip("\n") for l in open(tr)]
         final, order = parse_msa(out)
         assert order == names and len({len(r) for r in final}) <= 2, (order[:3], [len(r) for r in final][:5])
@@ -72,6 +94,7 @@ def main(only=None):
             "cycle": int([l for l in L if l.startswith("C ")][0].split()[1]),
             "branches": [int(l.split()[1]) for l in L if l.startswith("D ")],
             "align2": [], "accepted": [], "final_rows": final,
+            "reference_seconds": round(ref_seconds, 1),
         }
         assert [int(t[1]) for t in T] == list(range(len(T)))
         for l in L:
@@ -83,7 +106,11 @@ def main(only=None):
                 sk = [int(x) for x in p[3].split()]
                 fix["accepted"].append({"lst0": [int(x) for x in p[1].split()], "lst1": [int(x) for x in p[2].split()],
                                         "skl": [sk[i:i + 2] for i in range(0, len(sk), 2)]})
-        json.dump(fix, open(os.path.join(GOLD, "refine_%s.json" % name), "w"))
+        if name == BIG[0]:
+            with gzip.open(os.path.join(GOLD, "refine_%s.json.gz" % name), "wt", compresslevel=9) as fd:
+                json.dump(fix, fd)
+        else:
+            json.dump(fix, open(os.path.join(GOLD, "refine_%s.json" % name), "w"))
         print("%-22s members %d, cycle %d, %d divisions drawn, %d align2 calls, %d accepted, %d -> %d columns" % (
             name, len(names), fix["cycle"], len(fix["branches"]), len(fix["align2"]), len(fix["accepted"]), len(fam.msa[0]), width))
 
