@@ -150,6 +150,92 @@ def cpu_baseline_allcores(sw, budget_s):
                       "forward fill + traceback only" % (len(pick), len(sw), cores, cells, slow)}
 
 
+def reference_prefix(rows, names, seconds, extra_opts=()):
+    """The reference's own refinement (oracle/_ref/prrn5_trace = the unmodified prrn5.cc + a tracing wrapper of align2) started on
+    the same MSA on one host core of THIS box and stopped after `seconds`: how many align2() calls it got through.  (The whole run
+    takes the better part of an hour for the 256 x 1024 family; its duration in the build container is in the fixture.)"""
+    import signal
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import refdump
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    exe = os.path.join(ref, "prrn5_trace")
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory() as tmp:
+        refdump.write_multi(os.path.join(tmp, "fam.msa"), names, rows, "fam")
+        tr = os.path.join(tmp, "trace.txt")
+        env = dict(os.environ, ALN_TAB=os.path.join(ref, "table"), G2G_TRACE=tr)
+        t0 = time.perf_counter()
+        p = subprocess.Popen([exe, "-YH0", "-R1"] + list(extra_opts) + ["fam.msa"], cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        try:
+            p.wait(timeout=seconds)
+        except subprocess.TimeoutExpired:
+            p.send_signal(signal.SIGKILL)
+            p.wait()
+        dt = time.perf_counter() - t0
+        calls = 0
+        if os.path.exists(tr):
+            with open(tr) as fd:
+                calls = sum(1 for l in fd if l.startswith("A "))
+    return {"align2_calls": calls, "seconds": dt, "finished": p.returncode == 0}
+
+
+def refinement_readout(ctx, args):
+    """The second half of the metric on the named workload itself: Prrn::rir (reference src/prrn5.cc:633-666) of the 256 x 1024 aa
+    family from the reference's progressive MSA, through g2g_refine, against the committed trace of the reference's own run
+    (tests/golden/refine_prot256x1024_prog.json.gz, tools/make_refine_golden.py): same branch sequence, same DP score and
+    fstat.val at every align2(), same final MSA => the SP-score delta of the refined alignment is exactly 0; pairsum_ss of
+    both final MSAs is computed anyway.  The reference itself is timed beside it on one host core for a bounded prefix."""
+    import gzip
+    import numpy as np
+    from prrn_aln_amd import operator as op
+    from prrn_aln_amd.refine import KTree, refine_native, pairsum
+    big = os.path.join(ROOT, "tests", "golden", "refine_prot256x1024_prog.json.gz")
+    small = os.path.join(ROOT, "tests", "golden", "refine_prot48x300_s5.json")
+    use_big = os.path.exists(big) and not args.dna and not os.environ.get("G2G_BENCH_SMALL_REFINE")
+    f = json.load(gzip.open(big, "rt")) if use_big else json.load(open(small))
+    t = f["tree"]
+    tree = KTree(t["left"], t["right"], t["parent"], t["vol"], t["cur"])
+    ralp = op.AlnParam(ls=f["ls"], molc=f["molc"], max_code=25 if f["molc"] == 1 else 17)
+    start = op.encode(f["rows"], f["molc"])
+    refine_native(ctx, start, tree, ralp, seed=1, maxitr=1, window=2) if not use_big else None      # (warm: first use of the small-batch paths)
+    c0 = ctx.counters()
+    t1 = time.perf_counter()
+    final, rsteps, rstats = refine_native(ctx, start, tree, ralp, seed=1, maxitr=10, window=16)
+    rt = time.perf_counter() - t1
+    c1 = ctx.counters()
+    want = op.encode(f["final_rows"], f["molc"])
+    same = bool(np.array_equal(final, want))
+    dps = [x for x in rsteps if not x["skipped"]]
+    scr_same = len(dps) == len(f["align2"]) and all(x["scr"] == r["scr"] and x["val_new"] == r["val"] for x, r in zip(dps, f["align2"]))
+    sp_gpu, sp_ref = pairsum(ctx, final, tree, ralp), pairsum(ctx, want, tree, ralp)
+    out = {"family": "%d %s x %s, start MSA %d columns (%s: trace of the reference's own Prrn::rir, serial, -YH0 -R1)"
+                     % (len(f["rows"]), "proteins" if f["molc"] == 1 else "DNA sequences", "1024 aa" if use_big else "300 aa", len(f["rows"][0]), os.path.basename(big if use_big else small)),
+           "engine": "g2g_refine (C++ behind the C ABI): windows of speculative divisions batched on the GPU, in-order acceptance",
+           "wall_s": rt, "divisions_evaluated": rstats["divisions"], "align2_calls": len(dps), "accepted_moves": rstats["accepted"],
+           "gpu_batches": rstats["batches"], "divisions_recomputed": rstats["divisions_wasted"],
+           "wait_timeouts": int(c1["wait_timeouts"] - c0["wait_timeouts"]), "recovered_dps": int(c1["recovered_dps"] - c0["recovered_dps"]),
+           "same_branch_sequence_as_reference": [x["branch"] for x in rsteps] == f["branches"],
+           "every_dp_score_and_fstat_val_equal_to_reference": bool(scr_same),
+           "final_msa_identical_to_reference": same,
+           # Ssrel::pairsum_ss (g2g_pairsum, on the trace's tree) of the start MSA, of OUR refined MSA and of the REFERENCE's refined MSA
+           "pairsum_ss_start": pairsum(ctx, start, tree, ralp), "pairsum_ss_refined": sp_gpu, "pairsum_ss_reference_refined": sp_ref,
+           "sp_delta_vs_reference": abs(sp_gpu - sp_ref)}
+    ref = {"whole_run_s_one_core_build_container": f.get("reference_seconds")}
+    if not args.no_cpu:
+        names = [("s%03d" if len(f["rows"]) > 99 else "s%02d") % i for i in range(len(f["rows"]))]
+        live = reference_prefix(list(f["rows"]), names, 30.0 if use_big else 20.0, ["-yl3"] if f["ls"] == 3 else [])
+        if live:
+            n = live["align2_calls"]
+            ours = dps[n - 1]["t_ms"] / 1e3 if 0 < n <= len(dps) else None
+            ref.update({"live_prefix_on_this_box": live, "g2g_refine_s_for_the_same_prefix": ours,
+                        "speedup_on_the_prefix": (live["seconds"] / ours) if ours else None})
+    out["reference_prrn5"] = ref
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,10 +329,16 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     fwd_ms = tb_ms = 0.0
+    wait_timeouts, recovered_dps = [], []                 # per timed step: scheduler waits that ran into their limit / DPs re-run for it
+    cnt_before = ctx.counters()
     for _ in range(args.steps):
         out, gathered = step()
         f, t = batch.times_ms() if batch is not None else (0.0, 0.0)
         fwd_ms += f; tb_ms += t
+        cnt_now = ctx.counters()
+        wait_timeouts.append(int(cnt_now["wait_timeouts"] - cnt_before["wait_timeouts"]))
+        recovered_dps.append(int(cnt_now["recovered_dps"] - cnt_before["recovered_dps"]))
+        cnt_before = cnt_now
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -313,28 +405,9 @@ def main():
     refinement = guide_tree = None
     if world == 1 and not args.shard_of and not args.limit and not args.no_cpu:
         try:
-            from prrn_aln_amd.refine import KTree, refine_native, pairsum
-            f = json.load(open(os.path.join(ROOT, "tests", "golden", "refine_prot48x300_s5.json")))
-            t = f["tree"]
-            tree = KTree(t["left"], t["right"], t["parent"], t["vol"], t["cur"])
-            ralp = op.AlnParam(ls=f["ls"], molc=f["molc"], max_code=25 if f["molc"] == 1 else 17)
-            start = op.encode(f["rows"], f["molc"])
-            refine_native(ctx, start, tree, ralp, seed=1, maxitr=1, window=16)              # (warm: first use of the small-batch paths)
-            t1 = time.perf_counter()
-            final, rsteps, rstats = refine_native(ctx, start, tree, ralp, seed=1, maxitr=10, window=16)
-            rt = time.perf_counter() - t1
-            same = bool(np.array_equal(final, op.encode(f["final_rows"], f["molc"])))
-            refinement = {"family": "48 proteins x 300 aa, start MSA %d columns (tests/golden/refine_prot48x300_s5.json: trace of the reference's Prrn::rir; "
-                                    "the reference's own serial `prrn5 -YH0 -R1` takes about 20-40 s for it on one core)" % len(f["rows"][0]),
-                          "engine": "g2g_refine (C++ behind the C ABI): windows of speculative divisions batched on the GPU, in-order acceptance",
-                          "wall_ms": 1e3 * rt, "divisions_evaluated": rstats["divisions"], "accepted_moves": rstats["accepted"],
-                          "gpu_batches": rstats["batches"], "divisions_recomputed": rstats["divisions_wasted"],
-                          "same_branch_sequence_as_reference": [x["branch"] for x in rsteps] == f["branches"],
-                          "final_msa_identical_to_reference": same, "sp_delta_vs_reference": 0.0 if same else None,
-                          # Ssrel::pairsum_ss (g2g_pairsum) of the start and of the refined MSA, on the trace's tree
-                          "pairsum_ss_start": pairsum(ctx, start, tree, ralp), "pairsum_ss_refined": pairsum(ctx, final, tree, ralp)}
+            refinement = refinement_readout(ctx, args)
         except Exception as e:
-            refinement = {"error": str(e)[:200]}
+            refinement = {"error": str(e)[:300]}
         try:
             from prrn_aln_amd import guide
             if not args.dna:
@@ -389,6 +462,9 @@ def main():
                                       sum(1 for p in sw.pwds if p.alnmode == 9), total_cells),
                        "divisions": len(sw), "cells_per_step": total_cells, "parallelism": "divisions round-robin by size over %d GPU(s)" % world,
                        "failed_items": bad, "align2_batch_from_host_ms": e2e_ms,
+                       # every run is evidence about the scheduler's waits: per timed step, the waits that ran into
+                       # their wall-clock limit and the DPs re-run because of it (rank 0's share); an ordinary run shows zeros
+                       "wait_timeouts": wait_timeouts, "recovered_dps": recovered_dps,
                        # checksum of the last timed step's results (this rank's divisions): the same workload must give the same
                        # two numbers in every run, with or without a recovered time-out in it
                        "score_sum": float(sum(scr for (scr, _, st) in out if st == 0)),
