@@ -8,7 +8,7 @@ import os
 from . import _abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "libg2g.so")
+LIB = os.environ.get("G2G_LIB") or os.path.join(HERE, "libg2g.so")      # (G2G_LIB: an experiment's build of the same library)
 
 _lib = None
 

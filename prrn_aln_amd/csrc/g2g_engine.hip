@@ -258,6 +258,7 @@ struct g2g_batch {
     long long ntiles;
     float fwd_ms, tb_ms;
     double *simscr[24]; size_t simscr_cap[24];
+    unsigned *twin[6]; size_t twin_cap[6];       // per v6 launch: HBM image of the dynamic lists' parts beyond their inline LDS slots
     bool v6_on;                     // this batch is large enough for v6 (else its _pf DPs go to v2: shorter critical path)
     int hdr_img[G2G_HDR + G2G_HDRN];       // host image of the queue heads + wait header of the current run
     std::vector<const g2g_problem *> src;        // the caller's problems (kept alive by the caller until the batch is freed): a DP
@@ -303,7 +304,7 @@ static V3Lds v3_layout(int rows_bytes, int ca4max, int apool, int bpool, int C)
 }
 // LDS plan of the v6 kernel (g2g_kernels_v6.hip): ring rows of dynamic lists, black lists, staging scalars, the ring of
 // b's static lists (3 views x rs entries x 16 B), queue scratch, sinks
-struct V6Ring { int rs[3]; };
+struct V6Ring { int rs[3]; int at, as; };                  // ring entries per view; entries of the t lists of the strip that has the most
 static V6Lds v6_layout(int rows_bytes, int ca4max, const V6Ring &R)
 {
     V6Lds L;
@@ -313,28 +314,30 @@ static V6Lds v6_layout(int rows_bytes, int ca4max, const V6Ring &R)
     L.black = take(4 * (ca4max + 8));
     L.stsc = take(4 * 28);
     for (int v = 0; v < 3; ++v) { L.rs[v] = R.rs[v]; L.ringf[v] = take(8 * R.rs[v]); }
-    for (int v = 0; v < 3; ++v) L.ringk[v] = take(4 * R.rs[v]);
+    for (int v = 0; v < 3; ++v) L.ringk[v] = take(v < 2 ? 4 * R.rs[v] : 0);       // (view 2: an array of head freqs per column, no keys)
+    L.atcap = R.at;
+    L.atf = take(8 * (R.at + 2));                          // the t lists of the strip's rows, compact (g2g_kernels_v6.hip)
+    L.atk = take(4 * (R.at + 2));
+    L.ascap = R.as;
+    L.asf = take(8 * (R.as + 2));
     L.svals = take(4 * 64);
     L.sink = take(4 * 64 + 16 * 64);
     L.total = o;
     return L;
 }
-// A launch has ONE LDS plan, the largest of its DPs, and LDS decides how many strips a CU holds: v6 DPs are dealt to two
-// launches by footprint -- up to 40 KB (four strips per CU) and up to 53 KB (three) -- and DPs above that stay on v2, which
-// beats v6 at two strips per CU (measured: 779 ms per bench sweep with the limit at 53 KB, 1015 ms at 64 KB).
-static int v6_small_lds(const g2g_ctx *c) { const char *e = g2g_opt(c, "V6_SMALL_KB"); return e ? atoi(e) * 1024 : 53 * 1024; }
+// A launch has ONE LDS plan, the largest of its DPs, and LDS decides how many strips a CU holds.  Since the dynamic lists keep
+// only their inline parts in LDS (g2g_kernels_v6.hip, LS6) a strip of the bench sweep takes 30-33 KB instead of 40-53: v6 DPs are
+// dealt to launches by footprint -- A up to 32 KB (five strips per CU), B up to V6_SMALL_KB (default 40 KB: four), C up to
+// V6_LARGE_KB (default 53 KB: three; 0 turns the class off) -- and DPs above that stay on v2.
+static const int V6_CLASS_A = 32 * 1024;
+static int v6_small_lds(const g2g_ctx *c) { const char *e = g2g_opt(c, "V6_SMALL_KB"); return e ? atoi(e) * 1024 : 40 * 1024; }
 #define V6_SMALL_LDS (v6_small_lds(ctx))
-static const int V6_CLASS_A = 40 * 1024;
-// footprint classes of the v6 launches (one LDS plan per launch = the largest of its DPs): A up to 40 KB (4 strips per CU), B up to
-// V6_SMALL_LDS (53 KB: 3 per CU), and -- only when option V6_LARGE_KB asks for it -- C up to that many KB (2 per CU at 80).  Class C is
-// OFF by default: the DPs it would take (the most balanced divisions: long column lists, the scanning cell instance) run faster on
-// the 8-lanes-per-cell kernel -- bench sweep 751 ms without it, 771 / 899 / 879 ms with a limit of 64 / 80 / 96 KB.
-static int v6_large_lds(const g2g_ctx *c) { const char *e = g2g_opt(c, "V6_LARGE_KB"); return e ? atoi(e) * 1024 : 0; }
+static int v6_large_lds(const g2g_ctx *c) { const char *e = g2g_opt(c, "V6_LARGE_KB"); return e ? atoi(e) * 1024 : 53 * 1024; }
 #define V6_LARGE_LDS (v6_large_lds(ctx))
 static inline int v6_slot(int cls) { return cls < 4 ? 12 + cls : 16 + cls; }      // queue / variant slot of class index (footprint class x 2 + Noll 3)
 static int v6_rows_bytes(const DevProb &d)
 {
-    const int lsz = ((d.capa + 3) & ~3) + ((d.capb + 3) & ~3);
+    const int lsz = v6_inline_dw((d.capa + 3) & ~3) + v6_inline_dw((d.capb + 3) & ~3);      // the INLINE parts of a record's two lists (LS6)
     return 65 * v3_pitch(d.noll == 3 ? 9 : 6, lsz) * 4 + 32;
 }
 // ring entries the v6 kernel needs per view for this problem: the most list entries (terminators not counted) any window
@@ -352,9 +355,34 @@ static V6Ring v6_ring_need(const g2g_problem *p)
         }
         int rs = 32;
         while (rs < need) rs <<= 1;
-        R.rs[v] = rs;
+        R.rs[v] = v < 2 ? rs : V6_RHCOLS;                    // (the r view is derived from the t ring: only its head freqs, one per column)
+    }
+    // entries (terminators not counted) of the t lists of 64 consecutive rows of a, strip by strip
+    R.at = 1;
+    {
+        const int32_t *off = p->a.gfq.off[1];
+        for (int m0 = p->a.left; m0 < p->a.right; m0 += 64) {
+            const int me = std::min(m0 + 64, p->a.right);
+            R.at = std::max(R.at, (off[me + 1] - (me + 1)) - (off[m0 + 1] - (m0 + 1)));
+        }
+        R.at = (R.at + 3) & ~3;
+        const int32_t *sof = p->a.gfq.off[0];
+        R.as = 1;
+        for (int m0 = p->a.left; m0 < p->a.right; m0 += 64) {
+            const int me = std::min(m0 + 64, p->a.right);
+            R.as = std::max(R.as, (sof[me + 1] - (me + 1)) - (sof[m0 + 1] - (m0 + 1)));
+        }
+        R.as = (R.as + 3) & ~3;
     }
     return R;
+}
+// the longest s list (entries, terminator not counted) of a's rows: the _pf strip kernel keeps a row's s list in V6_NS registers
+static int v6_slist_max(const g2g_problem *p)
+{
+    const int32_t *off = p->a.gfq.off[0];
+    int mx = 0;
+    for (int m = p->a.left; m < p->a.right; ++m) mx = std::max(mx, off[m + 2] - off[m + 1] - 1);
+    return mx;
 }
 struct V3Need { int rows_bytes, ca4, apool, bpool, total; };
 static V3Need v3_need(const DevProb &d, const g2g_problem *p, int C, bool areg = false)
@@ -559,6 +587,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
     g2g_batch *b = new g2g_batch();
     b->ctx = ctx; b->n = n; b->d_arena = 0; b->d_probs = 0; b->fwd_ms = b->tb_ms = 0;
     for (int k = 0; k < 24; ++k) { b->simscr[k] = 0; b->simscr_cap[k] = 0; }
+    for (int k = 0; k < 6; ++k) { b->twin[k] = 0; b->twin_cap[k] = 0; }
     b->src.assign(prob, prob + n); b->fail_off = 0; b->force_v1 = force_v1; b->is_retry = false; b->n_recovered = 0;
     b->recovered.assign(n, g2g_result()); b->was_recovered.assign(n, 0);
     b->nsimmat = 0;
@@ -716,9 +745,9 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         }
         if ((d.kind == 1 || d.kind == 2) && !force_v1 && !g2g_opt(ctx, "FORCE_V1") && p->a.len + p->b.len < 65000) {
             // _pf: one lane per cell with rank-form merges (v6) when the rows' static lists fit the register file
-            if (b->v6_on && !g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_V6") && d.kind == 2 && d.a.maxlist <= G2G_V6_NA && d.a.r_from_t &&
+            if (b->v6_on && !g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_V6") && d.kind == 2 && v6_slist_max(p) <= V6_NS && d.a.r_from_t && d.b.r_from_t &&
                 v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(p)).total <= std::max(V6_SMALL_LDS, V6_LARGE_LDS)) d.v2_ok = 6;
-            else if (!g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_AREG") && d.kind == 1 && d.a.maxlist <= G2G_V3_NA &&
+            else if (!g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_AREG") && d.kind == 1 && d.a.maxlist <= G2G_V3_NA && d.a.r_from_t &&
                 v3_need(d, p, b->v3_cols, true).total <= (int) V2_LDS_MAX) d.v2_ok = 3;
             else {
                 // lists too long for registers: the LDS-list one-lane-per-cell kernel, unless its LDS footprint leaves fewer than
@@ -826,7 +855,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         std::vector<int> ip;                              // the other DPs: chains in the prologue kernel
         const bool chainq = !g2g_opt(ctx, "NO_CHAINQ");
         int v6rows[6] = {0, 0, 0, 0, 0, 0}, v6ca4[6] = {0, 0, 0, 0, 0, 0};
-        V6Ring v6rs[6] = {{{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}};
+        V6Ring v6rs[6] = {{{32, 32, 32}, 4, 4}, {{32, 32, 32}, 4, 4}, {{32, 32, 32}, 4, 4}, {{32, 32, 32}, 4, 4}, {{32, 32, 32}, 4, 4}, {{32, 32, 32}, 4, 4}};
         V3Need need[8];
         memset(need, 0, sizeof need);
         for (int i = 0; i < n; ++i) {
@@ -854,7 +883,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
             if (d.v2_ok == 6) {
                 v6rows[v6cls] = std::max(v6rows[v6cls], v6_rows_bytes(d));
                 v6ca4[v6cls] = std::max(v6ca4[v6cls], (d.capa + 3) & ~3);
-                { const V6Ring rn = v6_ring_need(prob[i]); for (int q = 0; q < 3; ++q) v6rs[v6cls].rs[q] = std::max(v6rs[v6cls].rs[q], rn.rs[q]); }
+                { const V6Ring rn = v6_ring_need(prob[i]); for (int q = 0; q < 3; ++q) v6rs[v6cls].rs[q] = std::max(v6rs[v6cls].rs[q], rn.rs[q]); v6rs[v6cls].at = std::max(v6rs[v6cls].at, rn.at); v6rs[v6cls].as = std::max(v6rs[v6cls].as, rn.as); }
             } else if (d.v2_ok >= 7) {
             } else if (d.v2_ok >= 2) {
                 const V3Need nd = v3_need(d, prob[i], C, d.v2_ok == 3);
@@ -1094,7 +1123,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             const int slot = v6_slot(v);
             const int cnt = b->var_off[slot + 1] - b->var_off[slot];
             if (!cnt) continue;
-            typedef void (*v6k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V6Lds, int, int, double *);
+            typedef void (*v6k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V6Lds, int, int, double *, unsigned *, int);
             static const v6k_t v6k[6] = {g2g_v6_pf2, g2g_v6_pf3, g2g_v6_pf2, g2g_v6_pf3, g2g_v6_pf2, g2g_v6_pf3};
             hipStream_t vs = ctx->vstream[v < 4 ? 2 + v : v - 4];        // class A: streams 2, 3; B: 4, 5; C: 0, 1
             const int jev = v < 2 ? 2 + v : v < 4 ? 3 + v : v - 4;
@@ -1109,10 +1138,21 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] v6 variant %d: %d strips, grid %d, lds %d (rings %d / %d / %d entries), publish every %d, gen %d\n", v, cnt, grid, LO.total, LO.rs[0], LO.rs[1], LO.rs[2], pint, b->gen); fflush(stderr); }
             double *simscr6 = sim_scratch(slot, grid);
             if (!simscr6) { g2g_set_error("%s", "hipMalloc(column-score scratch)"); return G2G_ERR_NOMEM; }
+            // the twin image of the strips' dynamic lists (what does not fit their inline parts in LDS): two dwords per dword of rows
+            const int twin_dw = 2 * (LO.black - LO.rows) / 4 + 64;
+            {
+                const size_t need = (size_t) grid * twin_dw * sizeof(unsigned);
+                if (b->twin_cap[v] < need) {
+                    if (b->twin[v]) hipFree(b->twin[v]);
+                    b->twin[v] = 0; b->twin_cap[v] = 0;
+                    if (hipMalloc((void **) &b->twin[v], need) != hipSuccess) { (void) hipGetLastError(); g2g_set_error("%s", "hipMalloc(list twin image)"); return G2G_ERR_NOMEM; }
+                    b->twin_cap[v] = need;
+                }
+            }
             hipLaunchKernelGGL(v6k[v], dim3(grid), dim3(64), (size_t) LO.total, vs,
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[slot]), cnt,
                                b->d_flags + slot, b->d_flags, b->gen, LO, pint,
-                               (pro_off && pro_off + (int) PRO_LDS_BYTES <= LO.svals) ? pro_off : 0, simscr6);
+                               (pro_off && pro_off + (int) PRO_LDS_BYTES <= LO.svals) ? pro_off : 0, simscr6, b->twin[v], twin_dw);
             HIPCHK(hipGetLastError());
             if (g2g_opt(ctx, "DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v6 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
             HIPCHK(hipEventRecord(ctx->vev[jev], vs));
@@ -1276,6 +1316,7 @@ extern "C" void g2g_batch_free(g2g_batch *b)
     if (b->d_tiles) hipFree(b->d_tiles);
     if (b->d_flags) hipFree(b->d_flags);
     for (int k = 0; k < 24; ++k) if (b->simscr[k]) hipFree(b->simscr[k]);
+    for (int k = 0; k < 6; ++k) if (b->twin[k]) hipFree(b->twin[k]);
     for (size_t i = 0; i < b->recovered.size(); ++i) free(b->recovered[i].trace);
     delete b;
 }

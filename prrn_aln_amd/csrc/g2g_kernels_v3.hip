@@ -112,7 +112,20 @@ __device__ __forceinline__ void rl_load(int (&g)[N], double (&f)[N], const DevSi
     }
 }
 __device__ __forceinline__ bool wave_none(bool live) { return __ballot(live) == 0; }
-template <int N> struct ARegs { const int (&sg)[N]; const double (&sf)[N]; const int (&tg)[N]; const double (&tf)[N]; const int (&rg)[N]; const double (&rf)[N]; };
+// (the r view is not held: r = [head {glen 0, freq rhf}, if the position has one] + the t entries with glen + 1 -- DevSide::r_from_t,
+// checked by the host; 48 registers less than a third register list, which is what lets the kernel run two waves per SIMD unspilled)
+template <int N> struct ARegs { const int (&sg)[N]; const double (&sf)[N]; const int (&tg)[N]; const double (&tf)[N]; double rhf; bool rh; };
+template <int N> __device__ __forceinline__ int areg_rg(const ARegs<N> &A, const int i)
+{
+    if (i == 0) return A.rh ? 0 : (A.tg[0] >= 0 ? A.tg[0] + 1 : -1);
+    const int t = A.rh ? A.tg[i - 1] : A.tg[i];
+    return t >= 0 ? t + 1 : -1;
+}
+template <int N> __device__ __forceinline__ double areg_rf(const ARegs<N> &A, const int i)
+{
+    if (i == 0) return A.rh ? A.rhf : A.tf[0];
+    return A.rh ? A.tf[i - 1] : A.tf[i];
+}
 
 // ---- one cell by one lane ---------------------------------------------------------------------------
 struct Costs { double d0, d1, gnpv, gopv, gnph, goph, gnpv2, gnph2; };
@@ -371,7 +384,7 @@ __device__ __forceinline__ void v3_cell_hf(const DevProb &P, const ARegs<N> &A, 
     const DHead h_fl = dh_load<true>(fll), h_hl = dh_load<true>(hll);
     const DHead h_g2u = dh_load<true>(NOLL3 ? g2ul : gul), h_f2l = dh_load<true>(NOLL3 ? f2ll : fll);
     // ---- gap-open costs: one fused loop over the static entries ---------------------------------------
-    const bool ms = A.sg[0] >= 0 && A.sg[1] >= 0, mt = A.tg[0] >= 0 && A.tg[1] >= 0, mr = A.rg[0] >= 0 && A.rg[1] >= 0;
+    const bool ms = A.sg[0] >= 0 && A.sg[1] >= 0, mt = A.tg[0] >= 0 && A.tg[1] >= 0, mr = areg_rg(A, 0) >= 0 && areg_rg(A, 1) >= 0;
     NG s_d = {mt, 0.}, s_gu = {ms && do_vert, 0.}, s_hu = {ms && do_vert, 0.}, s_g2 = {ms && do_vert && NOLL3, 0.};
     NG s_fl = {mr && do_hori, 0.}, s_hl = {mr && do_hori, 0.}, s_f2 = {mr && do_hori && NOLL3, 0.};
 #pragma unroll G2G_V3_HF_UNROLL
@@ -380,11 +393,13 @@ __device__ __forceinline__ void v3_cell_hf(const DevProb &P, const ARegs<N> &A, 
         ng2_step(s_d, h_hd, hd.glb, A.tg[i], A.tf[i]);
         ng1_step(s_gu, h_gu, gu.glb, A.sg[i], A.sf[i]);
         ng1_step(s_hu, h_hu, hu.glb, A.sg[i], A.sf[i]);
-        ng2_step(s_fl, h_fl, fl.glb, A.rg[i], A.rf[i]);
-        ng2_step(s_hl, h_hl, hl.glb, A.rg[i], A.rf[i]);
+        const int rgi = areg_rg(A, i);
+        const double rfi = areg_rf(A, i);
+        ng2_step(s_fl, h_fl, fl.glb, rgi, rfi);
+        ng2_step(s_hl, h_hl, hl.glb, rgi, rfi);
         if (NOLL3) {
             ng1_step(s_g2, h_g2u, g2u.glb, A.sg[i], A.sf[i]);
-            ng2_step(s_f2, h_f2l, f2l.glb, A.rg[i], A.rf[i]);
+            ng2_step(s_f2, h_f2l, f2l.glb, rgi, rfi);
         }
     }
     Costs c;
@@ -392,10 +407,10 @@ __device__ __forceinline__ void v3_cell_hf(const DevProb &P, const ARegs<N> &A, 
     c.d0 = ng2_fin(P, s_d, h_hd, hd.glb, A.tg[0], A.tg[1], A.tf[0]);
     c.gnpv = ng1_fin(P, s_gu, h_gu, gu.glb, A.sg[0], A.sg[1], A.sf[0]);
     c.gopv = ng1_fin(P, s_hu, h_hu, hu.glb, A.sg[0], A.sg[1], A.sf[0]);
-    c.gnph = ng2_fin(P, s_fl, h_fl, fl.glb, A.rg[0], A.rg[1], A.rf[0]);
-    c.goph = ng2_fin(P, s_hl, h_hl, hl.glb, A.rg[0], A.rg[1], A.rf[0]);
+    c.gnph = ng2_fin(P, s_fl, h_fl, fl.glb, areg_rg(A, 0), areg_rg(A, 1), areg_rf(A, 0));
+    c.goph = ng2_fin(P, s_hl, h_hl, hl.glb, areg_rg(A, 0), areg_rg(A, 1), areg_rf(A, 0));
     c.gnpv2 = NOLL3 ? ng1_fin(P, s_g2, h_g2u, g2u.glb, A.sg[0], A.sg[1], A.sf[0]) : 0;
-    c.gnph2 = NOLL3 ? ng2_fin(P, s_f2, h_f2l, f2l.glb, A.rg[0], A.rg[1], A.rf[0]) : 0;
+    c.gnph2 = NOLL3 ? ng2_fin(P, s_f2, h_f2l, f2l.glb, areg_rg(A, 0), areg_rg(A, 1), areg_rf(A, 0)) : 0;
     const Dec d = v3_decide<1, NOLL3>(P, c, hd, hu, gu, g2u, hl, fl, f2l, do_vert, do_hori, dab, pua, pub);
     const int win = d.win;
     // ---- list updates: the newdeltas of G (G2) and of a diagonal H share one loop over the t list -----
@@ -492,93 +507,6 @@ __device__ __forceinline__ void mx_step(MX &s, const int dg, const double dff, c
     s.g = s.live ? s.g + bh_freq(cf, s.ci) * dff : s.g;
 }
 
-template <bool NOLL3, int N>
-__device__ __forceinline__ void v3_cell_pf(const DevProb &P, const int ca4, const ARegs<N> &A, const CellLists<LList> &L, lu32 *sink,
-    const RS &hd, const lu32 *hdl, const RS &hu, const lu32 *hul, const RS &gu, const lu32 *gul,
-    const RS &g2u, const lu32 *g2ul, const RS &hl, const lu32 *hll, const RS &fl, const lu32 *fll,
-    const RS &f2l, const lu32 *f2ll,
-    lu32 *dh, lu32 *dg, lu32 *dg2, lu32 *df, lu32 *df2,
-    const bool do_vert, const bool do_hori, const double dab, const double pua, const double pub,
-    RS &oH, RS &oG, RS &oG2, RS &oF, RS &oF2, int &trb)
-{
-    // list heads: the records' dynamic lists (a side, b side) and the column's three static lists
-    const DHead a_hd = dh_load<true>(hdl), b_hd = dh_load<true>(hdl + ca4);
-    const DHead a_gu = dh_load<true>(gul), b_gu = dh_load<true>(gul + ca4);
-    const DHead a_hu = dh_load<true>(hul), b_hu = dh_load<true>(hul + ca4);
-    const DHead a_fl = dh_load<true>(fll), b_fl = dh_load<true>(fll + ca4);
-    const DHead a_hl = dh_load<true>(hll), b_hl = dh_load<true>(hll + ca4);
-    const DHead a_g2 = dh_load<true>(NOLL3 ? g2ul : gul), b_g2 = dh_load<true>((NOLL3 ? g2ul : gul) + ca4);
-    const DHead a_f2 = dh_load<true>(NOLL3 ? f2ll : fll), b_f2 = dh_load<true>((NOLL3 ? f2ll : fll) + ca4);
-    const BHead bs = bh_load(L.bs), bt = bh_load(L.bt), br = bh_load(L.br);
-    // ---- gap-open costs: all merges in one uniform loop over the row's static entries -------------------
-    MY y_d, y_gu, y_hu, y_g2;
-    MX x_d, x_fl, x_hl, x_f2;
-    my_init(y_d, true, bt, b_hd); my_init(y_gu, do_vert, br, b_gu); my_init(y_hu, do_vert, br, b_hu);
-    mx_init(x_d, true, bs, b_hd); mx_init(x_fl, do_hori, bs, b_fl); mx_init(x_hl, do_hori, bs, b_hl);
-    if (NOLL3) { my_init(y_g2, do_vert, br, b_g2); mx_init(x_f2, do_hori, bs, b_f2); }
-#pragma unroll 1
-    for (int i = 0; i < N; ++i) {
-        if (wave_none(y_d.live || y_gu.live || y_hu.live || x_d.live || x_fl.live || x_hl.live || (NOLL3 && (y_g2.live || x_f2.live)))) break;
-        my_step(y_d, A.sg[i], A.sf[i], a_hd, bt, b_hd);
-        mx_step(x_d, A.tg[i], A.tf[i], a_hd, bs, b_hd);
-        my_step(y_gu, A.sg[i], A.sf[i], a_gu, br, b_gu);
-        my_step(y_hu, A.sg[i], A.sf[i], a_hu, br, b_hu);
-        mx_step(x_fl, A.rg[i], A.rf[i], a_fl, bs, b_fl);
-        mx_step(x_hl, A.rg[i], A.rf[i], a_hl, bs, b_hl);
-        if (NOLL3) {
-            my_step(y_g2, A.sg[i], A.sf[i], a_g2, br, b_g2);
-            mx_step(x_f2, A.rg[i], A.rf[i], a_f2, bs, b_f2);
-        }
-    }
-    Costs c;
-    c.d0 = y_d.g * P.basic_gop; c.d1 = x_d.g * P.basic_gop;
-    c.gnpv = y_gu.g * P.basic_gop; c.gopv = y_hu.g * P.basic_gop;
-    c.gnph = x_fl.g * P.basic_gop; c.goph = x_hl.g * P.basic_gop;
-    c.gnpv2 = NOLL3 ? y_g2.g * P.basic_gop : 0; c.gnph2 = NOLL3 ? x_f2.g * P.basic_gop : 0;
-    const Dec d = v3_decide<2, NOLL3>(P, c, hd, hu, gu, g2u, hl, fl, f2l, do_vert, do_hori, dab, pua, pub);
-    const int win = d.win;
-    // ---- list updates (update(), fwd2c.cc:216-231) -------------------------------------------------------
-    lu32 *const nul = (lu32 *) 0;
-    // a side: newdelta over a.t for G (G2) and a diagonal H; incdelta for F (F2)
-    {
-        const DHead h_gs = dh_sel(d.g_from_h, a_hu, a_gu), h_gs2 = dh_sel(d.g2_from_h, a_hu, a_g2);
-        ND n_g = {0, 0, 0, do_vert}, n_h = {0, 0, 0, win == 0}, n_g2 = {0, 0, 0, do_vert && NOLL3};
-        lu32 *const g_d2 = win == 1 ? dh : nul, *const g2_d2 = win == 2 ? dh : nul;
-#pragma unroll 1
-        for (int i = 0; i < N; ++i) {
-            if (wave_none(n_g.on || n_h.on || (NOLL3 && n_g2.on))) break;
-            nd_step(n_g, h_gs, A.tg[i], dg, g_d2, sink);
-            nd_step(n_h, a_hd, A.tg[i], dh, nul, sink);
-            if (NOLL3) nd_step(n_g2, h_gs2, A.tg[i], dg2, g2_d2, sink);
-        }
-        nd_fin(n_g, do_vert, dg, g_d2, sink);
-        nd_fin(n_h, win == 0, dh, nul, sink);
-        if (NOLL3) nd_fin(n_g2, do_vert, dg2, g2_d2, sink);
-        incdelta_h(do_hori, dh_sel(d.f_from_h, a_hl, a_fl), df, win == 3 ? dh : nul, sink);
-        if (NOLL3) incdelta_h(do_hori, dh_sel(d.f2_from_h, a_hl, a_f2), df2, win == 4 ? dh : nul, sink);
-    }
-    // b side: newdelta over b.t for F (F2) and a diagonal H; incdelta for G (G2).  The loop index is uniform
-    // (entry k of every lane's column list); lists are as long as the longest one in the wave.
-    {
-        const DHead h_fs = dh_sel(d.f_from_h, b_hl, b_fl), h_fs2 = dh_sel(d.f2_from_h, b_hl, b_f2);
-        ND n_f = {0, 0, 0, do_hori}, n_h = {0, 0, 0, win == 0}, n_f2 = {0, 0, 0, do_hori && NOLL3};
-        lu32 *const f_d2 = win == 3 ? dh + ca4 : nul, *const f2_d2 = win == 4 ? dh + ca4 : nul;
-#pragma unroll 1
-        for (int k = 0; k < DL_GUARD; ++k) {
-            if (wave_none(n_f.on || n_h.on || (NOLL3 && n_f2.on))) break;
-            const int g = bh_glen(bt, k);
-            nd_step(n_f, h_fs, g, df + ca4, f_d2, sink);
-            nd_step(n_h, b_hd, g, dh + ca4, nul, sink);
-            if (NOLL3) nd_step(n_f2, h_fs2, g, df2 + ca4, f2_d2, sink);
-        }
-        nd_fin(n_f, do_hori, df + ca4, f_d2, sink);
-        nd_fin(n_h, win == 0, dh + ca4, nul, sink);
-        if (NOLL3) nd_fin(n_f2, do_hori, df2 + ca4, f2_d2, sink);
-        incdelta_h(do_vert, dh_sel(d.g_from_h, b_hu, b_gu), dg + ca4, win == 1 ? dh + ca4 : nul, sink);
-        if (NOLL3) incdelta_h(do_vert, dh_sel(d.g2_from_h, b_hu, b_g2), dg2 + ca4, win == 2 ? dh + ca4 : nul, sink);
-    }
-    v3_outputs<2, NOLL3>(d, 0, 0, do_vert, do_hori, oH, oG, oG2, oF, oF2, trb);
-}
 
 // record image in HBM: {f64 val; i32 dir; i32 glb; u32 dla[capa]; u32 dlb[capb]} (the v2 format, which the
 // boundary-chain prologue writes): dword k of it <-> scalar k / list entry k - 4
@@ -666,14 +594,19 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
     // ---- static lists of the strip's rows / the block's columns: contiguous pool ranges -> LDS --------
     CellLists<LList> L;
     constexpr int NN = NA > 0 ? NA : 2;
-    int a_sg[NN], a_tg[NN], a_rg[NN];
-    double a_sf[NN], a_tf[NN], a_rf[NN];
-    const ARegs<NN> A = {a_sg, a_sf, a_tg, a_tf, a_rg, a_rf};
+    int a_sg[NN], a_tg[NN];
+    double a_sf[NN], a_tf[NN], a_rhf = 0;
+    bool a_rh = false;
     if (NA > 0) {
-        rl_load(a_sg, a_sf, a, 0, m, row_ok); rl_load(a_tg, a_tf, a, 1, m, row_ok); rl_load(a_rg, a_rf, a, 2, m, row_ok);
+        rl_load(a_sg, a_sf, a, 0, m, row_ok); rl_load(a_tg, a_tf, a, 1, m, row_ok);
+        if (row_ok) {                                      // the r view's head entry, if any (glen 0; the t entries follow with glen + 1)
+            const int o = a.off[2][m + 1], lt_ = a.off[1][m + 2] - a.off[1][m + 1] - 1;
+            if (a.off[2][m + 2] - o - 1 > lt_) { a_rh = true; a_rhf = a.freq[2][o]; }
+        }
         L.as.glen = (li32 *) (lds + LO.aglen); L.as.freq = (lf64 *) (lds + LO.afreq);
         L.at = L.ar = L.bs = L.bt = L.br = L.as;
     } else {
+        a_sg[0] = a_sg[1] = a_tg[0] = a_tg[1] = -1; a_sf[0] = a_sf[1] = a_tf[0] = a_tf[1] = 0;      // (the register lists are not used)
         li32 *ag = (li32 *) (lds + LO.aglen);
         lf64 *af = (lf64 *) (lds + LO.afreq);
         int acc = 0;
@@ -691,6 +624,7 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
         L.as = lv[0]; L.at = lv[1]; L.ar = lv[2];
         L.bs = L.bt = L.br = L.as;
     }
+    const ARegs<NN> A = {a_sg, a_sf, a_tg, a_tf, a_rhf, a_rh};
     li32 *const boff = (li32 *) (lds + LO.boff);
     li32 *const bg = (li32 *) (lds + LO.bglen);
     lf64 *const bf = (lf64 *) (lds + LO.bfreq);
@@ -893,10 +827,7 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
             const double pua = a.nils ? unpa(P, m, n) : pua_row;
             const double pub = bc_cur * a_efq * -P.u;                       // unp1(bsi, asi), maln.h:185-187
             int trb = 0;
-            if (KIND == 2 && NA > 0)
-                v3_cell_pf<NOLL3, (NA > 0 ? NA : 2)>(P, ca4, A, L, (lu32 *) (lds + LO.sink) + lane, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
-                                 dh, dg, dg2, df, df2, do_vert, do_hori, sim_cur, pua, pub, myH, myG, myG2, oF, oF2, trb);
-            else if (KIND == 1 && NA > 0)
+            if (KIND == 1 && NA > 0)
                 v3_cell_hf<NOLL3, (NA > 0 ? NA : 2)>(P, A, (lu32 *) (lds + LO.sink) + lane, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
                                  dh, dg, dg2, df, df2, do_vert, do_hori, sim_cur, pua, pub, myH, myG, myG2, oF, oF2, trb);
             else

@@ -2,22 +2,28 @@
 // merges in RANK form instead of two-pointer walks.
 //
 // Same recurrence and arithmetic order as every other generation (Fwd2c<DPunit_pf>::forwardB, reference src/fwd2c.h:359-482,
-// gapopen/update src/fwd2c.cc:203-233, newgap/newdelta/incdelta src/gfreq.cc:507-521,570-605).  What is new is how a cell's
+// gapopen/update src/fwd2c.cc:203-233, newgap/newdelta/incdelta src/gfreq.cc:507-521,570-605).  What differs is how a cell's
 // six (eight with Noll 3) gap-open costs are evaluated.  newgap(cf, dlc, df, dld) walks df and keeps a pointer into cf that
 // moves to the first entry whose STRETCHED length i = glen + nins(dlc, glen) reaches the stretched length j of the current
 // df entry; both sequences are non-decreasing, so that pointer is simply the lower bound of j in {i}:
 //        g = sum over d (in list order) of  cf.freq[ first c with i_c >= j_d ] * df.freq[d]       (0 once cf is exhausted)
-// Every term is independent of the others; only the ORDER of the additions is part of the contract.  On a 64-wide wave the
-// two-pointer walk is a divergent loop with a dependent LDS read per step (v2: 93 VALU + 125 SALU wave instructions per cell);
-// here every loop runs over a list index that is the same in all lanes:
-//   * row side (a): lane t owns row m0 + t of a 64-row strip; the row's three static lists live in REGISTERS (never change
-//     inside a strip), loops over them are fully unrolled and leave at the wave's longest list;
-//   * column side (b): the columns' static lists stream through a small LDS RING indexed by pool position (lists of
-//     consecutive columns are contiguous in the profile pools), refilled 16 columns at a time; loops over them are rolled
-//     and read entry k of every lane's own column;
-//   * "first c with i_c >= j" is a select chain walked from the last entry down (the lowest hit is written last), no
-//     per-lane pointer, no branch;
-//   * dynamic lists are read through five-entry register heads that are sanitised behind their terminator.
+// Every term is independent of the others; only the ORDER of the additions is part of the contract.  Here every loop runs
+// over a list index that is the same in all lanes, and "first c with i_c >= j" is a select chain walked from the last entry
+// down (the lowest hit is written last): no per-lane pointer, no divergent branch.
+//
+// Second form (round 3).  The first form kept both of the row's static lists in registers (96 VGPRs), the heads of all
+// fourteen dynamic lists of a cell at once and three instances of the cell: 511 registers, 365 spilled SGPRs, 1.1 KB of
+// scratch per lane, one wave per SIMD.  Now:
+//   * the row's s list (at most NS = 8 entries on this path: the host sends longer ones elsewhere) stays in registers; the
+//     row's t list -- the long one -- is staged once per strip into LDS in compact form (the lists of consecutive rows follow
+//     each other, a lane knows its start and length) and every loop over it is a rolled loop reading LDS;
+//   * the X merges (cf = the column's s list, df = the row's t / r list) run with df OUTSIDE: the column's s entries are
+//     stretched once into NC = 6 registers and each row entry walks the select chain (a wave whose longest column list is
+//     longer takes a fully rolled form);
+//   * heads of dynamic lists hold six entries and are loaded per PHASE (merges with the row's s list / with the column's s
+//     list / the two list updates), a lookup beyond the head scans LDS inline behind one wave-uniform test -- ONE instance of
+//     the cell for any list length;
+//   * no private array is indexed by anything but a constant: no scratch.
 // Strips of a DP run as a pipeline on progress counters exactly as in g2g_kernels_v3.hip (sweep mode); record scalars travel
 // down the lanes by DPP; the strip boundary and the boundary chains use the v2 record image in HBM.
 #include <hip/hip_runtime.h>
@@ -41,20 +47,37 @@ __device__ unsigned long long g2g_v6_stamp_acc[16];
 #endif
 
 // byte offsets; ringk / ringf / rs: per view (s, t, r) the key and freq arrays of the column-list ring and its entries (power of 2)
-struct V6Lds { int rows, black, stsc, svals, sink, total; int ringk[3], ringf[3], rs[3]; };
+struct V6Lds { int rows, black, stsc, svals, sink, total; int ringk[3], ringf[3], rs[3]; int atk, atf, atcap, asf, ascap; };   // atk / atf / atcap: keys, freqs and entries of the strip's t lists; asf / ascap: freqs of its s lists
 
 #define V6_FEED 16                      // columns per ring refill
 #define V6_AHEAD 32                     // a refill reaches this many columns beyond lane 0's
 #define V6_WINDOW (64 + V6_AHEAD + 4)   // columns whose lists must fit the ring together
+#define V6_RHCOLS 128                   // columns of the per-column array of r-list heads (a power of 2 >= V6_WINDOW)
+
+// ---- where the dynamic lists of a strip live ---------------------------------------------------------------
+// A record's list may be as long as its side has gap states (hetero + 1 dwords), but 99.98 % of the lists of a refinement sweep
+// have seven entries or fewer.  LDS therefore holds only the first I dwords of a list (its INLINE part: I = 8, or 4 when the
+// side's capacity is 4 -- then nothing else exists); the rest lives in a per-workgroup image in HBM (the list's TWIN: slot
+// offset x 2, so an inline part of I dwords owns 2 I dwords there; capacities above 16 take I = 16, 32).  Only the code that
+// already handled "beyond the register head" ever gets there -- the scans, the stores of a long newdelta result, the strip
+// hand-over of a long list -- always behind a wave-uniform test.  A wave reads back only what it wrote itself, after a
+// s_waitcnt vmcnt(0).  LDS per strip drops from 32-45 KB to 20-27 KB: five or six strips per CU instead of three or four.
+G2G_HD inline int v6_inline_dw(int cap4) { return cap4 <= 4 ? 4 : cap4 <= 16 ? 8 : cap4 <= 32 ? 16 : cap4 <= 64 ? 32 : cap4; }
+struct LS6 { const lu32 *rows0; GLB unsigned *tw; int ia, ib; };          // first dword of the rows, the twin image, inline dwords per side
+__device__ __forceinline__ GLB unsigned *ls6_twin(const LS6 &W, const lu32 *p, const int k) { return W.tw + 2 * (int) (p - W.rows0) + k; }
+__device__ __forceinline__ unsigned ls6_rd(const LS6 &W, const lu32 *p, const int k, const int I) { return k < I ? p[k] : *ls6_twin(W, p, k); }
+__device__ __forceinline__ void ls6_wr(const LS6 &W, lu32 *p, const int k, const int I, const unsigned v)
+{
+    if (k < I) p[k] = v;
+    else { *ls6_twin(W, p, k) = v; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+}
 
 // ---- register heads of dynamic lists ---------------------------------------------------------------------
 // {glen,nins} packed 16+16, ascending in both, terminator 0xFFFF0000; the first entry is never the terminator.  Behind the
 // terminator memory is stale: the head replaces it by terminators, so a lookup is a chain of unsigned compares of the
-// packed key (g << 16 | 0xFFFF) with no validity tests.  NE leading entries are held (5: ds_read_b128 + b64; 8: two b128);
-// x = entry NE, sanitised the same way: x < T says the list is longer than the head.
-// The cell exists in three instances (v6_cell_pf): NE = 5 and NE = 8 WITHOUT any per-lookup test -- they leave at once
-// when some lane's list is longer than the head (0.012 % of the lists have six entries or more, 4e-6 nine or more) -- and
-// NE = 8 with an inline scan of LDS behind the head (SCAN), which is correct for any length.
+// packed key (g << 16 | 0xFFFF) with no validity tests.  NE = 6 leading entries are held (ds_read_b128 + b96);
+// x = entry NE, sanitised the same way: x < T says the list is longer than the head, and a lookup that reaches x scans LDS
+// behind ONE wave-uniform test (0.3 % of the lists of a refinement sweep have seven entries or more).
 #define V6_UNROLL _Pragma("clang loop unroll(full)")
 template <int NE> struct DH { unsigned e[NE]; unsigned x; const lu32 *p; };
 template <int NE>
@@ -66,6 +89,7 @@ __device__ __forceinline__ DH<NE> dh_load6(const lu32 *p)
     h.e[0] = v.x; h.e[1] = v.y; h.e[2] = v.z; h.e[3] = v.w;
     if (NE == 8) { const v4u32 w = *(const LDS v4u32 *) (p + 4); h.e[4] = w.x; h.e[5] = w.y; h.e[6] = w.z; h.e[7] = w.w; h.x = p[8]; }
     else if (NE == 5) { const unsigned long long w = *(const LDS unsigned long long *) (p + 4); h.e[4] = (unsigned) w; h.x = (unsigned) (w >> 32); }
+    else if (NE == 6) { typedef unsigned v3u32 __attribute__((ext_vector_type(3))); const v3u32 w = *(const LDS v3u32 *) (p + 4); h.e[4] = w.x; h.e[5] = w.y; h.x = w.z; }
     else h.x = p[NE];
     V6_UNROLL
     for (int k = 2; k < NE; ++k) h.e[k] = (h.e[k - 1] >= T) ? T : h.e[k];
@@ -77,7 +101,7 @@ __device__ __forceinline__ DH<NE> dh_load6(const lu32 *p)
 __device__ __forceinline__ unsigned v6_key(const int g) { return ((unsigned) (g < 0 ? 0 : g) << 16) | 0xFFFFu; }
 // the entry that governs static gap length g (GapLenSD, gfreq.h:67): the largest entry <= key
 template <int NE, bool SCAN>
-__device__ __forceinline__ unsigned dh_ent(const unsigned key, const DH<NE> &h)
+__device__ __forceinline__ unsigned dh_ent(const unsigned key, const DH<NE> &h, const LS6 &W, const int I)
 {
     unsigned e = h.e[0];
     V6_UNROLL
@@ -87,8 +111,13 @@ __device__ __forceinline__ unsigned dh_ent(const unsigned key, const DH<NE> &h)
         if (__ballot(more)) {                               // more than NE entries at or below g
             if (more) {
                 int k = NE;
-                while (k < DL_GUARD && key >= h.p[k + 1]) ++k;
-                e = h.p[k];
+                e = h.x;
+                for (;;) {                                  // e = entry k (at or below the key); stop when entry k + 1 is above it
+                    if (k + 1 >= DL_GUARD) break;
+                    const unsigned nx = ls6_rd(W, h.p, k + 1, I);
+                    if (key < nx) break;
+                    e = nx; ++k;
+                }
             }
         }
     }
@@ -97,7 +126,7 @@ __device__ __forceinline__ unsigned dh_ent(const unsigned key, const DH<NE> &h)
 // Stretched lengths are compared, never used as numbers: they stay in key form, ((glen + nins) << 16) | 0xFFFF, which is
 // one shift-add on the matched entry (no overflow: glen + nins < 65536 on this path)
 template <int NE, bool SCAN>
-__device__ __forceinline__ unsigned dh_stretch(const unsigned key, const DH<NE> &h) { return (dh_ent<NE, SCAN>(key, h) << 16) + key; }
+__device__ __forceinline__ unsigned dh_stretch(const unsigned key, const DH<NE> &h, const LS6 &W, const int I) { return (dh_ent<NE, SCAN>(key, h, W, I) << 16) + key; }
 template <int NE>
 __device__ __forceinline__ DH<NE> dh_sel6(const bool c, const DH<NE> &x, const DH<NE> &y)
 {
@@ -110,7 +139,7 @@ __device__ __forceinline__ DH<NE> dh_sel6(const bool c, const DH<NE> &x, const D
 // incdelta(dlt, dln, 1), gfreq.cc:598-605, from a head: the leading entries go out as 16-byte stores (what lands behind
 // the terminator is stale by definition); d2: second destination or the lane's 16-byte sink
 template <int NE, bool SCAN>
-__device__ __forceinline__ void v6_incdelta(const bool on, const DH<NE> &h, lu32 *d1, lu32 *d2, lu32 *sink16)
+__device__ __forceinline__ void v6_incdelta(const bool on, const DH<NE> &h, lu32 *d1, lu32 *d2, lu32 *sink16, const LS6 &W, const int I)
 {
     const unsigned T = DL_END << 16;
     v4u32 w;
@@ -121,6 +150,14 @@ __device__ __forceinline__ void v6_incdelta(const bool on, const DH<NE> &h, lu32
         const bool m4 = on && h.e[3] < T;
         if (__ballot(m4)) {
             const unsigned long long w45 = ((unsigned long long) T << 32) | (h.e[4] >= T ? T : h.e[4] + 1);
+            *(LDS unsigned long long *) (m4 ? d1 + 4 : sink16) = w45;
+            *(LDS unsigned long long *) ((m4 && d2) ? d2 + 4 : sink16) = w45;
+        }
+    }
+    if (NE == 6) {                                          // entries 4 and 5 (the terminator is one of them when the list has four or five
+        const bool m4 = on && h.e[3] < T;                   // entries; behind a sixth entry the scan below goes on)
+        if (__ballot(m4)) {
+            const unsigned long long w45 = ((unsigned long long) (h.e[5] >= T ? T : h.e[5] + 1) << 32) | (h.e[4] >= T ? T : h.e[4] + 1);
             *(LDS unsigned long long *) (m4 ? d1 + 4 : sink16) = w45;
             *(LDS unsigned long long *) ((m4 && d2) ? d2 + 4 : sink16) = w45;
         }
@@ -142,10 +179,10 @@ __device__ __forceinline__ void v6_incdelta(const bool on, const DH<NE> &h, lu32
         if (__ballot(more)) {
             if (more) {
                 for (int k = NE; k < DL_GUARD; ++k) {
-                    unsigned e = h.p[k];
-                    if (e >= T) { d1[k] = e; if (d2) d2[k] = e; break; }
-                    e += 1;
-                    d1[k] = e; if (d2) d2[k] = e;
+                    unsigned e = ls6_rd(W, h.p, k, I);
+                    if (e < T) e += 1;
+                    ls6_wr(W, d1, k, I, e); if (d2) ls6_wr(W, d2, k, I, e);
+                    if (e >= T) break;
                 }
             }
         }
@@ -153,22 +190,34 @@ __device__ __forceinline__ void v6_incdelta(const bool on, const DH<NE> &h, lu32
 }
 // newdelta (gfreq.cc:570-587) as a step function over the static entries of a t list
 struct ND6 { int kd; unsigned tg, tn; bool on; };
-template <int NE, bool SCAN>
-__device__ __forceinline__ void nd6_step(ND6 &s, const DH<NE> &h, const int g, const unsigned key, lu32 *d1, lu32 *d2, lu32 *sink)
+// (LONG: some lane of the wave is about to store at or beyond the inline part)
+template <int NE, bool SCAN, bool LONG>
+__device__ __forceinline__ void nd6_step(ND6 &s, const DH<NE> &h, const int g, const unsigned key, lu32 *d1, lu32 *d2, lu32 *sink, const LS6 &W, const int I)
 {
-    const unsigned sn = dh_ent<NE, SCAN>(key, h) & 0xFFFFu;
+    const unsigned sn = dh_ent<NE, SCAN>(key, h, W, I) & 0xFFFFu;
     const bool emit = s.on && g >= 0 && sn > s.tn;
     const unsigned e = (s.tg << 16) | s.tn;
-    *(emit ? d1 + s.kd : sink) = e;
-    *((emit && d2) ? d2 + s.kd : sink) = e;
+    if (LONG) {
+        if (emit) { ls6_wr(W, d1, s.kd, I, e); if (d2) ls6_wr(W, d2, s.kd, I, e); }
+    } else {
+        *(emit ? d1 + s.kd : sink) = e;
+        *((emit && d2) ? d2 + s.kd : sink) = e;
+    }
     s.kd += emit ? 1 : 0;
     s.tn = emit ? sn : s.tn;
     s.tg = emit ? (unsigned) (g + 1) : s.tg;
     s.on = s.on && g >= 0;
 }
-__device__ __forceinline__ void nd6_fin(const ND6 &s, const bool was_on, lu32 *d1, lu32 *d2, lu32 *sink)
+__device__ __forceinline__ void nd6_fin(const ND6 &s, const bool was_on, lu32 *d1, lu32 *d2, lu32 *sink, const LS6 &W, const int I)
 {
     const unsigned e = (s.tg << 16) | s.tn;
+    if (__ballot(was_on && s.kd + 1 >= I)) {                // the last entry or the terminator of some lane lands beyond the inline part
+        if (was_on) {
+            ls6_wr(W, d1, s.kd, I, e); ls6_wr(W, d1, s.kd + 1, I, DL_END << 16);
+            if (d2) { ls6_wr(W, d2, s.kd, I, e); ls6_wr(W, d2, s.kd + 1, I, DL_END << 16); }
+        }
+        return;
+    }
     *(was_on ? d1 + s.kd : sink) = e;
     *(was_on ? d1 + s.kd + 1 : sink) = DL_END << 16;
     *((was_on && d2) ? d2 + s.kd : sink) = e;
@@ -188,51 +237,82 @@ __device__ __forceinline__ SE6 se6_read(const Ring6 &r, const int idx)
     SE6 e; e.key = r.k[i]; e.f = r.f[i]; e.g = (int) (e.key >> 16); return e;
 }
 
-// the row's static lists in registers: glen as lookup key ((g << 16) | 0xFFFF; slots behind the list: key 0xFFFF, freq 0) and freq;
-// ls / lt / lr: the lane's list lengths
-// The r view is not held: r = [head {glen 0, freq rhf}, if present] + the t list with glen + 1 (DevSide::r_from_t).
-template <int N> struct A6 { const unsigned (&sk)[N]; const double (&sf)[N]; const unsigned (&tk)[N]; const double (&tf)[N]; double rhf; int ls, lt; };
-struct B6 { Ring6 rs, rt, rr; int os, ot, orr, lens, lent, lenr; };         // the lane's column: rings, list starts (compact), lengths
+// The row's lists.  s (cf of the Y merges): registers, glen as lookup key ((g << 16) | 0xFFFF; slots behind the list: key 0xFFFF,
+// freq 0), at most NS entries.  t (df of the X merges, the list newdelta walks): LDS, compact -- entry k of the lane's list
+// is tk[at0 + k] / tf[at0 + k] for k < lt; TAs / TAt: the wave's longest s / t list.  The r view is not held: r = [head {glen 0,
+// freq rhf}, if present] + the t list with glen + 1 (DevSide::r_from_t).
+#define V6_NS 12
+#define V6_NC 6
+struct A6 { const unsigned (&sk)[V6_NS]; const lf64 *sf; const lu32 *tk; const lf64 *tf; double rhf; int ls, lt, as0, at0, TAs, TAt; };    // (sf[as0 + k]: the s entries' freqs, in LDS like the t list)
+// the lane's column: rings of its s and t lists, list starts (compact), lengths.  The r view has no ring: r = [head {glen 0, freq rhf}, if the
+// column has one (lenr > lent)] + the t entries with glen + 1 (DevSide::r_from_t, checked by the host); rhf comes from a per-column array
+struct B6 { Ring6 rs, rt; int os, ot, lens, lent, lenr; double rhf; };
+typedef DH<6> DHn;
+#define V6_STRA(key, h) dh_stretch<6, true>((key), (h), W, W.ia)        /* stretched by a record's a-side / b-side list */
+#define V6_STRB(key, h) dh_stretch<6, true>((key), (h), W, W.ib)
 
-// one "X" merge: cf = the column's s list (ring, stretched by dlb of the record), df = a row list in registers (stretched by
-// dla): newgap(b.s, dlb, a.t|a.r, dla).  RV: df is the r view = an optional head entry {glen 0, freq hf} followed by the t
-// entries with glen + 1 (hf = 0: no head; its term is then +0).  lmax: the wave's longest s list.  Slots behind the row's
-// list hold key 0xFFFF / freq 0: their terms are +0 as well, so validity needs no test.
-template <int N, int NE, bool SCAN, bool RV>
-__device__ __forceinline__ double v6_xmerge(const DH<NE> &ha, const DH<NE> &hb, const unsigned (&dk)[N], const double (&dfq)[N], const double hf,
-                                            const int TA, const B6 &B, const int lmax)
+// one "X" merge: cf = the column's s list (ring, stretched by dlb of the record), df = a row list (LDS, stretched by dla):
+// newgap(b.s, dlb, a.t|a.r, dla).  RV: df is the r view = an optional head entry {glen 0, freq rhf} followed by the t entries with
+// glen + 1 (rhf = 0: no head; its term is then +0).  lmax: the wave's longest column s list.  The column's entries are
+// stretched once (NC registers); a term of a lane whose list is shorter than the loop's index is +0.
+template <bool RV>
+__device__ __forceinline__ double v6_xmerge(const DHn &ha, const DHn &hb, const A6 &A, const B6 &B, const int lmax, const LS6 &W)
 {
-    unsigned j[N], jh = 0;
-    double S[N], Sh = 0;
-    if (RV) jh = dh_stretch<NE, SCAN>(0xFFFFu, ha);
-    V6_UNROLL
-    for (int d = 0; d < N; ++d) {
-        if (d < TA) {
-            j[d] = dh_stretch<NE, SCAN>(dk[d] + (RV ? 0x10000u : 0u), ha);
-            S[d] = 0;
+    double g = 0;
+    if (lmax <= V6_NC) {
+        unsigned ic[V6_NC];
+        double fc[V6_NC];
+        V6_UNROLL
+        for (int c = 0; c < V6_NC; ++c) {
+            ic[c] = 0u; fc[c] = 0.;
+            if (c < lmax) {
+                const bool valid = c < B.lens;
+                const SE6 e = se6_read(B.rs, B.os + (valid ? c : 0));
+                ic[c] = valid ? V6_STRB(e.key, hb) : 0u;            // (0 never reaches a stretched length: those are >= 0xFFFF)
+                fc[c] = e.f;
+            }
+        }
+#define V6_XCHAIN(S, j) { V6_UNROLL for (int c = V6_NC - 1; c >= 0; --c) if (c < lmax) S = ic[c] >= (j) ? fc[c] : S; }
+        if (RV) {
+            const unsigned jh = V6_STRA(0xFFFFu, ha);
+            double S = 0;
+            V6_XCHAIN(S, jh)
+            g += S * A.rhf;
+        }
+        for (int d = 0; d < A.TAt; ++d) {
+            const bool valid = d < A.lt;
+            const int at = A.at0 + (valid ? d : 0);
+            const unsigned key = A.tk[at];
+            const double f = valid ? A.tf[at] : 0.;
+            const unsigned j = V6_STRA(key + (RV ? 0x10000u : 0u), ha);
+            double S = 0;
+            V6_XCHAIN(S, j)
+            g += S * f;
+        }
+#undef V6_XCHAIN
+    } else {                                                     // a column list longer than NC somewhere in the wave: both loops rolled
+        for (int d = RV ? -1 : 0; d < A.TAt; ++d) {
+            const bool valid = d < A.lt;
+            const int at = A.at0 + ((valid && d >= 0) ? d : 0);
+            const unsigned key = d < 0 ? 0xFFFFu : A.tk[at] + (RV ? 0x10000u : 0u);
+            const double f = d < 0 ? A.rhf : valid ? A.tf[at] : 0.;
+            const unsigned j = V6_STRA(key, ha);
+            double S = 0;
+            for (int kk = lmax - 1; kk >= 0; --kk) {
+                const bool cv = kk < B.lens;
+                const SE6 e = se6_read(B.rs, B.os + (cv ? kk : 0));
+                const unsigned i = cv ? V6_STRB(e.key, hb) : 0u;
+                S = i >= j ? e.f : S;
+            }
+            g += S * f;
         }
     }
-    for (int kk = lmax - 1; kk >= 0; --kk) {
-        const bool valid = kk < B.lens;
-        const SE6 e = se6_read(B.rs, B.os + (valid ? kk : 0));
-        const unsigned i = valid ? dh_stretch<NE, SCAN>(e.key, hb) : 0u;
-        if (RV) Sh = i >= jh ? e.f : Sh;
-        V6_UNROLL
-        for (int d = 0; d < N; ++d)
-            if (d < TA) S[d] = i >= j[d] ? e.f : S[d];
-    }
-    double g = 0;
-    if (RV) g += Sh * hf;
-    V6_UNROLL
-    for (int d = 0; d < N; ++d)
-        if (d < TA) g += S[d] * dfq[d];
     return g;
 }
 
 // ---- one cell by one lane ----------------------------------------------------------------------------------
-// Returns false -- before anything is stored -- when !SCAN and some lane's list is longer than the heads of this instance.
-template <bool NOLL3, int N, int NE, bool SCAN>
-__device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, const A6<N> &A, const int TAs, const int TAt,
+template <bool NOLL3>
+__device__ __forceinline__ void v6_cell_pf(const DevProb &P, const LS6 &W, const A6 &A,
     const B6 &B, lu32 *sink, lu32 *sink16,
     const RS &hd, const lu32 *hdl, const RS &hu, const lu32 *hul, const RS &gu, const lu32 *gul,
     const RS &g2u, const lu32 *g2ul, const RS &hl, const lu32 *hll, const RS &fl, const lu32 *fll,
@@ -241,23 +321,7 @@ __device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, cons
     const bool do_vert, const bool do_hori, const double dab, const double pua, const double pub,
     RS &oH, RS &oG, RS &oG2, RS &oF, RS &oF2, int &trb V6_STAMP_ARGS)
 {
-    typedef DH<NE> DHn;
-    // heads of the dynamic lists of the five (seven) records this cell reads: a side and b side
-    const DHn a_hd = dh_load6<NE>(hdl), b_hd = dh_load6<NE>(hdl + ca4);
-    const DHn a_gu = dh_load6<NE>(gul), b_gu = dh_load6<NE>(gul + ca4);
-    const DHn a_hu = dh_load6<NE>(hul), b_hu = dh_load6<NE>(hul + ca4);
-    const DHn a_fl = dh_load6<NE>(fll), b_fl = dh_load6<NE>(fll + ca4);
-    const DHn a_hl = dh_load6<NE>(hll), b_hl = dh_load6<NE>(hll + ca4);
-    const DHn a_g2 = dh_load6<NE>(NOLL3 ? g2ul : gul), b_g2 = dh_load6<NE>((NOLL3 ? g2ul : gul) + ca4);
-    const DHn a_f2 = dh_load6<NE>(NOLL3 ? f2ll : fll), b_f2 = dh_load6<NE>((NOLL3 ? f2ll : fll) + ca4);
-    if (!SCAN) {
-        const unsigned T = DL_END << 16;
-        unsigned mn = a_hd.x < b_hd.x ? a_hd.x : b_hd.x;
-        mn = a_gu.x < mn ? a_gu.x : mn; mn = b_gu.x < mn ? b_gu.x : mn; mn = a_hu.x < mn ? a_hu.x : mn; mn = b_hu.x < mn ? b_hu.x : mn;
-        mn = a_fl.x < mn ? a_fl.x : mn; mn = b_fl.x < mn ? b_fl.x : mn; mn = a_hl.x < mn ? a_hl.x : mn; mn = b_hl.x < mn ? b_hl.x : mn;
-        if (NOLL3) { mn = a_g2.x < mn ? a_g2.x : mn; mn = b_g2.x < mn ? b_g2.x : mn; mn = a_f2.x < mn ? a_f2.x : mn; mn = b_f2.x < mn ? b_f2.x : mn; }
-        if (__ballot(mn < T)) { V6_STAMP(8) return false; }
-    }
+    const int ca4 = W.ia;                                   // a record's b-side list follows its a-side list's inline part
     V6_STAMP(1)
     Costs c;
     c.d0 = c.d1 = c.gnpv = c.gopv = c.gnph = c.goph = c.gnpv2 = c.gnph2 = 0;
@@ -265,45 +329,56 @@ __device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, cons
     // ---- "Y" merges: cf = the row's s list (registers), df = a column list (ring): diagonal part 0 (b.t, record hd),
     // vertical gnp / gop (b.r, records gu / hu), vertical2 (b.r, g2u) -- gfreq.cc:507-521 in rank form
     {
-        unsigned i_hd[N], i_gu[N], i_hu[N], i_g2[N];          // stretched keys
+        unsigned i_hd[V6_NS], i_gu[V6_NS], i_hu[V6_NS], i_g2[V6_NS];          // stretched keys
         unsigned m_hd = 0, m_gu = 0, m_hu = 0, m_g2 = 0;
-        V6_UNROLL
-        for (int k = 0; k < N; ++k) {
-            if (k < TAs) {
-                // (slots behind the list: key 0xFFFF, freq 0 -- a hit there selects freq 0, which is what an exhausted cf adds)
-                const unsigned key = A.sk[k];
-                i_hd[k] = dh_stretch<NE, SCAN>(key, a_hd);
-                i_gu[k] = dh_stretch<NE, SCAN>(key, a_gu);
-                i_hu[k] = dh_stretch<NE, SCAN>(key, a_hu);
-                if (NOLL3) i_g2[k] = dh_stretch<NE, SCAN>(key, a_g2);
-                m_hd = i_hd[k] > m_hd ? i_hd[k] : m_hd;
-                m_gu = i_gu[k] > m_gu ? i_gu[k] : m_gu;
-                m_hu = i_hu[k] > m_hu ? i_hu[k] : m_hu;
-                if (NOLL3) m_g2 = i_g2[k] > m_g2 ? i_g2[k] : m_g2;
+        {   // (the a-side heads live only while the row's keys are stretched; the b-side heads are read after that)
+            const DHn a_hd = dh_load6<6>(hdl), a_gu = dh_load6<6>(gul), a_hu = dh_load6<6>(hul), a_g2 = dh_load6<6>(NOLL3 ? g2ul : gul);
+            V6_UNROLL
+            for (int k = 0; k < V6_NS; ++k) {
+                i_hd[k] = i_gu[k] = i_hu[k] = i_g2[k] = 0u;
+                if (k < A.TAs) {
+                    // (slots behind the list: key 0xFFFF, freq 0 -- a hit there selects freq 0, which is what an exhausted cf adds)
+                    const unsigned key = A.sk[k];
+                    i_hd[k] = V6_STRA(key, a_hd);
+                    i_gu[k] = V6_STRA(key, a_gu);
+                    i_hu[k] = V6_STRA(key, a_hu);
+                    if (NOLL3) i_g2[k] = V6_STRA(key, a_g2);
+                    m_hd = i_hd[k] > m_hd ? i_hd[k] : m_hd;
+                    m_gu = i_gu[k] > m_gu ? i_gu[k] : m_gu;
+                    m_hu = i_hu[k] > m_hu ? i_hu[k] : m_hu;
+                    if (NOLL3) m_g2 = i_g2[k] > m_g2 ? i_g2[k] : m_g2;
+                }
             }
         }
+        asm volatile("" ::: "memory");
+        const DHn b_hd = dh_load6<6>(hdl + ca4), b_gu = dh_load6<6>(gul + ca4), b_hu = dh_load6<6>(hul + ca4), b_g2 = dh_load6<6>((NOLL3 ? g2ul : gul) + ca4);
         double g0 = 0, g1 = 0, g2 = 0, g3 = 0;
         bool l0 = true, l1 = do_vert, l2 = do_vert, l3 = do_vert && NOLL3;
         for (int d = 0; d < DL_GUARD; ++d) {
             if (wave_none(l0 || l1 || l2 || l3)) break;
-            const SE6 et = se6_read(B.rt, B.ot + d), er = se6_read(B.rr, B.orr + d);
+            const int dr = d - (B.lenr > B.lent ? 1 : 0);                          // entry d of the r view: the head, or t entry d - 1 / d
+            const SE6 et = se6_read(B.rt, B.ot + d), ert = se6_read(B.rt, B.ot + (dr < 0 ? 0 : dr));
+            SE6 er;
+            er.key = dr < 0 ? 0xFFFFu : ert.key + 0x10000u; er.f = dr < 0 ? B.rhf : ert.f; er.g = (int) (er.key >> 16);
             l0 = l0 && d < B.lent;
             const bool lv = d < B.lenr;
             l1 = l1 && lv; l2 = l2 && lv; l3 = l3 && lv;
-            const unsigned j0 = dh_stretch<NE, SCAN>(et.key, b_hd), j1 = dh_stretch<NE, SCAN>(er.key, b_gu), j2 = dh_stretch<NE, SCAN>(er.key, b_hu);
-            const unsigned j3 = NOLL3 ? dh_stretch<NE, SCAN>(er.key, b_g2) : 0u;
+            const unsigned j0 = V6_STRB(et.key, b_hd), j1 = V6_STRB(er.key, b_gu), j2 = V6_STRB(er.key, b_hu);
+            const unsigned j3 = NOLL3 ? V6_STRB(er.key, b_g2) : 0u;
             l0 = l0 && m_hd >= j0; l1 = l1 && m_gu >= j1; l2 = l2 && m_hu >= j2; l3 = l3 && m_g2 >= j3;       // cf exhausted: break
-            double S0 = 0, S1 = 0, S2 = 0, S3 = 0;
-            // from the wave's last s entry down to entry 0: a fall-through switch (a guarded unrolled loop is turned into
-            // selects over all N entries by the compiler; the jump is wave-uniform)
-#define V6_YCH(k) if (N > (k)) { S0 = i_hd[k] >= j0 ? A.sf[k] : S0; S1 = i_gu[k] >= j1 ? A.sf[k] : S1; S2 = i_hu[k] >= j2 ? A.sf[k] : S2; \
-                                 if (NOLL3) S3 = i_g2[k] >= j3 ? A.sf[k] : S3; }
-            switch (TAs) {
-            default: V6_YCH(15) case 15: V6_YCH(14) case 14: V6_YCH(13) case 13: V6_YCH(12) case 12: V6_YCH(11) case 11: V6_YCH(10)
-            case 10: V6_YCH(9) case 9: V6_YCH(8) case 8: V6_YCH(7) case 7: V6_YCH(6) case 6: V6_YCH(5) case 5: V6_YCH(4)
+            // from the wave's last s entry down to entry 0 the chain keeps the INDEX of the lowest hit (a fall-through switch: the jump
+            // is wave-uniform); the entry's freq is then read from LDS -- a hit behind the lane's own list stands for "cf exhausted"
+            int K0 = -1, K1 = -1, K2 = -1, K3 = -1;
+#define V6_YCH(k) { K0 = i_hd[k] >= j0 ? (k) : K0; K1 = i_gu[k] >= j1 ? (k) : K1; K2 = i_hu[k] >= j2 ? (k) : K2; if (NOLL3) K3 = i_g2[k] >= j3 ? (k) : K3; }
+            switch (A.TAs) {
+            default: V6_YCH(11) case 11: V6_YCH(10) case 10: V6_YCH(9)
+            case 9: V6_YCH(8) case 8: V6_YCH(7) case 7: V6_YCH(6) case 6: V6_YCH(5) case 5: V6_YCH(4)
             case 4: V6_YCH(3) case 3: V6_YCH(2) case 2: V6_YCH(1) case 1: V6_YCH(0) case 0: ;
             }
 #undef V6_YCH
+#define V6_YSF(K) (((unsigned) (K) < (unsigned) A.ls) ? A.sf[A.as0 + (K)] : 0.)
+            const double S0 = V6_YSF(K0), S1 = V6_YSF(K1), S2 = V6_YSF(K2), S3 = NOLL3 ? V6_YSF(K3) : 0.;
+#undef V6_YSF
             g0 = l0 ? g0 + S0 * et.f : g0;
             g1 = l1 ? g1 + S1 * er.f : g1;
             g2 = l2 ? g2 + S2 * er.f : g2;
@@ -318,10 +393,10 @@ __device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, cons
     {
         int lmax = 0;
         while (__ballot(B.lens > lmax)) ++lmax;
-        c.d1 = v6_xmerge<N, NE, SCAN, false>(a_hd, b_hd, A.tk, A.tf, 0., TAt, B, lmax) * P.basic_gop;
-        c.gnph = v6_xmerge<N, NE, SCAN, true>(a_fl, b_fl, A.tk, A.tf, A.rhf, TAt, B, lmax) * P.basic_gop;
-        c.goph = v6_xmerge<N, NE, SCAN, true>(a_hl, b_hl, A.tk, A.tf, A.rhf, TAt, B, lmax) * P.basic_gop;
-        c.gnph2 = NOLL3 ? v6_xmerge<N, NE, SCAN, true>(a_f2, b_f2, A.tk, A.tf, A.rhf, TAt, B, lmax) * P.basic_gop : 0;
+        { const DHn ha = dh_load6<6>(hdl), hb = dh_load6<6>(hdl + ca4); c.d1 = v6_xmerge<false>(ha, hb, A, B, lmax, W) * P.basic_gop; }
+        { const DHn ha = dh_load6<6>(fll), hb = dh_load6<6>(fll + ca4); c.gnph = v6_xmerge<true>(ha, hb, A, B, lmax, W) * P.basic_gop; }
+        { const DHn ha = dh_load6<6>(hll), hb = dh_load6<6>(hll + ca4); c.goph = v6_xmerge<true>(ha, hb, A, B, lmax, W) * P.basic_gop; }
+        if (NOLL3) { const DHn ha = dh_load6<6>(f2ll), hb = dh_load6<6>(f2ll + ca4); c.gnph2 = v6_xmerge<true>(ha, hb, A, B, lmax, W) * P.basic_gop; }
     }
 #endif
     V6_STAMP(3)
@@ -329,51 +404,66 @@ __device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, cons
     const int win = d.win;
     V6_STAMP(4)
     // ---- list updates (update(), fwd2c.cc:216-231); the winner's lists are also the new H's -------------------
+    // Sources are read into heads BEFORE the destinations of the same side are written (the lane below reads this lane's
+    // lists of the previous step from the slots this step overwrites only in ITS next step).
     lu32 *const nul = (lu32 *) 0;
 #ifndef V6_SKIP_ND
     {   // a side: newdelta over a.t for G (G2) and a diagonal H; incdelta for F (F2)
-        const DHn h_gs = dh_sel6<NE>(d.g_from_h, a_hu, a_gu), h_gs2 = dh_sel6<NE>(d.g2_from_h, a_hu, a_g2);
+        const DHn h_gs = dh_load6<6>(d.g_from_h ? hul : gul), h_hd = dh_load6<6>(hdl), h_fi = dh_load6<6>(d.f_from_h ? hll : fll);
+        const DHn h_gs2 = dh_load6<6>(NOLL3 ? (d.g2_from_h ? hul : g2ul) : gul), h_fi2 = dh_load6<6>(NOLL3 ? (d.f2_from_h ? hll : f2ll) : fll);
         ND6 n_g = {0, 0, 0, do_vert}, n_h = {0, 0, 0, win == 0}, n_g2 = {0, 0, 0, do_vert && NOLL3};
         lu32 *const g_d2 = win == 1 ? dh : nul, *const g2_d2 = win == 2 ? dh : nul;
-        V6_UNROLL
-        for (int k = 0; k < N; ++k) {
-            if (k < TAt) {
-                const int g = k < A.lt ? (int) (A.tk[k] >> 16) : -1;
-                nd6_step<NE, SCAN>(n_g, h_gs, g, A.tk[k], dg, g_d2, sink);
-                nd6_step<NE, SCAN>(n_h, a_hd, g, A.tk[k], dh, nul, sink);
-                if (NOLL3) nd6_step<NE, SCAN>(n_g2, h_gs2, g, A.tk[k], dg2, g2_d2, sink);
+        for (int k = 0; k < A.TAt; ++k) {
+            if (wave_none(n_g.on || n_h.on || (NOLL3 && n_g2.on))) break;
+            const bool valid = k < A.lt;
+            const unsigned key = A.tk[A.at0 + (valid ? k : 0)];
+            const int g = valid ? (int) (key >> 16) : -1;
+            if (__ballot(n_g.kd >= W.ia || n_h.kd >= W.ia || (NOLL3 && n_g2.kd >= W.ia))) {          // a result outgrows its inline part
+                nd6_step<6, true, true>(n_g, h_gs, g, key, dg, g_d2, sink, W, W.ia);
+                nd6_step<6, true, true>(n_h, h_hd, g, key, dh, nul, sink, W, W.ia);
+                if (NOLL3) nd6_step<6, true, true>(n_g2, h_gs2, g, key, dg2, g2_d2, sink, W, W.ia);
+            } else {
+                nd6_step<6, true, false>(n_g, h_gs, g, key, dg, g_d2, sink, W, W.ia);
+                nd6_step<6, true, false>(n_h, h_hd, g, key, dh, nul, sink, W, W.ia);
+                if (NOLL3) nd6_step<6, true, false>(n_g2, h_gs2, g, key, dg2, g2_d2, sink, W, W.ia);
             }
         }
-        nd6_fin(n_g, do_vert, dg, g_d2, sink);
-        nd6_fin(n_h, win == 0, dh, nul, sink);
-        if (NOLL3) nd6_fin(n_g2, do_vert, dg2, g2_d2, sink);
-        v6_incdelta<NE, SCAN>(do_hori, dh_sel6<NE>(d.f_from_h, a_hl, a_fl), df, win == 3 ? dh : nul, sink16);
-        if (NOLL3) v6_incdelta<NE, SCAN>(do_hori, dh_sel6<NE>(d.f2_from_h, a_hl, a_f2), df2, win == 4 ? dh : nul, sink16);
+        nd6_fin(n_g, do_vert, dg, g_d2, sink, W, W.ia);
+        nd6_fin(n_h, win == 0, dh, nul, sink, W, W.ia);
+        if (NOLL3) nd6_fin(n_g2, do_vert, dg2, g2_d2, sink, W, W.ia);
+        v6_incdelta<6, true>(do_hori, h_fi, df, win == 3 ? dh : nul, sink16, W, W.ia);
+        if (NOLL3) v6_incdelta<6, true>(do_hori, h_fi2, df2, win == 4 ? dh : nul, sink16, W, W.ia);
     }
     V6_STAMP(5)
     {   // b side: newdelta over b.t for F (F2) and a diagonal H; incdelta for G (G2)
-        const DHn h_fs = dh_sel6<NE>(d.f_from_h, b_hl, b_fl), h_fs2 = dh_sel6<NE>(d.f2_from_h, b_hl, b_f2);
+        const DHn h_fs = dh_load6<6>((d.f_from_h ? hll : fll) + ca4), h_hd = dh_load6<6>(hdl + ca4), h_gi = dh_load6<6>((d.g_from_h ? hul : gul) + ca4);
+        const DHn h_fs2 = dh_load6<6>((NOLL3 ? (d.f2_from_h ? hll : f2ll) : fll) + ca4), h_gi2 = dh_load6<6>((NOLL3 ? (d.g2_from_h ? hul : g2ul) : gul) + ca4);
         ND6 n_f = {0, 0, 0, do_hori}, n_h = {0, 0, 0, win == 0}, n_f2 = {0, 0, 0, do_hori && NOLL3};
         lu32 *const f_d2 = win == 3 ? dh + ca4 : nul, *const f2_d2 = win == 4 ? dh + ca4 : nul;
         for (int k = 0; k < DL_GUARD; ++k) {
             if (wave_none(n_f.on || n_h.on || (NOLL3 && n_f2.on))) break;
             const SE6 e = se6_read(B.rt, B.ot + k);
             const int g = k < B.lent ? e.g : -1;
-            nd6_step<NE, SCAN>(n_f, h_fs, g, e.key, df + ca4, f_d2, sink);
-            nd6_step<NE, SCAN>(n_h, b_hd, g, e.key, dh + ca4, nul, sink);
-            if (NOLL3) nd6_step<NE, SCAN>(n_f2, h_fs2, g, e.key, df2 + ca4, f2_d2, sink);
+            if (__ballot(n_f.kd >= W.ib || n_h.kd >= W.ib || (NOLL3 && n_f2.kd >= W.ib))) {
+                nd6_step<6, true, true>(n_f, h_fs, g, e.key, df + ca4, f_d2, sink, W, W.ib);
+                nd6_step<6, true, true>(n_h, h_hd, g, e.key, dh + ca4, nul, sink, W, W.ib);
+                if (NOLL3) nd6_step<6, true, true>(n_f2, h_fs2, g, e.key, df2 + ca4, f2_d2, sink, W, W.ib);
+            } else {
+                nd6_step<6, true, false>(n_f, h_fs, g, e.key, df + ca4, f_d2, sink, W, W.ib);
+                nd6_step<6, true, false>(n_h, h_hd, g, e.key, dh + ca4, nul, sink, W, W.ib);
+                if (NOLL3) nd6_step<6, true, false>(n_f2, h_fs2, g, e.key, df2 + ca4, f2_d2, sink, W, W.ib);
+            }
         }
-        nd6_fin(n_f, do_hori, df + ca4, f_d2, sink);
-        nd6_fin(n_h, win == 0, dh + ca4, nul, sink);
-        if (NOLL3) nd6_fin(n_f2, do_hori, df2 + ca4, f2_d2, sink);
-        v6_incdelta<NE, SCAN>(do_vert, dh_sel6<NE>(d.g_from_h, b_hu, b_gu), dg + ca4, win == 1 ? dh + ca4 : nul, sink16);
-        if (NOLL3) v6_incdelta<NE, SCAN>(do_vert, dh_sel6<NE>(d.g2_from_h, b_hu, b_g2), dg2 + ca4, win == 2 ? dh + ca4 : nul, sink16);
+        nd6_fin(n_f, do_hori, df + ca4, f_d2, sink, W, W.ib);
+        nd6_fin(n_h, win == 0, dh + ca4, nul, sink, W, W.ib);
+        if (NOLL3) nd6_fin(n_f2, do_hori, df2 + ca4, f2_d2, sink, W, W.ib);
+        v6_incdelta<6, true>(do_vert, h_gi, dg + ca4, win == 1 ? dh + ca4 : nul, sink16, W, W.ib);
+        if (NOLL3) v6_incdelta<6, true>(do_vert, h_gi2, dg2 + ca4, win == 2 ? dh + ca4 : nul, sink16, W, W.ib);
     }
 #endif
     V6_STAMP(6)
     v3_outputs<2, NOLL3>(d, 0, 0, do_vert, do_hori, oH, oG, oG2, oF, oF2, trb);
     V6_STAMP(7)
-    return true;
 }
 
 // ---- one STRIP (64 rows x all columns) by one wave, pipelined behind the strip above on progress counters -----------
@@ -391,21 +481,23 @@ __device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const int ca4, cons
 #define V6_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #define V6_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
 #endif
-template <bool NOLL3, int NA>
+template <bool NOLL3>
 __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const V6Lds LO, const int ti, const int nsteps,
                                          const int *prog_up, int *prog_self, int *dbg, const int pgen, const int pint, const int *prog_left,
-                                         double *simscr, int *failp)
+                                         double *simscr, int *failp, unsigned *twin)
 {
     DevProb P;
     uni_prob(P, Pmem);
     const DevSide &a = P.a, &b = P.b;
     const int lane = threadIdx.x;                          // blockDim.x == 64
     const int capa = P.capa, capb = P.capb;
-    const int ca4 = (capa + 3) & ~3, cb4 = (capb + 3) & ~3, lsz = ca4 + cb4;
+    const int ca4 = v6_inline_dw((capa + 3) & ~3), cb4 = v6_inline_dw((capb + 3) & ~3), lsz = ca4 + cb4;      // INLINE dwords per side (LS6)
     const int nslot = NOLL3 ? 9 : 6;
     const int pitch = v3_pitch(nslot, lsz);
     const int ndw = ((16 + 4 * (capa + capb) + 15) & ~15) / 4;
     lu32 *const rows = (lu32 *) (lds + LO.rows);           // row 0: staging (the strip above), row t+1: lane t
+    const LS6 W = {rows, glbw(twin), ca4, cb4};
+    const unsigned TERM = DL_END << 16;
     lu32 *const blk = (lu32 *) (lds + LO.black);
     lu32 *const stsc = (lu32 *) (lds + LO.stsc);           // staging scalars: H ring 0-2, G 3-4, G2 5-6
 #define V6_L(r, slot) (rows + (r) * pitch + (slot) * lsz)
@@ -454,43 +546,80 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
         p[0] = 0; p[1] = DL_END << 16;
         p[ca4] = 0; p[ca4 + 1] = DL_END << 16;
     }
-    // ---- the row's static lists -> registers; the wave's longest list per view bounds the unrolled loops
-    unsigned a_sk[NA], a_tk[NA];
-    double a_sf[NA], a_tf[NA], a_rhf = 0;
-    int ls = 0, lt = 0;
+    // ---- the row's static lists: s -> registers (at most NS entries on this path), t -> LDS in compact form (the lists of the
+    // strip's rows follow each other; the terminators are left out); the wave's longest list per view bounds the loops
+    unsigned a_sk[V6_NS];
+    double a_rhf = 0;
+    int ls = 0, lt = 0, at0 = 0, as0 = 0;
+    lu32 *const atk = (lu32 *) (lds + LO.atk);
+    lf64 *const atf = (lf64 *) (lds + LO.atf);
+    lf64 *const asf = (lf64 *) (lds + LO.asf);
     {
-        int g[NA];
-        rl_load(g, a_sf, a, 0, m, row_ok);
-        V6_UNROLL for (int k = 0; k < NA; ++k) { a_sk[k] = v6_key(g[k]); ls += g[k] >= 0; }
-        rl_load(g, a_tf, a, 1, m, row_ok);
-        V6_UNROLL for (int k = 0; k < NA; ++k) { a_tk[k] = v6_key(g[k]); lt += g[k] >= 0; }
-        if (row_ok) {                                      // the r view's head entry, if any (glen 0; the t entries follow with glen + 1)
+        V6_UNROLL for (int k = 0; k < V6_NS; ++k) a_sk[k] = 0xFFFFu;
+        if (row_ok) {
+            const GLB int *so = glb(a.off[0]);
+            const int sbase = so[m0 + 1] - (m0 + 1);
+            const int k0 = so[m + 1];
+            ls = so[m + 2] - k0 - 1;
+            if (ls > V6_NS) ls = V6_NS;                            // (never: the host sends rows with longer s lists elsewhere)
+            as0 = k0 - (m + 1) - sbase;
+            if (as0 + ls > LO.ascap) ls = LO.ascap > as0 ? LO.ascap - as0 : 0;      // (never: sized by the host)
+            const GLB int *sg = glb(a.glen[0]);
+            const GLB double *sfq = glb(a.freq[0]);
+            V6_UNROLL for (int k = 0; k < V6_NS; ++k) if (k < ls) a_sk[k] = v6_key(sg[k0 + k]);
+            for (int e = 0; e < ls; ++e) asf[as0 + e] = sfq[k0 + e];
+        }
+        if (row_ok) {
+            const GLB int *to = glb(a.off[1]);
+            const int tbase = to[m0 + 1] - (m0 + 1);               // compact position of the strip's first t entry
+            const int k0 = to[m + 1];
+            lt = to[m + 2] - k0 - 1;
+            at0 = k0 - (m + 1) - tbase;
+            if (at0 + lt > LO.atcap) lt = LO.atcap > at0 ? LO.atcap - at0 : 0;      // (never: the host sized the area for the strip with the most entries)
+            const GLB int *tg = glb(a.glen[1]);
+            const GLB double *tf = glb(a.freq[1]);
+            for (int e = 0; e < lt; ++e) { atk[at0 + e] = v6_key(tg[k0 + e]); atf[at0 + e] = tf[k0 + e]; }
+            // the r view's head entry, if any (glen 0; the t entries follow with glen + 1)
             const int o = a.off[2][m + 1];
             if (a.off[2][m + 2] - o - 1 > lt) a_rhf = a.freq[2][o];
         }
     }
-    const A6<NA> A = {a_sk, a_sf, a_tk, a_tf, a_rhf, ls, lt};
     int TAs = 0, TAt = 0;
     while (__ballot(ls > TAs)) ++TAs;
     while (__ballot(lt > TAt)) ++TAt;
+    const A6 A = {a_sk, asf, atk, atf, a_rhf, ls, lt, as0, at0, TAs, TAt};
     // ---- the ring of the columns' static lists
     Ring6 ring[3];
 #pragma unroll
     for (int v = 0; v < 3; ++v) { ring[v].k = (const lu32 *) (lds + LO.ringk[v]); ring[v].f = (const lf64 *) (lds + LO.ringf[v]); ring[v].mask = LO.rs[v] - 1; }
     int fedcol = cbase - 1;                                // columns <= fedcol are in the ring
-    auto refill = [&](int upto) {                          // wave-uniform; lane <-> (column, view): at most 16 columns x 3 views a time
-        if (upto > b.right - 1) upto = b.right - 1;
-        for (int c0_ = fedcol + 1; c0_ <= upto; c0_ += 21) {
-            const int col = c0_ + lane / 3, v = lane % 3;
-            if (lane < 63 && col <= upto) {
-                const GLB int *bo = v == 0 ? boff0 : v == 1 ? boff1 : boff2;
-                const int k0 = bo[col + 1], len = bo[col + 2] - k0 - 1, c = k0 - (col + 1);
-                const GLB int *bgl = glb(b.glen[v]);
-                const GLB double *bfr = glb(b.freq[v]);
-                lu32 *rk = (lu32 *) (lds + LO.ringk[v]);
-                lf64 *rf = (lf64 *) (lds + LO.ringf[v]);
-                const int mask = LO.rs[v] - 1;
-                for (int e = 0; e < len; ++e) { rk[(c + e) & mask] = v6_key(bgl[k0 + e]); rf[(c + e) & mask] = bfr[k0 + e]; }
+    lf64 *const rhring = (lf64 *) (lds + LO.ringf[2]);     // head freq of the r list of column c at [c & (V6_RHCOLS - 1)] (0: no head)
+    auto refill = [&](int upto) {                          // wave-uniform; lane <-> column, one view after the other (the view is a
+        if (upto > b.right - 1) upto = b.right - 1;        // compile-time index: a per-lane choice among the descriptor's fields would
+#pragma unroll                                             // turn its register copy into an indexed object in scratch memory)
+        for (int v = 0; v < 2; ++v) {
+            const GLB int *bo = v == 0 ? boff0 : boff1;
+            const GLB int *bgl = glb(b.glen[v]);
+            const GLB double *bfr = glb(b.freq[v]);
+            lu32 *rk = (lu32 *) (lds + LO.ringk[v]);
+            lf64 *rf = (lf64 *) (lds + LO.ringf[v]);
+            const int mask = LO.rs[v] - 1;
+            for (int c0_ = fedcol + 1; c0_ <= upto; c0_ += 64) {
+                const int col = c0_ + lane;
+                if (col <= upto) {
+                    const int k0 = bo[col + 1], len = bo[col + 2] - k0 - 1, c = k0 - (col + 1);
+                    for (int e = 0; e < len; ++e) { rk[(c + e) & mask] = v6_key(bgl[k0 + e]); rf[(c + e) & mask] = bfr[k0 + e]; }
+                }
+            }
+        }
+        {
+            const GLB double *bfr2 = glb(b.freq[2]);
+            for (int c0_ = fedcol + 1; c0_ <= upto; c0_ += 64) {
+                const int col = c0_ + lane;
+                if (col <= upto) {
+                    const int k2 = boff2[col + 1], lr_ = boff2[col + 2] - k2 - 1, lt_ = boff1[col + 2] - boff1[col + 1] - 1;
+                    rhring[col & (V6_RHCOLS - 1)] = lr_ > lt_ ? bfr2[k2] : 0.;
+                }
             }
         }
         if (upto > fedcol) fedcol = upto;
@@ -501,8 +630,8 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
         lu32 *p = V6_L(lane + 1, SLOT_H(c0));
         const GLB unsigned *src = colH + (size_t) (m + 1 - a.left) * ndw;
         oH.val = __hiloint2double((int) V6_XLD(src + 1), (int) V6_XLD(src)); oH.dir = (int) V6_XLD(src + 2); oH.glb = (int) V6_XLD(src + 3);
-        for (int k = 0; k < capa; ++k) p[k] = V6_XLD(src + 4 + k);
-        for (int k = 0; k < capb; ++k) p[ca4 + k] = V6_XLD(src + 4 + capa + k);
+        for (int k = 0; k < capa; ++k) { const unsigned v = V6_XLD(src + 4 + k); ls6_wr(W, p, k, ca4, v); if (v >= TERM) break; }
+        for (int k = 0; k < capb; ++k) { const unsigned v = V6_XLD(src + 4 + capa + k); ls6_wr(W, p + ca4, k, cb4, v); if (v >= TERM) break; }
     }
     // ---- staging row: records of the strip above for lane 0's columns, one dword per lane --------------
     auto stage_load = [&](int col, bool wantG, unsigned &rh, unsigned &rg, unsigned &rg2) {
@@ -512,11 +641,22 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
             if (wantG) { rg = V6_XLD(rowGp + (size_t) col * ndw + lane); if (NOLL3) rg2 = V6_XLD(rowG2p + (size_t) col * ndw + lane); }
         }
     };
+    // one record dword per lane: 0-3 the scalars, then the a-side list, then the b-side list.  Dwords beyond a list's inline
+    // part go to its twin -- only while they are in front of (or are) the list's terminator: what follows it is stale
     auto stage_put = [&](int slot, int sid, unsigned v) {
         const int j = lane - 4;
+        lu32 *const p = V6_L(0, slot);
         if (lane < 4) stsc[sid * 4 + lane] = v;
-        else if (j < capa) V6_L(0, slot)[j] = v;
-        else if (j < capa + capb) V6_L(0, slot)[ca4 + j - capa] = v;
+        else if (j < ca4 && j < capa) p[j] = v;
+        else if (j >= capa && j - capa < cb4 && j < capa + capb) p[ca4 + j - capa] = v;
+        if (capa > ca4 || capb > cb4) {                    // (wave-uniform: this DP's lists can outgrow their inline parts)
+            const unsigned long long tb = __ballot(v >= TERM) >> 4;                              // bit j: dword j of the lists is a terminator
+            const int ta = tb ? (int) __builtin_ctzll(tb) : 63;                                  // the a list's terminator (it has one)
+            const unsigned long long tbb = capa < 60 ? tb >> capa : 0ull;
+            const int tbp = tbb ? (int) __builtin_ctzll(tbb) : 63;                               // the b list's, relative to its start
+            if (j >= ca4 && j < capa && j <= ta) ls6_wr(W, p, j, ca4, v);
+            if (j >= capa + cb4 && j < capa + capb && j - capa <= tbp) ls6_wr(W, p + ca4, j - capa, cb4, v);
+        }
     };
     auto stage_store = [&](int col, bool wantG, unsigned rh, unsigned rg, unsigned rg2) {
         if (lane < ndw) {
@@ -603,7 +743,10 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
                 unsigned v = lane == 0 ? v0 : lane == 1 ? v1 : lane == 2 ? v2 : v3;
                 if (lane >= 4 && lane < ndw) {
                     const lu32 *p = V6_L(llast + 1, slot);
-                    v = (j < capa) ? p[j] : (j < capa + capb) ? p[ca4 + j - capa] : 0;
+                    v = (j < capa) ? (j < ca4 ? p[j] : TERM) : (j < capa + capb) ? (j - capa < cb4 ? p[ca4 + j - capa] : TERM) : 0;
+                    // a list that runs beyond its inline part (its last inline dword is an entry): the rest comes from the twin
+                    if (capa > ca4 && p[ca4 - 1] < TERM && j >= ca4 && j < capa) v = ls6_rd(W, p, j, ca4);
+                    if (capb > cb4 && p[ca4 + cb4 - 1] < TERM && j >= capa + cb4 && j < capa + capb) v = ls6_rd(W, p + ca4, j - capa, cb4);
                 }
                 GLB unsigned *dst = (x == 0) ? rowHc : (x == 1) ? rowGc : rowG2c;
                 if (lane < ndw) V6_XST(dst + (size_t) col * ndw + lane, v);
@@ -673,8 +816,9 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
         if (active) {                                      // (loops inside are uniform over the ACTIVE lanes: ballots see only them)
             const bool do_hori = n > b.left;
             B6 B;
-            B.rs = ring[0]; B.rt = ring[1]; B.rr = ring[2];
-            B.os = os_cur - (n + 1); B.ot = ot_cur - (n + 1); B.orr = or_cur - (n + 1);          // compact positions (see Ring6)
+            B.rs = ring[0]; B.rt = ring[1];
+            B.os = os_cur - (n + 1); B.ot = ot_cur - (n + 1);                                     // compact positions (see Ring6)
+            B.rhf = rhring[n & (V6_RHCOLS - 1)];
             B.lens = oe_cur - os_cur - 1; B.lent = te_cur - ot_cur - 1; B.lenr = re_cur - or_cur - 1;
             const bool up_in = do_vert && (n - (m - 1) <= P.up);          // cell (m-1, n) exists
             const bool left_in = (n - 1 - m >= P.lw);                      // cell (m, n-1) exists
@@ -698,13 +842,8 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
             const double pua = a.nils ? unpa(P, m, n) : pua_row;
             const double pub = bc_cur * a_efq * -P.u;                       // unp1(bsi, asi), maln.h:185-187
             int trb = 0;
-// three instances of the cell: heads of 5 entries, of 8, and 8 + scan (see dh_load6); the first that applies runs
-            if (!v6_cell_pf<NOLL3, NA, 5, false>(P, ca4, A, TAs, TAt, B, sink, sink16, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
-                                  dh, dg, dg2, df, df2, do_vert, do_hori, sim_cur, pua, pub, myH, myG, myG2, oF, oF2, trb V6_STAMP_PASS))
-                if (!v6_cell_pf<NOLL3, NA, 8, false>(P, ca4, A, TAs, TAt, B, sink, sink16, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
-                                  dh, dg, dg2, df, df2, do_vert, do_hori, sim_cur, pua, pub, myH, myG, myG2, oF, oF2, trb V6_STAMP_PASS))
-                    v6_cell_pf<NOLL3, NA, 8, true>(P, ca4, A, TAs, TAt, B, sink, sink16, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
-                                  dh, dg, dg2, df, df2, do_vert, do_hori, sim_cur, pua, pub, myH, myG, myG2, oF, oF2, trb V6_STAMP_PASS);
+            v6_cell_pf<NOLL3>(P, W, A, B, sink, sink16, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
+                              dh, dg, dg2, df, df2, do_vert, do_hori, sim_cur, pua, pub, myH, myG, myG2, oF, oF2, trb V6_STAMP_PASS);
             const int d = m + n;
             int mlo, mhi;
             diag_rows(d, a.left, a.right, b.left, b.right, P.lw, P.up, &mlo, &mhi);
@@ -730,9 +869,9 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
 #undef V6_L
 }
 
-#define V6_KERNEL(NAME, N3, NA, WPE)                                                                 \
+#define V6_KERNEL(NAME, N3, WPE)                                                                 \
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))      \
-NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V6Lds LO, int pint, int pro_off, double *simscr) \
+NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V6Lds LO, int pint, int pro_off, double *simscr, unsigned *twin, int twin_dw) \
 {                                                                                                   \
     extern __shared__ __attribute__((aligned(16))) char g2g_lds[];                                  \
     li32 *s_vals = (li32 *) ((lchar *) g2g_lds + LO.svals);                                         \
@@ -761,19 +900,22 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         const int *pl = T.dep_left >= 0 ? done + T.dep_left : (const int *) 0;                      \
         const int *pu = T.dep_up >= 0 ? done + T.dep_up : (const int *) 0;                          \
         __syncthreads();                                                                            \
-        v6_strip<N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, T.nsteps, pu, done + T.self, done + G2G_HDR, gen, pint, pl, \
-                         simscr + (size_t) blockIdx.x * (3 * 4096), failp); \
+        v6_strip<N3>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, T.nsteps, pu, done + T.self, done + G2G_HDR, gen, pint, pl, \
+                         simscr + (size_t) blockIdx.x * (3 * 4096), failp, twin + (size_t) blockIdx.x * twin_dw); \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
     }                                                                                               \
 }
 #ifndef G2G_V6_NA
-#define G2G_V6_NA 16
+#define G2G_V6_NA 16                    /* the row's t lists: longest list (terminator included) this path takes */
+#endif
+#ifndef G2G_V6_WPE
+#define G2G_V6_WPE 2                    /* waves per SIMD the register allocation aims at */
 #endif
 #ifdef G2G_TU_V6
-V6_KERNEL(g2g_v6_pf2, false, G2G_V6_NA, 1)
-V6_KERNEL(g2g_v6_pf3, true, G2G_V6_NA, 1)
+V6_KERNEL(g2g_v6_pf2, false, G2G_V6_WPE)
+V6_KERNEL(g2g_v6_pf3, true, 1)                   // (Noll 3: two more records per cell; at two waves per SIMD it would spill 38 registers)
 #else
-#define V6_KERNEL_DECL(NAME) extern "C" __global__ void NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V6Lds LO, int pint, int pro_off, double *simscr);
+#define V6_KERNEL_DECL(NAME) extern "C" __global__ void NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V6Lds LO, int pint, int pro_off, double *simscr, unsigned *twin, int twin_dw);
 V6_KERNEL_DECL(g2g_v6_pf2) V6_KERNEL_DECL(g2g_v6_pf3)
 #endif

@@ -77,6 +77,21 @@ def test_bench_family_divisions_vs_oracle(ctx):
     _check_vs_oracle(ctx, [sw.pwds[k] for k in pick])
 
 
+def test_progressive_start_divisions_vs_oracle(ctx):
+    """The same family from the REFERENCE's progressive MSA (tests/golden/msa/prog256x1024.npz: where prrn's refinement really
+    starts): rougher than the true alignment, so the records' dynamic gap-state lists grow longer -- 0.06 % of the cells of
+    these DPs read a list of eight entries or more, i.e. one that no longer fits its inline part in LDS: the scans, the long
+    newdelta results and the strip hand-over of such lists (g2g_kernels_v6.hip, LS6) all run here, against the oracle."""
+    import os
+    fam = make_family(256, 1024, 1)
+    alp = op.AlnParam()
+    codes = np.load(os.path.join(os.path.dirname(__file__), "golden", "msa", "prog256x1024.npz"))["codes"]
+    sw = sweep.Sweep(fam, alp, weighted=True, codes=codes)
+    pf = [k for k in sw.order if sw.pwds[k].alnmode == 9]
+    pick = [pf[0], pf[2], pf[len(pf) // 3], pf[len(pf) // 2], pf[-1]]
+    _check_vs_oracle(ctx, [sw.pwds[k] for k in pick])
+
+
 def test_dna_ls3_4096nt_divisions_vs_oracle(ctx):
     """configs[4]'s per-DP shape: DNA family of 4096-nt sequences, double-affine penalty (-yl3: Noll 3 kernels, codonk1 = 21),
     static gap-profile lists of more than 16 entries (beyond what the register-list kernel holds), 0.8-1.8e8 cells per DP."""

@@ -58,8 +58,56 @@ def start_rows(name, kw, dna):
     return list(make_family(**kw).msa)
 
 
-def main(only=None):
+def build_fixture(name, rows, dna, extra, opts, L, out, ref_seconds):
+    """the fixture dict from the trace lines L, the reference's printed final alignment `out` and its wall time"""
+    names = [("s%03d" if len(rows) > 99 else "s%02d") % i for i in range(len(rows))]
+    final, order = parse_msa(out)
+    assert order == names and len({len(r) for r in final}) <= 2, (order[:3], [len(r) for r in final][:5])
+    width = max(len(r) for r in final)
+    final = [r.ljust(width, "-").replace(" ", "-") for r in final]
+    T = [l.split() for l in L if l.startswith("T ")]
+    fix = {
+        "name": name, "molc": 2 if dna else 1, "ls": 3 if "-yl3" in extra else 1, "options": opts,
+        "rows": list(rows),
+        "tree": {"left": [int(t[2]) for t in T], "right": [int(t[3]) for t in T], "parent": [int(t[4]) for t in T],
+                 "vol": [float(t[5]) for t in T], "cur": [float(t[6]) for t in T]},
+        "cycle": int([l for l in L if l.startswith("C ")][0].split()[1]),
+        "branches": [int(l.split()[1]) for l in L if l.startswith("D ")],
+        "align2": [], "accepted": [], "final_rows": final,
+        "reference_seconds": round(ref_seconds, 1),
+    }
+    assert [int(t[1]) for t in T] == list(range(len(T)))
+    for l in L:
+        if l.startswith("A "):
+            h = l[:400].split("|")[0].split()
+            fix["align2"].append({"na": int(h[1]), "nb": int(h[2]), "swp": int(h[3]), "scr": float(h[4]), "val": float(h[5])})
+        elif l.startswith("S "):
+            p = l.split("|")
+            sk = [int(x) for x in p[3].split()]
+            mv = {"lst0": [int(x) for x in p[1].split()], "lst1": [int(x) for x in p[2].split()],
+                  "skl": [sk[i:i + 2] for i in range(0, len(sk), 2)]}
+            if name == BIG[0]:
+                # 834 moves of a 256-member family: the member list of the smaller group (the larger is its complement) and a
+                # checksum of the skeleton (count of corners + CRC-32 of the int32 corner array) instead of ~4000 numbers per move
+                import zlib
+                import numpy as np
+                mv = {"lst1": mv["lst1"], "ncorners": len(mv["skl"]), "skl_crc32": zlib.crc32(np.asarray(mv["skl"], np.int32).tobytes())}
+            fix["accepted"].append(mv)
+    return fix, width
+
+
+def write_fixture(name, fix):
     import gzip
+    if name == BIG[0]:
+        with gzip.open(os.path.join(GOLD, "refine_%s.json.gz" % name), "wt", compresslevel=9) as fd:
+            json.dump(fix, fd)
+    else:
+        json.dump(fix, open(os.path.join(GOLD, "refine_%s.json" % name), "w"))
+
+
+def main(only=None, reuse=None):
+    """reuse = (trace file, file with the reference's printed output, seconds): assemble the fixture from a run made earlier (the
+    256 x 1024 case takes the reference 45 minutes traced and as long again plain)"""
     import time
     import refdump
     env = dict(os.environ, ALN_TAB=os.path.join(REF, "table"))
@@ -68,52 +116,31 @@ def main(only=None):
         if only and name != only:
             continue
         rows = start_rows(name, kw, dna)
-        fam = type("Fam", (), {"msa": rows})
         names = [("s%03d" if len(rows) > 99 else "s%02d") % i for i in range(len(rows))]
-        with tempfile.TemporaryDirectory() as tmp:
-            refdump.write_multi(os.path.join(tmp, "fam.msa"), names, list(fam.msa), "fam")
-            tr = os.path.join(tmp, "trace.txt")
-            opts = ["-YH0", "-R1"] + extra
-            subprocess.run([os.path.join(REF, "prrn5_trace")] + opts + ["-O4", "fam.msa"], cwd=tmp, env=dict(env, G2G_TRACE=tr),
-                           check=True, capture_output=True)
-            t0 = time.time()
-            out = subprocess.run([os.path.join(REF, "prrn5")] + opts + ["fam.msa"], cwd=tmp, env=env, check=True,
-                                 capture_output=True, text=True).stdout
-            ref_seconds = time.time() - t0          # the reference's own serial refinement, one core of the build container
-            L = [l.rstrip("\n") for l in open(tr)]
-        final, order = parse_msa(out)
-        assert order == names and len({len(r) for r in final}) <= 2, (order[:3], [len(r) for r in final][:5])
-        width = max(len(r) for r in final)
-        final = [r.ljust(width, "-").replace(" ", "-") for r in final]
-        T = [l.split() for l in L if l.startswith("T ")]
-        fix = {
-            "name": name, "molc": 2 if dna else 1, "ls": 3 if "-yl3" in extra else 1, "options": opts,
-            "rows": list(fam.msa),
-            "tree": {"left": [int(t[2]) for t in T], "right": [int(t[3]) for t in T], "parent": [int(t[4]) for t in T],
-                     "vol": [float(t[5]) for t in T], "cur": [float(t[6]) for t in T]},
-            "cycle": int([l for l in L if l.startswith("C ")][0].split()[1]),
-            "branches": [int(l.split()[1]) for l in L if l.startswith("D ")],
-            "align2": [], "accepted": [], "final_rows": final,
-            "reference_seconds": round(ref_seconds, 1),
-        }
-        assert [int(t[1]) for t in T] == list(range(len(T)))
-        for l in L:
-            if l.startswith("A "):
-                h = l.split("|")[0].split()
-                fix["align2"].append({"na": int(h[1]), "nb": int(h[2]), "swp": int(h[3]), "scr": float(h[4]), "val": float(h[5])})
-            elif l.startswith("S "):
-                p = l.split("|")
-                sk = [int(x) for x in p[3].split()]
-                fix["accepted"].append({"lst0": [int(x) for x in p[1].split()], "lst1": [int(x) for x in p[2].split()],
-                                        "skl": [sk[i:i + 2] for i in range(0, len(sk), 2)]})
-        if name == BIG[0]:
-            with gzip.open(os.path.join(GOLD, "refine_%s.json.gz" % name), "wt", compresslevel=9) as fd:
-                json.dump(fix, fd)
+        opts = ["-YH0", "-R1"] + extra
+        if reuse:
+            L = [l.rstrip("\n") for l in open(reuse[0])]
+            out = open(reuse[1]).read()
+            ref_seconds = float(reuse[2])
         else:
-            json.dump(fix, open(os.path.join(GOLD, "refine_%s.json" % name), "w"))
+            with tempfile.TemporaryDirectory() as tmp:
+                refdump.write_multi(os.path.join(tmp, "fam.msa"), names, list(rows), "fam")
+                tr = os.path.join(tmp, "trace.txt")
+                subprocess.run([os.path.join(REF, "prrn5_trace")] + opts + ["-O4", "fam.msa"], cwd=tmp, env=dict(env, G2G_TRACE=tr),
+                               check=True, capture_output=True)
+                t0 = time.time()
+                out = subprocess.run([os.path.join(REF, "prrn5")] + opts + ["fam.msa"], cwd=tmp, env=env, check=True,
+                                     capture_output=True, text=True).stdout
+                ref_seconds = time.time() - t0          # the reference's own serial refinement, one core of the build container
+                L = [l.rstrip("\n") for l in open(tr)]
+        fix, width = build_fixture(name, rows, dna, extra, opts, L, out, ref_seconds)
+        write_fixture(name, fix)
         print("%-22s members %d, cycle %d, %d divisions drawn, %d align2 calls, %d accepted, %d -> %d columns" % (
-            name, len(names), fix["cycle"], len(fix["branches"]), len(fix["align2"]), len(fix["accepted"]), len(fam.msa[0]), width))
+            name, len(names), fix["cycle"], len(fix["branches"]), len(fix["align2"]), len(fix["accepted"]), len(rows[0]), width))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else None)
+    if len(sys.argv) > 2 and sys.argv[2] == "--reuse":
+        main(sys.argv[1], sys.argv[3:6])
+    else:
+        main(sys.argv[1] if len(sys.argv) > 1 else None)
