@@ -251,63 +251,89 @@ typedef DH<6> DHn;
 #define V6_STRA(key, h) dh_stretch<6, true>((key), (h), W, W.ia)        /* stretched by a record's a-side / b-side list */
 #define V6_STRB(key, h) dh_stretch<6, true>((key), (h), W, W.ib)
 
-// one "X" merge: cf = the column's s list (ring, stretched by dlb of the record), df = a row list (LDS, stretched by dla):
-// newgap(b.s, dlb, a.t|a.r, dla).  RV: df is the r view = an optional head entry {glen 0, freq rhf} followed by the t entries with
-// glen + 1 (rhf = 0: no head; its term is then +0).  lmax: the wave's longest column s list.  The column's entries are
-// stretched once (NC registers); a term of a lane whose list is shorter than the loop's index is +0.
-template <bool RV>
-__device__ __forceinline__ double v6_xmerge(const DHn &ha, const DHn &hb, const A6 &A, const B6 &B, const int lmax, const LS6 &W)
+// The "X" merges: cf = the column's s list (ring, stretched by dlb of a record), df = a row list (LDS, stretched by dla of the same
+// record): newgap(b.s, dlb, a.t | a.r, dla) for the records hd (t view: the diagonal's second part), fl and hl (r view: horizontal
+// gnp / gop) and, with Noll 3, f2l.  The r view is an optional head entry {glen 0, freq rhf} followed by the t entries with
+// glen + 1 (rhf = 0: no head; its term is then +0), so ALL of them walk the row's t list: ONE loop reads an entry from LDS (the
+// next one is fetched while this one is worked on) and feeds every merge.  The column's entries are the same for all merges;
+// stretched by each record's b-side list once (NC registers per merge).  lmax: the wave's longest column s list; a term of a
+// lane whose list is shorter than the loop's index is +0.
+template <bool NOLL3>
+__device__ __forceinline__ void v6_xmerges(const lu32 *hdl, const lu32 *fll, const lu32 *hll, const lu32 *f2ll, const A6 &A, const B6 &B, const int lmax,
+                                           const LS6 &W, double &g_hd, double &g_fl, double &g_hl, double &g_f2)
 {
-    double g = 0;
+    const int ca4 = W.ia;
+    g_hd = g_fl = g_hl = g_f2 = 0;
     if (lmax <= V6_NC) {
-        unsigned ic[V6_NC];
+        unsigned i0[V6_NC], i1[V6_NC], i2[V6_NC], i3[V6_NC];
         double fc[V6_NC];
-        V6_UNROLL
-        for (int c = 0; c < V6_NC; ++c) {
-            ic[c] = 0u; fc[c] = 0.;
-            if (c < lmax) {
-                const bool valid = c < B.lens;
-                const SE6 e = se6_read(B.rs, B.os + (valid ? c : 0));
-                ic[c] = valid ? V6_STRB(e.key, hb) : 0u;            // (0 never reaches a stretched length: those are >= 0xFFFF)
-                fc[c] = e.f;
+        {
+            const DHn b0 = dh_load6<6>(hdl + ca4), b1 = dh_load6<6>(fll + ca4), b2 = dh_load6<6>(hll + ca4), b3 = dh_load6<6>((NOLL3 ? f2ll : fll) + ca4);
+            V6_UNROLL
+            for (int c = 0; c < V6_NC; ++c) {
+                i0[c] = i1[c] = i2[c] = i3[c] = 0u; fc[c] = 0.;
+                if (c < lmax) {
+                    const bool valid = c < B.lens;
+                    const SE6 e = se6_read(B.rs, B.os + (valid ? c : 0));
+                    fc[c] = e.f;
+                    i0[c] = valid ? V6_STRB(e.key, b0) : 0u;      // (0 never reaches a stretched length: those are >= 0xFFFF)
+                    i1[c] = valid ? V6_STRB(e.key, b1) : 0u;
+                    i2[c] = valid ? V6_STRB(e.key, b2) : 0u;
+                    if (NOLL3) i3[c] = valid ? V6_STRB(e.key, b3) : 0u;
+                }
             }
         }
-#define V6_XCHAIN(S, j) { V6_UNROLL for (int c = V6_NC - 1; c >= 0; --c) if (c < lmax) S = ic[c] >= (j) ? fc[c] : S; }
-        if (RV) {
-            const unsigned jh = V6_STRA(0xFFFFu, ha);
-            double S = 0;
-            V6_XCHAIN(S, jh)
-            g += S * A.rhf;
+        asm volatile("" ::: "memory");
+        const DHn a0 = dh_load6<6>(hdl), a1 = dh_load6<6>(fll), a2 = dh_load6<6>(hll), a3 = dh_load6<6>(NOLL3 ? f2ll : fll);
+#define V6_XCHAIN(S, ic, j) { V6_UNROLL for (int c = V6_NC - 1; c >= 0; --c) if (c < lmax) S = ic[c] >= (j) ? fc[c] : S; }
+        {   // the r view's head entry
+            const unsigned j1 = V6_STRA(0xFFFFu, a1), j2 = V6_STRA(0xFFFFu, a2), j3 = NOLL3 ? V6_STRA(0xFFFFu, a3) : 0u;
+            double S1 = 0, S2 = 0, S3 = 0;
+            V6_XCHAIN(S1, i1, j1) V6_XCHAIN(S2, i2, j2)
+            if (NOLL3) V6_XCHAIN(S3, i3, j3)
+            g_fl += S1 * A.rhf; g_hl += S2 * A.rhf;
+            if (NOLL3) g_f2 += S3 * A.rhf;
         }
+        unsigned key = A.tk[A.at0];
+        double f = A.lt > 0 ? A.tf[A.at0] : 0.;
         for (int d = 0; d < A.TAt; ++d) {
-            const bool valid = d < A.lt;
-            const int at = A.at0 + (valid ? d : 0);
-            const unsigned key = A.tk[at];
-            const double f = valid ? A.tf[at] : 0.;
-            const unsigned j = V6_STRA(key + (RV ? 0x10000u : 0u), ha);
-            double S = 0;
-            V6_XCHAIN(S, j)
-            g += S * f;
+            const bool nv = d + 1 < A.lt;                          // the next entry, fetched now
+            const int nat = A.at0 + (nv ? d + 1 : 0);
+            const unsigned nkey = A.tk[nat];
+            const double nf = nv ? A.tf[nat] : 0.;
+            const unsigned j0 = V6_STRA(key, a0), j1 = V6_STRA(key + 0x10000u, a1), j2 = V6_STRA(key + 0x10000u, a2);
+            const unsigned j3 = NOLL3 ? V6_STRA(key + 0x10000u, a3) : 0u;
+            double S0 = 0, S1 = 0, S2 = 0, S3 = 0;
+            V6_XCHAIN(S0, i0, j0) V6_XCHAIN(S1, i1, j1) V6_XCHAIN(S2, i2, j2)
+            if (NOLL3) V6_XCHAIN(S3, i3, j3)
+            g_hd += S0 * f; g_fl += S1 * f; g_hl += S2 * f;
+            if (NOLL3) g_f2 += S3 * f;
+            key = nkey; f = nf;
         }
 #undef V6_XCHAIN
     } else {                                                     // a column list longer than NC somewhere in the wave: both loops rolled
-        for (int d = RV ? -1 : 0; d < A.TAt; ++d) {
+        const DHn a0 = dh_load6<6>(hdl), a1 = dh_load6<6>(fll), a2 = dh_load6<6>(hll), a3 = dh_load6<6>(NOLL3 ? f2ll : fll);
+        const DHn b0 = dh_load6<6>(hdl + ca4), b1 = dh_load6<6>(fll + ca4), b2 = dh_load6<6>(hll + ca4), b3 = dh_load6<6>((NOLL3 ? f2ll : fll) + ca4);
+        for (int d = -1; d < A.TAt; ++d) {
             const bool valid = d < A.lt;
             const int at = A.at0 + ((valid && d >= 0) ? d : 0);
-            const unsigned key = d < 0 ? 0xFFFFu : A.tk[at] + (RV ? 0x10000u : 0u);
+            const unsigned key = d < 0 ? 0xFFFFu : A.tk[at];
             const double f = d < 0 ? A.rhf : valid ? A.tf[at] : 0.;
-            const unsigned j = V6_STRA(key, ha);
-            double S = 0;
+            const unsigned j0 = V6_STRA(key, a0), j1 = V6_STRA(d < 0 ? key : key + 0x10000u, a1), j2 = V6_STRA(d < 0 ? key : key + 0x10000u, a2);
+            const unsigned j3 = NOLL3 ? V6_STRA(d < 0 ? key : key + 0x10000u, a3) : 0u;
+            double S0 = 0, S1 = 0, S2 = 0, S3 = 0;
             for (int kk = lmax - 1; kk >= 0; --kk) {
                 const bool cv = kk < B.lens;
                 const SE6 e = se6_read(B.rs, B.os + (cv ? kk : 0));
-                const unsigned i = cv ? V6_STRB(e.key, hb) : 0u;
-                S = i >= j ? e.f : S;
+                const unsigned x0 = cv ? V6_STRB(e.key, b0) : 0u, x1 = cv ? V6_STRB(e.key, b1) : 0u, x2 = cv ? V6_STRB(e.key, b2) : 0u;
+                S0 = x0 >= j0 ? e.f : S0; S1 = x1 >= j1 ? e.f : S1; S2 = x2 >= j2 ? e.f : S2;
+                if (NOLL3) { const unsigned x3 = cv ? V6_STRB(e.key, b3) : 0u; S3 = x3 >= j3 ? e.f : S3; }
             }
-            g += S * f;
+            if (d >= 0) g_hd += S0 * f;                              // (the t view has no head entry)
+            g_fl += S1 * f; g_hl += S2 * f;
+            if (NOLL3) g_f2 += S3 * f;
         }
     }
-    return g;
 }
 
 // ---- one cell by one lane ----------------------------------------------------------------------------------
@@ -354,10 +380,13 @@ __device__ __forceinline__ void v6_cell_pf(const DevProb &P, const LS6 &W, const
         const DHn b_hd = dh_load6<6>(hdl + ca4), b_gu = dh_load6<6>(gul + ca4), b_hu = dh_load6<6>(hul + ca4), b_g2 = dh_load6<6>((NOLL3 ? g2ul : gul) + ca4);
         double g0 = 0, g1 = 0, g2 = 0, g3 = 0;
         bool l0 = true, l1 = do_vert, l2 = do_vert, l3 = do_vert && NOLL3;
+        const int rhas = B.lenr > B.lent ? 1 : 0;                                  // the column's r view starts with a head entry
+        SE6 et_n = se6_read(B.rt, B.ot), ert_n = et_n;                             // entry 0 of the t ring (= what d = 0 reads for both views)
         for (int d = 0; d < DL_GUARD; ++d) {
             if (wave_none(l0 || l1 || l2 || l3)) break;
-            const int dr = d - (B.lenr > B.lent ? 1 : 0);                          // entry d of the r view: the head, or t entry d - 1 / d
-            const SE6 et = se6_read(B.rt, B.ot + d), ert = se6_read(B.rt, B.ot + (dr < 0 ? 0 : dr));
+            const int dr = d - rhas;                                               // entry d of the r view: the head, or t entry d - 1 / d
+            const SE6 et = et_n, ert = ert_n;
+            et_n = se6_read(B.rt, B.ot + d + 1); ert_n = rhas ? et : et_n;                    // the next round's, fetched now (the r view lags one entry behind a head)
             SE6 er;
             er.key = dr < 0 ? 0xFFFFu : ert.key + 0x10000u; er.f = dr < 0 ? B.rhf : ert.f; er.g = (int) (er.key >> 16);
             l0 = l0 && d < B.lent;
@@ -393,10 +422,9 @@ __device__ __forceinline__ void v6_cell_pf(const DevProb &P, const LS6 &W, const
     {
         int lmax = 0;
         while (__ballot(B.lens > lmax)) ++lmax;
-        { const DHn ha = dh_load6<6>(hdl), hb = dh_load6<6>(hdl + ca4); c.d1 = v6_xmerge<false>(ha, hb, A, B, lmax, W) * P.basic_gop; }
-        { const DHn ha = dh_load6<6>(fll), hb = dh_load6<6>(fll + ca4); c.gnph = v6_xmerge<true>(ha, hb, A, B, lmax, W) * P.basic_gop; }
-        { const DHn ha = dh_load6<6>(hll), hb = dh_load6<6>(hll + ca4); c.goph = v6_xmerge<true>(ha, hb, A, B, lmax, W) * P.basic_gop; }
-        if (NOLL3) { const DHn ha = dh_load6<6>(f2ll), hb = dh_load6<6>(f2ll + ca4); c.gnph2 = v6_xmerge<true>(ha, hb, A, B, lmax, W) * P.basic_gop; }
+        double g_hd, g_fl, g_hl, g_f2;
+        v6_xmerges<NOLL3>(hdl, fll, hll, f2ll, A, B, lmax, W, g_hd, g_fl, g_hl, g_f2);
+        c.d1 = g_hd * P.basic_gop; c.gnph = g_fl * P.basic_gop; c.goph = g_hl * P.basic_gop; c.gnph2 = NOLL3 ? g_f2 * P.basic_gop : 0;
     }
 #endif
     V6_STAMP(3)
@@ -413,10 +441,12 @@ __device__ __forceinline__ void v6_cell_pf(const DevProb &P, const LS6 &W, const
         const DHn h_gs2 = dh_load6<6>(NOLL3 ? (d.g2_from_h ? hul : g2ul) : gul), h_fi2 = dh_load6<6>(NOLL3 ? (d.f2_from_h ? hll : f2ll) : fll);
         ND6 n_g = {0, 0, 0, do_vert}, n_h = {0, 0, 0, win == 0}, n_g2 = {0, 0, 0, do_vert && NOLL3};
         lu32 *const g_d2 = win == 1 ? dh : nul, *const g2_d2 = win == 2 ? dh : nul;
+        unsigned nkey = A.tk[A.at0];
         for (int k = 0; k < A.TAt; ++k) {
             if (wave_none(n_g.on || n_h.on || (NOLL3 && n_g2.on))) break;
             const bool valid = k < A.lt;
-            const unsigned key = A.tk[A.at0 + (valid ? k : 0)];
+            const unsigned key = nkey;
+            nkey = A.tk[A.at0 + (k + 1 < A.lt ? k + 1 : 0)];                          // the next entry, fetched now
             const int g = valid ? (int) (key >> 16) : -1;
             if (__ballot(n_g.kd >= W.ia || n_h.kd >= W.ia || (NOLL3 && n_g2.kd >= W.ia))) {          // a result outgrows its inline part
                 nd6_step<6, true, true>(n_g, h_gs, g, key, dg, g_d2, sink, W, W.ia);
@@ -593,7 +623,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
 #pragma unroll
     for (int v = 0; v < 3; ++v) { ring[v].k = (const lu32 *) (lds + LO.ringk[v]); ring[v].f = (const lf64 *) (lds + LO.ringf[v]); ring[v].mask = LO.rs[v] - 1; }
     int fedcol = cbase - 1;                                // columns <= fedcol are in the ring
-    lf64 *const rhring = (lf64 *) (lds + LO.ringf[2]);     // head freq of the r list of column c at [c & (V6_RHCOLS - 1)] (0: no head)
+    lf64 *const rhring = (lf64 *) (lds + LO.ringf[2]);     // head freq of the r list of column c at [c & (V6_RHCOLS - 1)] (-1: no head)
     auto refill = [&](int upto) {                          // wave-uniform; lane <-> column, one view after the other (the view is a
         if (upto > b.right - 1) upto = b.right - 1;        // compile-time index: a per-lane choice among the descriptor's fields would
 #pragma unroll                                             // turn its register copy into an indexed object in scratch memory)
@@ -618,7 +648,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
                 const int col = c0_ + lane;
                 if (col <= upto) {
                     const int k2 = boff2[col + 1], lr_ = boff2[col + 2] - k2 - 1, lt_ = boff1[col + 2] - boff1[col + 1] - 1;
-                    rhring[col & (V6_RHCOLS - 1)] = lr_ > lt_ ? bfr2[k2] : 0.;
+                    rhring[col & (V6_RHCOLS - 1)] = lr_ > lt_ ? bfr2[k2] : -1.;          // (-1: the column's r view has no head entry)
                 }
             }
         }
@@ -716,7 +746,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
     simblk_fill(P, SB, 0, m0, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     double sim_cur = 0, bc_cur = 0;
-    int os_cur = 0, oe_cur = 0, ot_cur = 0, te_cur = 0, or_cur = 0, re_cur = 0;       // starts / ends (pool positions) of the column's three lists
+    int os_cur = 0, oe_cur = 0, ot_cur = 0, te_cur = 0;       // starts / ends (pool positions) of the column's s and t lists
     bool have = false;
     RS hu = rs_black(), gu = rs_black(), g2u = rs_black(), hd;
     const bool do_vert = m > a.left;
@@ -797,15 +827,15 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
         }
         // -- loads for the next step: next column's score / thickness / list offsets; the strip above's records two columns ahead
         double sim_nx = 0, bc_nx = 0;
-        int os_nx = 0, oe_nx = 0, ot_nx = 0, te_nx = 0, or_nx = 0, re_nx = 0;
+        int os_nx = 0, oe_nx = 0, ot_nx = 0, te_nx = 0;
         if (active) {
             if (!have) {
                 sim_cur = *simblk_at(SB, lane, n); bc_cur = bthk[(size_t) (n + 1) * 3];
-                os_cur = boff0[n + 1]; oe_cur = boff0[n + 2]; ot_cur = boff1[n + 1]; te_cur = boff1[n + 2]; or_cur = boff2[n + 1]; re_cur = boff2[n + 2];
+                os_cur = boff0[n + 1]; oe_cur = boff0[n + 2]; ot_cur = boff1[n + 1]; te_cur = boff1[n + 2];
             }
             if (n + 1 < hi) {
                 sim_nx = *simblk_at(SB, lane, n + 1); bc_nx = bthk[(size_t) (n + 2) * 3];
-                os_nx = oe_cur; oe_nx = boff0[n + 3]; ot_nx = te_cur; te_nx = boff1[n + 3]; or_nx = re_cur; re_nx = boff2[n + 3];
+                os_nx = oe_cur; oe_nx = boff0[n + 3]; ot_nx = te_cur; te_nx = boff1[n + 3];
             }
         }
         st_prev = n0 + 1 < hi0 && n0 + 2 <= c1;
@@ -818,8 +848,8 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
             B6 B;
             B.rs = ring[0]; B.rt = ring[1];
             B.os = os_cur - (n + 1); B.ot = ot_cur - (n + 1);                                     // compact positions (see Ring6)
-            B.rhf = rhring[n & (V6_RHCOLS - 1)];
-            B.lens = oe_cur - os_cur - 1; B.lent = te_cur - ot_cur - 1; B.lenr = re_cur - or_cur - 1;
+            { const double hv = rhring[n & (V6_RHCOLS - 1)]; B.rhf = hv >= 0 ? hv : 0.; B.lenr = te_cur - ot_cur - 1 + (hv >= 0 ? 1 : 0); }
+            B.lens = oe_cur - os_cur - 1; B.lent = te_cur - ot_cur - 1;
             const bool up_in = do_vert && (n - (m - 1) <= P.up);          // cell (m-1, n) exists
             const bool left_in = (n - 1 - m >= P.lw);                      // cell (m, n-1) exists
             const RS bk = rs_black();
@@ -850,7 +880,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
             p_tri = (size_t) (d - P.d0) * P.tstride + (m - mlo);
             p_trb = trb;
             sim_cur = sim_nx; bc_cur = bc_nx; have = (n + 1 < hi);
-            os_cur = os_nx; oe_cur = oe_nx; ot_cur = ot_nx; te_cur = te_nx; or_cur = or_nx; re_cur = re_nx;
+            os_cur = os_nx; oe_cur = oe_nx; ot_cur = ot_nx; te_cur = te_nx;
             if (m == a.right - 1 && n == b.right - 1) *P.score = myH.val;
         }
         p_act = active;
