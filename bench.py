@@ -23,6 +23,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one hardware queue per concurrent persistent launch (read at HIP initialisation)
 
 BYTES_PER_CELL = {2: 33, 3: 49}          # 2*Noll*sizeof(double) + 1 direction byte
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec

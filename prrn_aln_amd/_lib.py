@@ -23,6 +23,9 @@ def lib():
         return _lib
     if not os.path.exists(LIB):
         raise G2GError("libg2g.so is not built (python -m prrn_aln_amd.build); there is no CPU fallback")
+    # the persistent launches of a sweep run side by side on streams of their own; HIP multiplexes streams onto this many
+    # hardware queues (4 by default) -- read when the HIP runtime initialises, so it only helps if nothing has touched the GPU yet
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     L = C.CDLL(LIB)
     L.g2g_create.restype = C.c_void_p
     L.g2g_create.argtypes = [C.c_int]

@@ -39,19 +39,24 @@ extern "C" int g2g_abi_version(void) { return G2G_ABI_VERSION; }
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     g2g_set_error("HIP error: %s", hipGetErrorString(e_)); return G2G_ERR_DEVICE; } } while (0)
 
+#define G2G_NVS 8                   // (HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default: bench.py asks for 8)
 struct g2g_ctx {
     int device;
     int ok;
     hipStream_t stream;
-    hipStream_t vstream[6];         // one per concurrently running kernel variant: their tile wavefronts are independent
+    hipStream_t vstream[G2G_NVS];   // the persistent launches of a run are independent of each other: each takes the next of these streams
+                                    // (round 2 gave some pairs of launches one stream by table, and a sweep was the SUM of their times)
     hipEvent_t ev[4];
-    hipEvent_t vev[7];              // 0-3, 5-6: join events of the variant streams; 4: fork event
+    hipEvent_t vev[G2G_NVS + 1];    // join events of those streams; [G2G_NVS]: the fork event
     char *stage; size_t stage_cap;  // pinned host staging buffer of g2g_batch_prepare, kept between calls
     double rt_ticks_per_ms;         // rate of s_memrealtime on this device, measured at g2g_create (the waits' time limit is wall clock)
     std::map<std::string, std::pair<bool, std::string>> opt;   // g2g_set_option: name -> (present, value); see g2g_opt
     char *spare; size_t spare_bytes; // one device arena kept from the last freed batch (hipMalloc/hipFree of tens of GB per
                                     // call cost up to a second); contents are as undefined as a fresh allocation's
     long long n_runs, n_timeouts, n_recovered, n_v1;   // g2g_ctx_counters: batch runs, waits that ran into the limit, DPs re-run, of those on v1
+    struct MStream { int lo, n; hipStream_t s; unsigned long long used; };
+    std::vector<MStream> mstream;   // streams confined to a share of the CUs (units lo .. lo + n - 1 of 32; see cu_share_stream)
+    unsigned long long mstamp;
 };
 
 // Tuning and diagnostic switches belong to a context (g2g_set_option / g2g_get_option); a name a context has not set
@@ -111,10 +116,11 @@ extern "C" g2g_ctx *g2g_create(int device)
     c->stage = 0; c->stage_cap = 0;
     c->spare = 0; c->spare_bytes = 0;
     c->n_runs = c->n_timeouts = c->n_recovered = c->n_v1 = 0;
+    c->mstamp = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; g2g_set_error("%s", "stream"); return NULL; }
     for (int i = 0; i < 4; ++i) hipEventCreate(&c->ev[i]);
-    for (int i = 0; i < 6; ++i) hipStreamCreateWithFlags(&c->vstream[i], hipStreamNonBlocking);
-    for (int i = 0; i < 7; ++i) hipEventCreateWithFlags(&c->vev[i], hipEventDisableTiming);
+    for (int i = 0; i < G2G_NVS; ++i) hipStreamCreateWithFlags(&c->vstream[i], hipStreamNonBlocking);
+    for (int i = 0; i < G2G_NVS + 1; ++i) hipEventCreateWithFlags(&c->vev[i], hipEventDisableTiming);
     // the code object must contain an image for this GPU (the library is built for gfx950 only)
     hipFuncAttributes fa;
     hipError_t e = hipFuncGetAttributes(&fa, (const void *) g2g_forward_kernel);
@@ -148,8 +154,9 @@ extern "C" void g2g_destroy(g2g_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
-    for (int i = 0; i < 7; ++i) hipEventDestroy(c->vev[i]);
-    for (int i = 0; i < 6; ++i) hipStreamDestroy(c->vstream[i]);
+    for (int i = 0; i < G2G_NVS + 1; ++i) hipEventDestroy(c->vev[i]);
+    for (int i = 0; i < G2G_NVS; ++i) hipStreamDestroy(c->vstream[i]);
+    for (auto &m : c->mstream) hipStreamDestroy(m.s);
     hipStreamDestroy(c->stream);
     if (c->stage) hipHostFree(c->stage);
     if (c->spare) hipFree(c->spare);
@@ -245,6 +252,7 @@ struct g2g_batch {
     size_t simtile_lds;             // LDS of the tiled column-score kernel
     V2Tile *d_tiles;                // tiles: per variant (v2: hf2, hf3, pf2, pf3; v3: the same four) a queue ordered by wavefront i + j
     int var_off[25];                // variant v owns tiles [var_off[v], var_off[v+1])
+    long long var_cells[24];        // in-band cells of the DPs of variant v (the CU shares of a run are proportional to cells x cost)
     V3Lds v3lds[8];                 // LDS plan of the v3 variants
     V6Lds v6lds[6];                 // LDS plans of the v6 (_pf, one lane per cell, rank-form merges) launches: Noll 2, 3 x footprint class A / B / C
     int v2_cols;
@@ -304,7 +312,7 @@ static V3Lds v3_layout(int rows_bytes, int ca4max, int apool, int bpool, int C)
 }
 // LDS plan of the v6 kernel (g2g_kernels_v6.hip): ring rows of dynamic lists, black lists, staging scalars, the ring of
 // b's static lists (3 views x rs entries x 16 B), queue scratch, sinks
-struct V6Ring { int rs[3]; int at, as; };                  // ring entries per view; entries of the t lists of the strip that has the most
+struct V6Ring { int rs[3]; };                  // ring entries per view; entries of the t lists of the strip that has the most
 static V6Lds v6_layout(int rows_bytes, int ca4max, const V6Ring &R)
 {
     V6Lds L;
@@ -315,24 +323,20 @@ static V6Lds v6_layout(int rows_bytes, int ca4max, const V6Ring &R)
     L.stsc = take(4 * 28);
     for (int v = 0; v < 3; ++v) { L.rs[v] = R.rs[v]; L.ringf[v] = take(8 * R.rs[v]); }
     for (int v = 0; v < 3; ++v) L.ringk[v] = take(v < 2 ? 4 * R.rs[v] : 0);       // (view 2: an array of head freqs per column, no keys)
-    L.atcap = R.at;
-    L.atf = take(8 * (R.at + 2));                          // the t lists of the strip's rows, compact (g2g_kernels_v6.hip)
-    L.atk = take(4 * (R.at + 2));
-    L.ascap = R.as;
-    L.asf = take(8 * (R.as + 2));
     L.svals = take(4 * 64);
     L.sink = take(4 * 64 + 16 * 64);
     L.total = o;
     return L;
 }
-// A launch has ONE LDS plan, the largest of its DPs, and LDS decides how many strips a CU holds.  Since the dynamic lists keep
-// only their inline parts in LDS (g2g_kernels_v6.hip, LS6) a strip of the bench sweep takes 30-33 KB instead of 40-53: v6 DPs are
-// dealt to launches by footprint -- A up to 32 KB (five strips per CU), B up to V6_SMALL_KB (default 40 KB: four), C up to
-// V6_LARGE_KB (default 53 KB: three; 0 turns the class off) -- and DPs above that stay on v2.
-static const int V6_CLASS_A = 32 * 1024;
-static int v6_small_lds(const g2g_ctx *c) { const char *e = g2g_opt(c, "V6_SMALL_KB"); return e ? atoi(e) * 1024 : 40 * 1024; }
+// A launch has ONE LDS plan, the largest of its DPs, and LDS decides how many strips a CU holds (the kernel takes a whole SIMD's
+// registers: four per CU at most).  Since the dynamic lists keep only their inline parts in LDS (g2g_kernels_v6.hip, LS6) a strip
+// of the bench sweep takes 26-30 KB where it took 31-53 and more: class A (up to 40 KB, four strips per CU) now holds every _pf
+// DP of the sweep; B (up to V6_SMALL_KB, default 53: three per CU) and C (V6_LARGE_KB, off by default) remain for families with
+// more gap states per column, and DPs above that stay on v2.
+static const int V6_CLASS_A = 40 * 1024;
+static int v6_small_lds(const g2g_ctx *c) { const char *e = g2g_opt(c, "V6_SMALL_KB"); return e ? atoi(e) * 1024 : 53 * 1024; }
 #define V6_SMALL_LDS (v6_small_lds(ctx))
-static int v6_large_lds(const g2g_ctx *c) { const char *e = g2g_opt(c, "V6_LARGE_KB"); return e ? atoi(e) * 1024 : 53 * 1024; }
+static int v6_large_lds(const g2g_ctx *c) { const char *e = g2g_opt(c, "V6_LARGE_KB"); return e ? atoi(e) * 1024 : 0; }
 #define V6_LARGE_LDS (v6_large_lds(ctx))
 static inline int v6_slot(int cls) { return cls < 4 ? 12 + cls : 16 + cls; }      // queue / variant slot of class index (footprint class x 2 + Noll 3)
 static int v6_rows_bytes(const DevProb &d)
@@ -357,32 +361,7 @@ static V6Ring v6_ring_need(const g2g_problem *p)
         while (rs < need) rs <<= 1;
         R.rs[v] = v < 2 ? rs : V6_RHCOLS;                    // (the r view is derived from the t ring: only its head freqs, one per column)
     }
-    // entries (terminators not counted) of the t lists of 64 consecutive rows of a, strip by strip
-    R.at = 1;
-    {
-        const int32_t *off = p->a.gfq.off[1];
-        for (int m0 = p->a.left; m0 < p->a.right; m0 += 64) {
-            const int me = std::min(m0 + 64, p->a.right);
-            R.at = std::max(R.at, (off[me + 1] - (me + 1)) - (off[m0 + 1] - (m0 + 1)));
-        }
-        R.at = (R.at + 3) & ~3;
-        const int32_t *sof = p->a.gfq.off[0];
-        R.as = 1;
-        for (int m0 = p->a.left; m0 < p->a.right; m0 += 64) {
-            const int me = std::min(m0 + 64, p->a.right);
-            R.as = std::max(R.as, (sof[me + 1] - (me + 1)) - (sof[m0 + 1] - (m0 + 1)));
-        }
-        R.as = (R.as + 3) & ~3;
-    }
     return R;
-}
-// the longest s list (entries, terminator not counted) of a's rows: the _pf strip kernel keeps a row's s list in V6_NS registers
-static int v6_slist_max(const g2g_problem *p)
-{
-    const int32_t *off = p->a.gfq.off[0];
-    int mx = 0;
-    for (int m = p->a.left; m < p->a.right; ++m) mx = std::max(mx, off[m + 2] - off[m + 1] - 1);
-    return mx;
 }
 struct V3Need { int rows_bytes, ca4, apool, bpool, total; };
 static V3Need v3_need(const DevProb &d, const g2g_problem *p, int C, bool areg = false)
@@ -591,6 +570,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
     b->src.assign(prob, prob + n); b->fail_off = 0; b->force_v1 = force_v1; b->is_retry = false; b->n_recovered = 0;
     b->recovered.assign(n, g2g_result()); b->was_recovered.assign(n, 0);
     b->nsimmat = 0;
+    for (int k = 0; k < 24; ++k) b->var_cells[k] = 0;
     b->last_timeouts = b->last_recovered = 0;
     b->v3_cols = 128; b->v2_cols = G2G_V2_TILE_COLS;
 
@@ -745,7 +725,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         }
         if ((d.kind == 1 || d.kind == 2) && !force_v1 && !g2g_opt(ctx, "FORCE_V1") && p->a.len + p->b.len < 65000) {
             // _pf: one lane per cell with rank-form merges (v6) when the rows' static lists fit the register file
-            if (b->v6_on && !g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_V6") && d.kind == 2 && v6_slist_max(p) <= V6_NS && d.a.r_from_t && d.b.r_from_t &&
+            if (b->v6_on && !g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_V6") && d.kind == 2 && d.a.maxlist <= (d.noll == 3 ? G2G_V6_NA3 : G2G_V6_NA) && d.a.r_from_t && d.b.r_from_t &&
                 v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(p)).total <= std::max(V6_SMALL_LDS, V6_LARGE_LDS)) d.v2_ok = 6;
             else if (!g2g_opt(ctx, "FORCE_V2") && !g2g_opt(ctx, "NO_AREG") && d.kind == 1 && d.a.maxlist <= G2G_V3_NA && d.a.r_from_t &&
                 v3_need(d, p, b->v3_cols, true).total <= (int) V2_LDS_MAX) d.v2_ok = 3;
@@ -855,7 +835,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         std::vector<int> ip;                              // the other DPs: chains in the prologue kernel
         const bool chainq = !g2g_opt(ctx, "NO_CHAINQ");
         int v6rows[6] = {0, 0, 0, 0, 0, 0}, v6ca4[6] = {0, 0, 0, 0, 0, 0};
-        V6Ring v6rs[6] = {{{32, 32, 32}, 4, 4}, {{32, 32, 32}, 4, 4}, {{32, 32, 32}, 4, 4}, {{32, 32, 32}, 4, 4}, {{32, 32, 32}, 4, 4}, {{32, 32, 32}, 4, 4}};
+        V6Ring v6rs[6] = {{{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}, {{32, 32, 32}}};
         V3Need need[8];
         memset(need, 0, sizeof need);
         for (int i = 0; i < n; ++i) {
@@ -880,10 +860,11 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
             int v6cls = 0;
             if (d.v2_ok == 6) { const int tot = v6_layout(v6_rows_bytes(d), (d.capa + 3) & ~3, v6_ring_need(prob[i])).total; v6cls = (d.noll == 3 ? 1 : 0) + (tot > V6_SMALL_LDS ? 4 : tot > V6_CLASS_A ? 2 : 0); }
             const int var = d.v2_ok == 8 ? 18 + (d.noll == 3 ? 1 : 0) : d.v2_ok == 7 ? 16 + (d.noll == 3 ? 1 : 0) : d.v2_ok == 6 ? v6_slot(v6cls) : (d.v2_ok - 1) * 4 + (d.kind == 2 ? 2 : 0) + (d.noll == 3 ? 1 : 0);
+            b->var_cells[var] += b->cells[i];
             if (d.v2_ok == 6) {
                 v6rows[v6cls] = std::max(v6rows[v6cls], v6_rows_bytes(d));
                 v6ca4[v6cls] = std::max(v6ca4[v6cls], (d.capa + 3) & ~3);
-                { const V6Ring rn = v6_ring_need(prob[i]); for (int q = 0; q < 3; ++q) v6rs[v6cls].rs[q] = std::max(v6rs[v6cls].rs[q], rn.rs[q]); v6rs[v6cls].at = std::max(v6rs[v6cls].at, rn.at); v6rs[v6cls].as = std::max(v6rs[v6cls].as, rn.as); }
+                { const V6Ring rn = v6_ring_need(prob[i]); for (int q = 0; q < 3; ++q) v6rs[v6cls].rs[q] = std::max(v6rs[v6cls].rs[q], rn.rs[q]); }
             } else if (d.v2_ok >= 7) {
             } else if (d.v2_ok >= 2) {
                 const V3Need nd = v3_need(d, prob[i], C, d.v2_ok == 3);
@@ -972,6 +953,45 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
     return G2G_OK;
 }
 
+
+// ---- CU shares ---------------------------------------------------------------------------------------------------
+// The persistent launches of a sweep used to share every CU: whichever workgroup the dispatcher picked next took the LDS
+// and the wave slots that had just become free, so strips of up to four kernels sat side by side on a CU.  A run that
+// fills the machine now gives each launch a SHARE of the CUs of its own (hipExtStreamCreateWithCUMask): the chip is cut
+// into 32 units -- unit u = CU slot u of every XCD, which is how the mask bits map on this part (bit i -> XCD i % 8,
+// CU slot i / 8: tools/probes/cumask_probe.hip) -- and a launch gets a contiguous range of units in proportion to its
+// estimated work, capped by what its strips can occupy.  No CU ever holds workgroups of two launches, every launch
+// still spreads over all eight XCDs (L2s), and a grid is sized for ITS CUs.  Small runs (a refinement window) keep the
+// whole chip for every launch: there a DP's critical path is what counts.
+static hipStream_t cu_share_stream(g2g_ctx *c, int lo, int n)
+{
+    for (auto &m : c->mstream) if (m.lo == lo && m.n == n) { m.used = ++c->mstamp; return m.s; }
+    if (c->mstream.size() >= 24) {                          // forget the least recently used share
+        size_t k = 0;
+        for (size_t i = 1; i < c->mstream.size(); ++i) if (c->mstream[i].used < c->mstream[k].used) k = i;
+        hipStreamSynchronize(c->mstream[k].s); hipStreamDestroy(c->mstream[k].s);
+        c->mstream.erase(c->mstream.begin() + k);
+    }
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int bit = 8 * lo; bit < 8 * (lo + n) && bit < 256; ++bit) mask[bit >> 5] |= 1u << (bit & 31);
+    g2g_ctx::MStream m; m.lo = lo; m.n = n; m.s = 0; m.used = ++c->mstamp;
+    if (hipExtStreamCreateWithCUMask(&m.s, 8, mask) != hipSuccess || !m.s) { (void) hipGetLastError(); return 0; }
+    c->mstream.push_back(m);
+    return m.s;
+}
+// relative cost of a cell on the kernel of variant slot v (what the shares are proportional to)
+static double variant_cost(int v)
+{
+    const double n3 = (v & 1) ? 1.4 : 1.0;                  // odd slots: Noll 3
+    if (v < 2) return 2.0 * n3;                             // v2 _hf
+    if (v < 4) return 5.0 * n3;                             // v2 _pf
+    if (v < 8) return 2.5 * n3;                             // v3 with LDS lists
+    if (v < 12) return 1.0 * n3;                            // v3r
+    if (v < 16 || v >= 20) return 2.7 * n3;                 // v6
+    if (v < 18) return 0.8 * n3;                            // v7
+    return 1.2 * n3;                                        // v8
+}
+
 // Compact the valid problems to the front?  No: invalid ones keep kind = -1 and the kernels skip them.
 extern "C" int g2g_batch_run(g2g_batch *b)
 {
@@ -1001,14 +1021,14 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                                    (const DevProb *) b->d_probs, (const int *) b->d_idx2, b->n2);
                 HIPCHK(hipGetLastError());
             }
-            HIPCHK(hipEventRecord(ctx->vev[4], ctx->stream));
-            HIPCHK(hipStreamWaitEvent(ctx->vstream[3], ctx->vev[4], 0));
+            HIPCHK(hipEventRecord(ctx->vev[G2G_NVS], ctx->stream));
+            HIPCHK(hipStreamWaitEvent(ctx->vstream[G2G_NVS - 1], ctx->vev[G2G_NVS], 0));
             if (b->np) {
-                hipLaunchKernelGGL(g2g_v2_prologue_kernel, dim3(b->np), dim3(128), pro_off ? pro_off + 2 * PRO_LDS_BYTES : b->lds2p, ctx->vstream[3],
+                hipLaunchKernelGGL(g2g_v2_prologue_kernel, dim3(b->np), dim3(128), pro_off ? pro_off + 2 * PRO_LDS_BYTES : b->lds2p, ctx->vstream[G2G_NVS - 1],
                                    (const DevProb *) b->d_probs, (const int *) b->d_idxp, pro_off);
                 HIPCHK(hipGetLastError());
             }
-            HIPCHK(hipEventRecord(ctx->vev[3], ctx->vstream[3]));
+            HIPCHK(hipEventRecord(ctx->vev[G2G_NVS - 1], ctx->vstream[G2G_NVS - 1]));
             if (b->nsimmat) {
                 const int simtiled = (!g2g_opt(ctx, "NO_SIMTILE") && b->simtile_lds && b->simtile_lds <= 64 * 1024) ? 1 : 0;
                 if (simtiled) {
@@ -1020,7 +1040,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                                    (const DevProb *) b->d_probs, (const int *) b->d_idx2, simtiled);
                 HIPCHK(hipGetLastError());
             }
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[3], 0));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[G2G_NVS - 1], 0));
         }
         if (g2g_opt(ctx, "DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[g2g] prologue+sim done: %s\n", hipGetErrorString(e3)); fflush(stderr); }
         // persistent tile / strip kernels: one launch per kernel variant, each on its own stream (they are independent)
@@ -1048,7 +1068,8 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipMemcpyAsync(b->d_flags, hdr, sizeof b->hdr_img, hipMemcpyHostToDevice, ctx->stream));
             HIPCHK(hipMemsetAsync(b->d_flags + b->fail_off, 0, sizeof(int) * (size_t) (b->n > 0 ? b->n : 1), ctx->stream));
         }
-        HIPCHK(hipEventRecord(ctx->vev[4], ctx->stream));
+        HIPCHK(hipEventRecord(ctx->vev[G2G_NVS], ctx->stream));
+        int nlaunch = 0;                                      // every persistent launch of this run takes the next stream
         int ncu = 256;
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) ncu = pr.multiProcessorCount; }
         auto sim_scratch = [&](int slot, int grid) -> double * {
@@ -1061,18 +1082,102 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             }
             return b->simscr[slot];
         };
+        // ---- CU shares of this run's persistent launches (cu_share_stream) ----
+        int sh_lo[G2G_HDR], sh_n[G2G_HDR];
+        bool shares = false;
+        {
+            const int T2s = b->v2_threads;
+            auto wpc_of = [&](int v) -> int {                 // resident workgroups per CU of variant slot v
+                if (v < 4) return std::max(1, std::min(2048 / T2s, (int) (V2_LDS_MAX / (b->lds2 + 4 * (size_t) T2s))));
+                if (v < 12) { const int t = b->v3lds[v - 4].total; return t > 0 ? std::max(1, std::min(16, (int) (V2_LDS_MAX / (size_t) t))) : 1; }
+                if (v < 16 || v >= 20) { const int cls = v < 16 ? v - 12 : v - 16; const int t = b->v6lds[cls].total; return t > 0 ? std::max(1, std::min(4, (int) (V2_LDS_MAX / (size_t) t))) : 1; }
+                return v < 18 ? 16 : 4;
+            };
+            double work[G2G_HDR], tot = 0;
+            int need[G2G_HDR], nl = 0;
+            double demand = 0;
+            for (int v = 0; v < G2G_HDR; ++v) {
+                const int cnt = b->var_off[v + 1] - b->var_off[v];
+                work[v] = cnt ? (double) std::max<long long>(b->var_cells[v], 1) * variant_cost(v) : 0;
+                need[v] = cnt ? std::min(32, std::max(1, (cnt + 8 * wpc_of(v) - 1) / (8 * wpc_of(v)))) : 0;   // units its tiles can occupy
+                sh_lo[v] = 0; sh_n[v] = 0;
+                if (cnt) { ++nl; tot += work[v]; demand += (double) cnt / wpc_of(v); }
+            }
+            const char *opt = g2g_opt(ctx, "CU_SHARES");
+            const bool want = opt ? atoi(opt) != 0 : true;
+            const bool force = opt && atoi(opt) >= 2;           // (test switch: shares even for a run that does not fill the machine)
+            // only a run that fills the machine more than twice over is partitioned, and only if every launch can have a unit
+            if (want && ncu == 256 && nl >= 2 && nl <= 16 && (force || demand >= 2.0 * ncu) && tot > 0 && !g2g_opt(ctx, "DEBUG")) {      // (256 CUs in 8 XCDs: the mask layout the shares are written for)
+                int left = 32;
+                double wleft = tot;
+                bool done[G2G_HDR];
+                for (int v = 0; v < G2G_HDR; ++v) done[v] = work[v] == 0;
+                // launches whose tiles cannot fill their proportional share take what they can fill; the rest is re-divided
+                for (int round = 0; round < G2G_HDR; ++round) {
+                    bool changed = false;
+                    for (int v = 0; v < G2G_HDR; ++v) {
+                        if (done[v]) continue;
+                        const double prop = wleft > 0 ? left * work[v] / wleft : 0;
+                        if (need[v] <= prop) { sh_n[v] = need[v]; left -= need[v]; wleft -= work[v]; done[v] = true; changed = true; }
+                    }
+                    if (!changed) break;
+                }
+                int open_ = 0;
+                for (int v = 0; v < G2G_HDR; ++v) if (!done[v]) ++open_;
+                if (left >= open_) {
+                    int given = 0;
+                    double frac[G2G_HDR];
+                    for (int v = 0; v < G2G_HDR; ++v) {
+                        frac[v] = -1;
+                        if (done[v]) continue;
+                        const double prop = left * work[v] / wleft;
+                        sh_n[v] = std::max(1, (int) prop);
+                        frac[v] = prop - (int) prop;
+                        given += sh_n[v];
+                    }
+                    while (given < left) {                       // largest remainders first
+                        int best = -1;
+                        for (int v = 0; v < G2G_HDR; ++v) if (frac[v] >= 0 && (best < 0 || frac[v] > frac[best])) best = v;
+                        if (best < 0) break;
+                        ++sh_n[best]; frac[best] = -0.5; ++given;
+                    }
+                    while (given > left) {                       // (the minimum of one unit each overdrew: take from the largest)
+                        int big = -1;
+                        for (int v = 0; v < G2G_HDR; ++v) if (!done[v] && sh_n[v] > 1 && (big < 0 || sh_n[v] > sh_n[big])) big = v;
+                        if (big < 0) break;
+                        --sh_n[big]; --given;
+                    }
+                    if (given == left) {
+                        int lo = 0;
+                        shares = true;
+                        for (int v = 0; v < G2G_HDR; ++v) if (sh_n[v]) { sh_lo[v] = lo; lo += sh_n[v]; if (!cu_share_stream(ctx, sh_lo[v], sh_n[v])) shares = false; }
+                        if (lo > 32) shares = false;
+                    }
+                }
+            }
+            if (g2g_opt(ctx, "WARN") && shares) {
+                fprintf(stderr, "[g2g] CU shares (units of 8 CUs, one per XCD):");
+                for (int v = 0; v < G2G_HDR; ++v) if (sh_n[v]) fprintf(stderr, " slot %d: %d..%d", v, sh_lo[v], sh_lo[v] + sh_n[v] - 1);
+                fprintf(stderr, "\n");
+            }
+        }
+        auto launch_stream = [&](int slot, int k) -> hipStream_t { return shares ? cu_share_stream(ctx, sh_lo[slot], sh_n[slot]) : ctx->vstream[k]; };
+        auto launch_cus = [&](int slot) -> int { return shares ? 8 * sh_n[slot] : ncu; };
         for (int v = 0; v < 4; ++v) {
             const int cnt = b->var_off[v + 1] - b->var_off[v];
             if (!cnt) continue;
-            HIPCHK(hipStreamWaitEvent(ctx->vstream[v], ctx->vev[4], 0));
+            const int sk2 = nlaunch++ % G2G_NVS;
+            hipStream_t vs2 = launch_stream(v, sk2);
+            const int ncu2 = launch_cus(v);
+            HIPCHK(hipStreamWaitEvent(vs2, ctx->vev[G2G_NVS], 0));
             int wpc2 = 2048 / T2;              // workgroups per CU the grid provides (LDS decides how many are resident)
             if (const char *e = g2g_opt(ctx, "V2_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc2 = w; }
-            const int grid = std::min(cnt, ncu * wpc2);
+            const int grid = std::min(cnt, ncu2 * wpc2);
             // sweep mode: the kernel argument is the publish interval.  A DP's critical path is columns + strips x
             // interval: 32 steps when the strips outnumber the resident workgroups several times over (throughput
             // bound, fewer fences), 16 when they do not (a shard of a sweep: -8 % at 1/8 of the bench sweep), 4 when the
             // strips fill less than a quarter of the chip (a handful of DPs: latency is all that counts, -10 %).
-            const int res2 = ncu * std::max(1, std::min(wpc2, (int) (V2_LDS_MAX / (b->lds2 + 4 * (size_t) T2))));
+            const int res2 = ncu2 * std::max(1, std::min(wpc2, (int) (V2_LDS_MAX / (b->lds2 + 4 * (size_t) T2))));
             const int pint2 = !b->v2_sweep ? 0 : b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= res2 ? 4 : cnt < 4 * res2 ? 16 : 32;
             if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] variant %d: %d tiles, grid %d x %d threads, lds %zu, cols %d, gen %d\n", v, cnt, grid, T2, b->lds2, b->v2_cols, b->gen); fflush(stderr); }
             double *simscr2 = 0;
@@ -1080,28 +1185,30 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                 simscr2 = sim_scratch(v, grid);
                 if (!simscr2) { g2g_set_error("%s", "hipMalloc(column-score scratch)"); return G2G_ERR_NOMEM; }
             }
-            hipLaunchKernelGGL(v2k[v], dim3(grid), dim3(T2), b->lds2 + 4 * T2, ctx->vstream[v],
+            hipLaunchKernelGGL(v2k[v], dim3(grid), dim3(T2), b->lds2 + 4 * T2, vs2,
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v]), cnt,
                                b->d_flags + v, b->d_flags, b->gen, (int) b->lds2, b->v2_sweep ? (1 << 20) : b->v2_cols, pint2,
                                (pro_off && pro_off + PRO_LDS_BYTES <= b->lds2) ? pro_off : 0, simscr2);
             HIPCHK(hipGetLastError());
-            if (g2g_opt(ctx, "DEBUG")) { hipError_t e3 = hipStreamSynchronize(ctx->vstream[v]); fprintf(stderr, "[g2g] variant %d done: %s\n", v, hipGetErrorString(e3)); fflush(stderr); }
-            HIPCHK(hipEventRecord(ctx->vev[v], ctx->vstream[v]));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[v], 0));
+            if (g2g_opt(ctx, "DEBUG")) { hipError_t e3 = hipStreamSynchronize(vs2); fprintf(stderr, "[g2g] variant %d done: %s\n", v, hipGetErrorString(e3)); fflush(stderr); }
+            HIPCHK(hipEventRecord(ctx->vev[sk2], vs2));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[sk2], 0));
         }
         for (int v = 0; v < 8; ++v) {
             const int cnt = b->var_off[v + 5] - b->var_off[v + 4];
             if (!cnt || !v3k[v]) continue;
             if (const char *e = g2g_opt(ctx, "ONLY_VAR")) if (atoi(e) != v) continue;       // profiling aid
-            hipStream_t vs = ctx->vstream[v & 3];
+            const int sk3 = nlaunch++ % G2G_NVS;
+            hipStream_t vs = launch_stream(v + 4, sk3);
+            const int ncu3 = launch_cus(v + 4);
             const V3Lds &LO = b->v3lds[v];
             const bool swpv = (v & 3) < 2;                   // the _hf variants (LDS lists 0,1; register lists 4,5) run in sweep mode
             if (LO.total > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *) v3k[v], hipFuncAttributeMaxDynamicSharedMemorySize, LO.total));
-            HIPCHK(hipStreamWaitEvent(vs, ctx->vev[4], 0));
+            HIPCHK(hipStreamWaitEvent(vs, ctx->vev[G2G_NVS], 0));
             int wpc = (int) (V2_LDS_MAX / (size_t) LO.total);              // resident tiles per CU (LDS-bound)
             if (wpc < 1) wpc = 1; if (wpc > 16) wpc = 16;
             if (const char *e = g2g_opt(ctx, "V3_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc = w; }
-            const int grid = std::min(cnt, ncu * wpc);
+            const int grid = std::min(cnt, ncu3 * wpc);
             if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] v3 variant %d: %d tiles, grid %d, lds %d (rows %d, apool@%d, bpool@%d), cols %d, gen %d\n", v, cnt, grid, LO.total, LO.black, LO.aglen, LO.bglen, b->v3_cols, b->gen); fflush(stderr); }
             double *simscr3 = 0;
             if (swpv && b->v3_sweep && !g2g_opt(ctx, "NO_SIMBLK")) {
@@ -1111,12 +1218,12 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             hipLaunchKernelGGL(v3k[v], dim3(grid), dim3(64), (size_t) LO.total, vs,
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v + 4]), cnt,
                                b->d_flags + 4 + v, b->d_flags, b->gen, LO, (swpv && b->v3_sweep) ? (1 << 20) : b->v3_cols,
-                               !(swpv && b->v3_sweep) ? 0 : b->v3_sweep >= 2 ? b->v3_sweep : 4 * cnt <= ncu * std::min(wpc, 8) ? 4 : cnt < 4 * ncu * std::min(wpc, 8) ? 16 : 32,
+                               !(swpv && b->v3_sweep) ? 0 : b->v3_sweep >= 2 ? b->v3_sweep : 4 * cnt <= ncu3 * std::min(wpc, 8) ? 4 : cnt < 4 * ncu3 * std::min(wpc, 8) ? 16 : 32,
                                (pro_off && pro_off + (int) PRO_LDS_BYTES <= LO.svals) ? pro_off : 0, simscr3);
             HIPCHK(hipGetLastError());
             if (g2g_opt(ctx, "DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v3 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
-            HIPCHK(hipEventRecord(ctx->vev[v & 3], vs));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[v & 3], 0));
+            HIPCHK(hipEventRecord(ctx->vev[sk3], vs));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[sk3], 0));
         }
         for (int vi = 0; vi < 6; ++vi) {
             const int v = 5 - vi;                    // (the larger-footprint launch first)
@@ -1125,16 +1232,17 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             if (!cnt) continue;
             typedef void (*v6k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, V6Lds, int, int, double *, unsigned *, int);
             static const v6k_t v6k[6] = {g2g_v6_pf2, g2g_v6_pf3, g2g_v6_pf2, g2g_v6_pf3, g2g_v6_pf2, g2g_v6_pf3};
-            hipStream_t vs = ctx->vstream[v < 4 ? 2 + v : v - 4];        // class A: streams 2, 3; B: 4, 5; C: 0, 1
-            const int jev = v < 2 ? 2 + v : v < 4 ? 3 + v : v - 4;
+            const int jev = nlaunch++ % G2G_NVS;
+            hipStream_t vs = launch_stream(slot, jev);
+            const int ncu6 = launch_cus(slot);
             const V6Lds &LO = b->v6lds[v];
             if (LO.total > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *) v6k[v], hipFuncAttributeMaxDynamicSharedMemorySize, LO.total));
-            HIPCHK(hipStreamWaitEvent(vs, ctx->vev[4], 0));
+            HIPCHK(hipStreamWaitEvent(vs, ctx->vev[G2G_NVS], 0));
             int wpc = (int) (V2_LDS_MAX / (size_t) LO.total);              // resident strips per CU (LDS-bound)
-            if (wpc < 1) wpc = 1; if (wpc > 8) wpc = 8;
+            if (wpc < 1) wpc = 1; if (wpc > 4) wpc = 4;       // (the kernel takes a whole SIMD's registers: four strips per CU at most)
             if (const char *e = g2g_opt(ctx, "V6_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc = w; }
-            const int grid = std::min(cnt, ncu * wpc);
-            const int pint = b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= ncu * wpc ? 4 : cnt < 4 * ncu * wpc ? 16 : 32;   // publish interval (power of 2)
+            const int grid = std::min(cnt, ncu6 * wpc);
+            const int pint = b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= ncu6 * wpc ? 4 : cnt < 4 * ncu6 * wpc ? 16 : 32;   // publish interval (power of 2)
             if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] v6 variant %d: %d strips, grid %d, lds %d (rings %d / %d / %d entries), publish every %d, gen %d\n", v, cnt, grid, LO.total, LO.rs[0], LO.rs[1], LO.rs[2], pint, b->gen); fflush(stderr); }
             double *simscr6 = sim_scratch(slot, grid);
             if (!simscr6) { g2g_set_error("%s", "hipMalloc(column-score scratch)"); return G2G_ERR_NOMEM; }
@@ -1163,11 +1271,13 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             if (!cnt) continue;
             typedef void (*v7k_t)(const DevProb *, const V2Tile *, int, int *, int *, int, int, double *);
             static const v7k_t v7k[4] = {g2g_v7_ngp2, g2g_v7_ngp3, g2g_v8_ntv2, g2g_v8_ntv3};
-            hipStream_t vs = ctx->vstream[4 + (v & 1)];
-            HIPCHK(hipStreamWaitEvent(vs, ctx->vev[4], 0));
+            const int sk7 = nlaunch++ % G2G_NVS;
+            hipStream_t vs = launch_stream(v + 16, sk7);
+            const int ncu7 = launch_cus(v + 16);
+            HIPCHK(hipStreamWaitEvent(vs, ctx->vev[G2G_NVS], 0));
             const int wpc = v < 2 ? 16 : 4;                  // (v8 holds its records' lengths in registers: one wave per SIMD)
-            const int grid = std::min(cnt, ncu * wpc);
-            const int pint = b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= ncu * wpc ? 4 : cnt < 4 * ncu * wpc ? 16 : 32;
+            const int grid = std::min(cnt, ncu7 * wpc);
+            const int pint = b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= ncu7 * wpc ? 4 : cnt < 4 * ncu7 * wpc ? 16 : 32;
             double *simscr7 = sim_scratch(16 + v, grid);
             if (!simscr7) { g2g_set_error("%s", "hipMalloc(column-score scratch)"); return G2G_ERR_NOMEM; }
             if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] %s variant %d: %d strips, grid %d, publish every %d, gen %d\n", v < 2 ? "v7" : "v8", v & 1, cnt, grid, pint, b->gen); fflush(stderr); }
@@ -1175,8 +1285,8 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                                b->d_flags + 16 + v, b->d_flags, b->gen, pint, simscr7);
             HIPCHK(hipGetLastError());
             if (g2g_opt(ctx, "DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] %s variant %d done: %s, %.1f ms\n", v < 2 ? "v7" : "v8", v & 1, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
-            HIPCHK(hipEventRecord(ctx->vev[5 + (v & 1)], vs));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[5 + (v & 1)], 0));
+            HIPCHK(hipEventRecord(ctx->vev[sk7], vs));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[sk7], 0));
         }
 }
     if (b->n1) {

@@ -2,30 +2,32 @@
 // merges in RANK form instead of two-pointer walks.
 //
 // Same recurrence and arithmetic order as every other generation (Fwd2c<DPunit_pf>::forwardB, reference src/fwd2c.h:359-482,
-// gapopen/update src/fwd2c.cc:203-233, newgap/newdelta/incdelta src/gfreq.cc:507-521,570-605).  What differs is how a cell's
+// gapopen/update src/fwd2c.cc:203-233, newgap/newdelta/incdelta src/gfreq.cc:507-521,570-605).  What is new is how a cell's
 // six (eight with Noll 3) gap-open costs are evaluated.  newgap(cf, dlc, df, dld) walks df and keeps a pointer into cf that
 // moves to the first entry whose STRETCHED length i = glen + nins(dlc, glen) reaches the stretched length j of the current
 // df entry; both sequences are non-decreasing, so that pointer is simply the lower bound of j in {i}:
 //        g = sum over d (in list order) of  cf.freq[ first c with i_c >= j_d ] * df.freq[d]       (0 once cf is exhausted)
-// Every term is independent of the others; only the ORDER of the additions is part of the contract.  Here every loop runs
-// over a list index that is the same in all lanes, and "first c with i_c >= j" is a select chain walked from the last entry
-// down (the lowest hit is written last): no per-lane pointer, no divergent branch.
-//
-// Second form (round 3).  The first form kept both of the row's static lists in registers (96 VGPRs), the heads of all
-// fourteen dynamic lists of a cell at once and three instances of the cell: 511 registers, 365 spilled SGPRs, 1.1 KB of
-// scratch per lane, one wave per SIMD.  Now:
-//   * the row's s list (at most NS = 8 entries on this path: the host sends longer ones elsewhere) stays in registers; the
-//     row's t list -- the long one -- is staged once per strip into LDS in compact form (the lists of consecutive rows follow
-//     each other, a lane knows its start and length) and every loop over it is a rolled loop reading LDS;
-//   * the X merges (cf = the column's s list, df = the row's t / r list) run with df OUTSIDE: the column's s entries are
-//     stretched once into NC = 6 registers and each row entry walks the select chain (a wave whose longest column list is
-//     longer takes a fully rolled form);
-//   * heads of dynamic lists hold six entries and are loaded per PHASE (merges with the row's s list / with the column's s
-//     list / the two list updates), a lookup beyond the head scans LDS inline behind one wave-uniform test -- ONE instance of
-//     the cell for any list length;
-//   * no private array is indexed by anything but a constant: no scratch.
+// Every term is independent of the others; only the ORDER of the additions is part of the contract.  On a 64-wide wave the
+// two-pointer walk is a divergent loop with a dependent LDS read per step (v2: 93 VALU + 125 SALU wave instructions per cell);
+// here every loop runs over a list index that is the same in all lanes:
+//   * row side (a): lane t owns row m0 + t of a 64-row strip; the row's three static lists live in REGISTERS (never change
+//     inside a strip), loops over them are fully unrolled and leave at the wave's longest list;
+//   * column side (b): the columns' static lists stream through a small LDS RING indexed by pool position (lists of
+//     consecutive columns are contiguous in the profile pools), refilled 16 columns at a time; loops over them are rolled
+//     and read entry k of every lane's own column;
+//   * "first c with i_c >= j" is a select chain walked from the last entry down (the lowest hit is written last), no
+//     per-lane pointer, no branch;
+//   * dynamic lists are read through register heads that are sanitised behind their terminator.
 // Strips of a DP run as a pipeline on progress counters exactly as in g2g_kernels_v3.hip (sweep mode); record scalars travel
 // down the lanes by DPP; the strip boundary and the boundary chains use the v2 record image in HBM.
+//
+// Round 3: LDS decides how many strips a CU holds, and the rings of dynamic lists were most of it (a slot per list of
+// hetero + 1 dwords: 31-45 KB per strip).  Now a list keeps only its INLINE part in LDS and the rest in an HBM twin (LS6 below):
+// 26-30 KB per strip, so EVERY _pf DP of a sweep runs at four strips per CU -- those that ran three per CU or fell back to the
+// 8-lanes-per-cell kernel before included.  (A second form of the cell -- row lists in LDS, rolled loops, 253 registers, two
+// waves per SIMD -- was built and measured: slower per cell at equal occupancy, and LDS would not let the second wave in; it is
+// in the history of this file.)  The ring refill no longer picks a descriptor field by a per-lane index, which had put the
+// register copy of the whole descriptor into scratch memory (1.1 KB per lane): the kernel has no private segment now.
 #include <hip/hip_runtime.h>
 
 // HBM pointers of the sweep carry their address space: a generic pointer compiles to flat_load/flat_store, which also
@@ -47,7 +49,7 @@ __device__ unsigned long long g2g_v6_stamp_acc[16];
 #endif
 
 // byte offsets; ringk / ringf / rs: per view (s, t, r) the key and freq arrays of the column-list ring and its entries (power of 2)
-struct V6Lds { int rows, black, stsc, svals, sink, total; int ringk[3], ringf[3], rs[3]; int atk, atf, atcap, asf, ascap; };   // atk / atf / atcap: keys, freqs and entries of the strip's t lists; asf / ascap: freqs of its s lists
+struct V6Lds { int rows, black, stsc, svals, sink, total; int ringk[3], ringf[3], rs[3]; };
 
 #define V6_FEED 16                      // columns per ring refill
 #define V6_AHEAD 32                     // a refill reaches this many columns beyond lane 0's
@@ -61,7 +63,7 @@ struct V6Lds { int rows, black, stsc, svals, sink, total; int ringk[3], ringf[3]
 // offset x 2, so an inline part of I dwords owns 2 I dwords there; capacities above 16 take I = 16, 32).  Only the code that
 // already handled "beyond the register head" ever gets there -- the scans, the stores of a long newdelta result, the strip
 // hand-over of a long list -- always behind a wave-uniform test.  A wave reads back only what it wrote itself, after a
-// s_waitcnt vmcnt(0).  LDS per strip drops from 32-45 KB to 20-27 KB: five or six strips per CU instead of three or four.
+// s_waitcnt vmcnt(0).  LDS per strip drops from 31-45 KB (and more) to 26-30 KB.
 G2G_HD inline int v6_inline_dw(int cap4) { return cap4 <= 4 ? 4 : cap4 <= 16 ? 8 : cap4 <= 32 ? 16 : cap4 <= 64 ? 32 : cap4; }
 struct LS6 { const lu32 *rows0; GLB unsigned *tw; int ia, ib; };          // first dword of the rows, the twin image, inline dwords per side
 __device__ __forceinline__ GLB unsigned *ls6_twin(const LS6 &W, const lu32 *p, const int k) { return W.tw + 2 * (int) (p - W.rows0) + k; }
@@ -75,21 +77,29 @@ __device__ __forceinline__ void ls6_wr(const LS6 &W, lu32 *p, const int k, const
 // ---- register heads of dynamic lists ---------------------------------------------------------------------
 // {glen,nins} packed 16+16, ascending in both, terminator 0xFFFF0000; the first entry is never the terminator.  Behind the
 // terminator memory is stale: the head replaces it by terminators, so a lookup is a chain of unsigned compares of the
-// packed key (g << 16 | 0xFFFF) with no validity tests.  NE = 6 leading entries are held (ds_read_b128 + b96);
-// x = entry NE, sanitised the same way: x < T says the list is longer than the head, and a lookup that reaches x scans LDS
-// behind ONE wave-uniform test (0.3 % of the lists of a refinement sweep have seven entries or more).
+// packed key (g << 16 | 0xFFFF) with no validity tests.  NE leading entries are held (5: ds_read_b128 + b64; 8: two b128);
+// x = entry NE, sanitised the same way: x < T says the list is longer than the head.
+// The cell exists in three instances (v6_cell_pf): NE = 5 and NE = 8 WITHOUT any per-lookup test -- they leave at once
+// when some lane's list is longer than the head (0.012 % of the lists have six entries or more, 4e-6 nine or more) -- and
+// NE = 8 with an inline scan of LDS behind the head (SCAN), which is correct for any length.
 #define V6_UNROLL _Pragma("clang loop unroll(full)")
 template <int NE> struct DH { unsigned e[NE]; unsigned x; const lu32 *p; };
+// (I: inline dwords of the list's side.  An eight-entry head of a list whose inline part is eight dwords finds entry 8 in the
+// twin -- looked at only when entry 7 is not the terminator, behind a wave-uniform test)
 template <int NE>
-__device__ __forceinline__ DH<NE> dh_load6(const lu32 *p)
+__device__ __forceinline__ DH<NE> dh_load6(const lu32 *p, const LS6 &W, const int I)
 {
     const unsigned T = DL_END << 16;
     DH<NE> h;
     const v4u32 v = *(const LDS v4u32 *) p;
     h.e[0] = v.x; h.e[1] = v.y; h.e[2] = v.z; h.e[3] = v.w;
-    if (NE == 8) { const v4u32 w = *(const LDS v4u32 *) (p + 4); h.e[4] = w.x; h.e[5] = w.y; h.e[6] = w.z; h.e[7] = w.w; h.x = p[8]; }
+    if (NE == 8) {
+        const v4u32 w = *(const LDS v4u32 *) (p + 4); h.e[4] = w.x; h.e[5] = w.y; h.e[6] = w.z; h.e[7] = w.w;
+        h.x = T;
+        if (I > 8) h.x = p[8];
+        else { const bool lg = w.w < T && w.z < T; if (__ballot(lg)) { if (lg) h.x = ls6_rd(W, p, 8, I); } }
+    }
     else if (NE == 5) { const unsigned long long w = *(const LDS unsigned long long *) (p + 4); h.e[4] = (unsigned) w; h.x = (unsigned) (w >> 32); }
-    else if (NE == 6) { typedef unsigned v3u32 __attribute__((ext_vector_type(3))); const v3u32 w = *(const LDS v3u32 *) (p + 4); h.e[4] = w.x; h.e[5] = w.y; h.x = w.z; }
     else h.x = p[NE];
     V6_UNROLL
     for (int k = 2; k < NE; ++k) h.e[k] = (h.e[k - 1] >= T) ? T : h.e[k];
@@ -171,7 +181,7 @@ __device__ __forceinline__ void v6_incdelta(const bool on, const DH<NE> &h, lu32
         }
         if (!SCAN) {                                        // eight entries: the terminator sits behind the head
             const bool m8 = on && h.e[7] < T;
-            if (__ballot(m8)) { *(m8 ? d1 + 8 : sink16) = T; *((m8 && d2) ? d2 + 8 : sink16) = T; }
+            if (__ballot(m8)) { if (m8) { ls6_wr(W, d1, 8, I, T); if (d2) ls6_wr(W, d2, 8, I, T); } }
         }
     }
     if (SCAN) {
@@ -208,10 +218,11 @@ __device__ __forceinline__ void nd6_step(ND6 &s, const DH<NE> &h, const int g, c
     s.tg = emit ? (unsigned) (g + 1) : s.tg;
     s.on = s.on && g >= 0;
 }
+template <int NE>
 __device__ __forceinline__ void nd6_fin(const ND6 &s, const bool was_on, lu32 *d1, lu32 *d2, lu32 *sink, const LS6 &W, const int I)
 {
     const unsigned e = (s.tg << 16) | s.tn;
-    if (__ballot(was_on && s.kd + 1 >= I)) {                // the last entry or the terminator of some lane lands beyond the inline part
+    if (NE > 5 && __ballot(was_on && s.kd + 1 >= I)) {                // the last entry or the terminator of some lane lands beyond the inline part
         if (was_on) {
             ls6_wr(W, d1, s.kd, I, e); ls6_wr(W, d1, s.kd + 1, I, DL_END << 16);
             if (d2) { ls6_wr(W, d2, s.kd, I, e); ls6_wr(W, d2, s.kd + 1, I, DL_END << 16); }
@@ -237,108 +248,53 @@ __device__ __forceinline__ SE6 se6_read(const Ring6 &r, const int idx)
     SE6 e; e.key = r.k[i]; e.f = r.f[i]; e.g = (int) (e.key >> 16); return e;
 }
 
-// The row's lists.  s (cf of the Y merges): registers, glen as lookup key ((g << 16) | 0xFFFF; slots behind the list: key 0xFFFF,
-// freq 0), at most NS entries.  t (df of the X merges, the list newdelta walks): LDS, compact -- entry k of the lane's list
-// is tk[at0 + k] / tf[at0 + k] for k < lt; TAs / TAt: the wave's longest s / t list.  The r view is not held: r = [head {glen 0,
-// freq rhf}, if present] + the t list with glen + 1 (DevSide::r_from_t).
-#define V6_NS 12
-#define V6_NC 6
-struct A6 { const unsigned (&sk)[V6_NS]; const lf64 *sf; const lu32 *tk; const lf64 *tf; double rhf; int ls, lt, as0, at0, TAs, TAt; };    // (sf[as0 + k]: the s entries' freqs, in LDS like the t list)
+// the row's static lists in registers: glen as lookup key ((g << 16) | 0xFFFF; slots behind the list: key 0xFFFF, freq 0) and freq;
+// ls / lt / lr: the lane's list lengths
+// The r view is not held: r = [head {glen 0, freq rhf}, if present] + the t list with glen + 1 (DevSide::r_from_t).
+template <int N> struct A6 { const unsigned (&sk)[N]; const double (&sf)[N]; const unsigned (&tk)[N]; const double (&tf)[N]; double rhf; int ls, lt; };
 // the lane's column: rings of its s and t lists, list starts (compact), lengths.  The r view has no ring: r = [head {glen 0, freq rhf}, if the
 // column has one (lenr > lent)] + the t entries with glen + 1 (DevSide::r_from_t, checked by the host); rhf comes from a per-column array
 struct B6 { Ring6 rs, rt; int os, ot, lens, lent, lenr; double rhf; };
-typedef DH<6> DHn;
-#define V6_STRA(key, h) dh_stretch<6, true>((key), (h), W, W.ia)        /* stretched by a record's a-side / b-side list */
-#define V6_STRB(key, h) dh_stretch<6, true>((key), (h), W, W.ib)
 
-// The "X" merges: cf = the column's s list (ring, stretched by dlb of a record), df = a row list (LDS, stretched by dla of the same
-// record): newgap(b.s, dlb, a.t | a.r, dla) for the records hd (t view: the diagonal's second part), fl and hl (r view: horizontal
-// gnp / gop) and, with Noll 3, f2l.  The r view is an optional head entry {glen 0, freq rhf} followed by the t entries with
-// glen + 1 (rhf = 0: no head; its term is then +0), so ALL of them walk the row's t list: ONE loop reads an entry from LDS (the
-// next one is fetched while this one is worked on) and feeds every merge.  The column's entries are the same for all merges;
-// stretched by each record's b-side list once (NC registers per merge).  lmax: the wave's longest column s list; a term of a
-// lane whose list is shorter than the loop's index is +0.
-template <bool NOLL3>
-__device__ __forceinline__ void v6_xmerges(const lu32 *hdl, const lu32 *fll, const lu32 *hll, const lu32 *f2ll, const A6 &A, const B6 &B, const int lmax,
-                                           const LS6 &W, double &g_hd, double &g_fl, double &g_hl, double &g_f2)
+// one "X" merge: cf = the column's s list (ring, stretched by dlb of the record), df = a row list in registers (stretched by
+// dla): newgap(b.s, dlb, a.t|a.r, dla).  RV: df is the r view = an optional head entry {glen 0, freq hf} followed by the t
+// entries with glen + 1 (hf = 0: no head; its term is then +0).  lmax: the wave's longest s list.  Slots behind the row's
+// list hold key 0xFFFF / freq 0: their terms are +0 as well, so validity needs no test.
+template <int N, int NE, bool SCAN, bool RV>
+__device__ __forceinline__ double v6_xmerge(const DH<NE> &ha, const DH<NE> &hb, const unsigned (&dk)[N], const double (&dfq)[N], const double hf,
+                                            const int TA, const B6 &B, const int lmax, const LS6 &W)
 {
-    const int ca4 = W.ia;
-    g_hd = g_fl = g_hl = g_f2 = 0;
-    if (lmax <= V6_NC) {
-        unsigned i0[V6_NC], i1[V6_NC], i2[V6_NC], i3[V6_NC];
-        double fc[V6_NC];
-        {
-            const DHn b0 = dh_load6<6>(hdl + ca4), b1 = dh_load6<6>(fll + ca4), b2 = dh_load6<6>(hll + ca4), b3 = dh_load6<6>((NOLL3 ? f2ll : fll) + ca4);
-            V6_UNROLL
-            for (int c = 0; c < V6_NC; ++c) {
-                i0[c] = i1[c] = i2[c] = i3[c] = 0u; fc[c] = 0.;
-                if (c < lmax) {
-                    const bool valid = c < B.lens;
-                    const SE6 e = se6_read(B.rs, B.os + (valid ? c : 0));
-                    fc[c] = e.f;
-                    i0[c] = valid ? V6_STRB(e.key, b0) : 0u;      // (0 never reaches a stretched length: those are >= 0xFFFF)
-                    i1[c] = valid ? V6_STRB(e.key, b1) : 0u;
-                    i2[c] = valid ? V6_STRB(e.key, b2) : 0u;
-                    if (NOLL3) i3[c] = valid ? V6_STRB(e.key, b3) : 0u;
-                }
-            }
-        }
-        asm volatile("" ::: "memory");
-        const DHn a0 = dh_load6<6>(hdl), a1 = dh_load6<6>(fll), a2 = dh_load6<6>(hll), a3 = dh_load6<6>(NOLL3 ? f2ll : fll);
-#define V6_XCHAIN(S, ic, j) { V6_UNROLL for (int c = V6_NC - 1; c >= 0; --c) if (c < lmax) S = ic[c] >= (j) ? fc[c] : S; }
-        {   // the r view's head entry
-            const unsigned j1 = V6_STRA(0xFFFFu, a1), j2 = V6_STRA(0xFFFFu, a2), j3 = NOLL3 ? V6_STRA(0xFFFFu, a3) : 0u;
-            double S1 = 0, S2 = 0, S3 = 0;
-            V6_XCHAIN(S1, i1, j1) V6_XCHAIN(S2, i2, j2)
-            if (NOLL3) V6_XCHAIN(S3, i3, j3)
-            g_fl += S1 * A.rhf; g_hl += S2 * A.rhf;
-            if (NOLL3) g_f2 += S3 * A.rhf;
-        }
-        unsigned key = A.tk[A.at0];
-        double f = A.lt > 0 ? A.tf[A.at0] : 0.;
-        for (int d = 0; d < A.TAt; ++d) {
-            const bool nv = d + 1 < A.lt;                          // the next entry, fetched now
-            const int nat = A.at0 + (nv ? d + 1 : 0);
-            const unsigned nkey = A.tk[nat];
-            const double nf = nv ? A.tf[nat] : 0.;
-            const unsigned j0 = V6_STRA(key, a0), j1 = V6_STRA(key + 0x10000u, a1), j2 = V6_STRA(key + 0x10000u, a2);
-            const unsigned j3 = NOLL3 ? V6_STRA(key + 0x10000u, a3) : 0u;
-            double S0 = 0, S1 = 0, S2 = 0, S3 = 0;
-            V6_XCHAIN(S0, i0, j0) V6_XCHAIN(S1, i1, j1) V6_XCHAIN(S2, i2, j2)
-            if (NOLL3) V6_XCHAIN(S3, i3, j3)
-            g_hd += S0 * f; g_fl += S1 * f; g_hl += S2 * f;
-            if (NOLL3) g_f2 += S3 * f;
-            key = nkey; f = nf;
-        }
-#undef V6_XCHAIN
-    } else {                                                     // a column list longer than NC somewhere in the wave: both loops rolled
-        const DHn a0 = dh_load6<6>(hdl), a1 = dh_load6<6>(fll), a2 = dh_load6<6>(hll), a3 = dh_load6<6>(NOLL3 ? f2ll : fll);
-        const DHn b0 = dh_load6<6>(hdl + ca4), b1 = dh_load6<6>(fll + ca4), b2 = dh_load6<6>(hll + ca4), b3 = dh_load6<6>((NOLL3 ? f2ll : fll) + ca4);
-        for (int d = -1; d < A.TAt; ++d) {
-            const bool valid = d < A.lt;
-            const int at = A.at0 + ((valid && d >= 0) ? d : 0);
-            const unsigned key = d < 0 ? 0xFFFFu : A.tk[at];
-            const double f = d < 0 ? A.rhf : valid ? A.tf[at] : 0.;
-            const unsigned j0 = V6_STRA(key, a0), j1 = V6_STRA(d < 0 ? key : key + 0x10000u, a1), j2 = V6_STRA(d < 0 ? key : key + 0x10000u, a2);
-            const unsigned j3 = NOLL3 ? V6_STRA(d < 0 ? key : key + 0x10000u, a3) : 0u;
-            double S0 = 0, S1 = 0, S2 = 0, S3 = 0;
-            for (int kk = lmax - 1; kk >= 0; --kk) {
-                const bool cv = kk < B.lens;
-                const SE6 e = se6_read(B.rs, B.os + (cv ? kk : 0));
-                const unsigned x0 = cv ? V6_STRB(e.key, b0) : 0u, x1 = cv ? V6_STRB(e.key, b1) : 0u, x2 = cv ? V6_STRB(e.key, b2) : 0u;
-                S0 = x0 >= j0 ? e.f : S0; S1 = x1 >= j1 ? e.f : S1; S2 = x2 >= j2 ? e.f : S2;
-                if (NOLL3) { const unsigned x3 = cv ? V6_STRB(e.key, b3) : 0u; S3 = x3 >= j3 ? e.f : S3; }
-            }
-            if (d >= 0) g_hd += S0 * f;                              // (the t view has no head entry)
-            g_fl += S1 * f; g_hl += S2 * f;
-            if (NOLL3) g_f2 += S3 * f;
+    unsigned j[N], jh = 0;
+    double S[N], Sh = 0;
+    if (RV) jh = dh_stretch<NE, SCAN>(0xFFFFu, ha, W, W.ia);
+    V6_UNROLL
+    for (int d = 0; d < N; ++d) {
+        if (d < TA) {
+            j[d] = dh_stretch<NE, SCAN>(dk[d] + (RV ? 0x10000u : 0u), ha, W, W.ia);
+            S[d] = 0;
         }
     }
+    for (int kk = lmax - 1; kk >= 0; --kk) {
+        const bool valid = kk < B.lens;
+        const SE6 e = se6_read(B.rs, B.os + (valid ? kk : 0));
+        const unsigned i = valid ? dh_stretch<NE, SCAN>(e.key, hb, W, W.ib) : 0u;
+        if (RV) Sh = i >= jh ? e.f : Sh;
+        V6_UNROLL
+        for (int d = 0; d < N; ++d)
+            if (d < TA) S[d] = i >= j[d] ? e.f : S[d];
+    }
+    double g = 0;
+    if (RV) g += Sh * hf;
+    V6_UNROLL
+    for (int d = 0; d < N; ++d)
+        if (d < TA) g += S[d] * dfq[d];
+    return g;
 }
 
 // ---- one cell by one lane ----------------------------------------------------------------------------------
-template <bool NOLL3>
-__device__ __forceinline__ void v6_cell_pf(const DevProb &P, const LS6 &W, const A6 &A,
+// Returns false -- before anything is stored -- when !SCAN and some lane's list is longer than the heads of this instance.
+template <bool NOLL3, int N, int NE, bool SCAN>
+__device__ __forceinline__ bool v6_cell_pf(const DevProb &P, const LS6 &W, const A6<N> &A, const int TAs, const int TAt,
     const B6 &B, lu32 *sink, lu32 *sink16,
     const RS &hd, const lu32 *hdl, const RS &hu, const lu32 *hul, const RS &gu, const lu32 *gul,
     const RS &g2u, const lu32 *g2ul, const RS &hl, const lu32 *hll, const RS &fl, const lu32 *fll,
@@ -347,7 +303,24 @@ __device__ __forceinline__ void v6_cell_pf(const DevProb &P, const LS6 &W, const
     const bool do_vert, const bool do_hori, const double dab, const double pua, const double pub,
     RS &oH, RS &oG, RS &oG2, RS &oF, RS &oF2, int &trb V6_STAMP_ARGS)
 {
+    typedef DH<NE> DHn;
     const int ca4 = W.ia;                                   // a record's b-side list follows its a-side list's inline part
+    // heads of the dynamic lists of the five (seven) records this cell reads: a side and b side
+    const DHn a_hd = dh_load6<NE>(hdl, W, W.ia), b_hd = dh_load6<NE>(hdl + ca4, W, W.ib);
+    const DHn a_gu = dh_load6<NE>(gul, W, W.ia), b_gu = dh_load6<NE>(gul + ca4, W, W.ib);
+    const DHn a_hu = dh_load6<NE>(hul, W, W.ia), b_hu = dh_load6<NE>(hul + ca4, W, W.ib);
+    const DHn a_fl = dh_load6<NE>(fll, W, W.ia), b_fl = dh_load6<NE>(fll + ca4, W, W.ib);
+    const DHn a_hl = dh_load6<NE>(hll, W, W.ia), b_hl = dh_load6<NE>(hll + ca4, W, W.ib);
+    const DHn a_g2 = dh_load6<NE>(NOLL3 ? g2ul : gul, W, W.ia), b_g2 = dh_load6<NE>((NOLL3 ? g2ul : gul) + ca4, W, W.ib);
+    const DHn a_f2 = dh_load6<NE>(NOLL3 ? f2ll : fll, W, W.ia), b_f2 = dh_load6<NE>((NOLL3 ? f2ll : fll) + ca4, W, W.ib);
+    if (!SCAN) {
+        const unsigned T = DL_END << 16;
+        unsigned mn = a_hd.x < b_hd.x ? a_hd.x : b_hd.x;
+        mn = a_gu.x < mn ? a_gu.x : mn; mn = b_gu.x < mn ? b_gu.x : mn; mn = a_hu.x < mn ? a_hu.x : mn; mn = b_hu.x < mn ? b_hu.x : mn;
+        mn = a_fl.x < mn ? a_fl.x : mn; mn = b_fl.x < mn ? b_fl.x : mn; mn = a_hl.x < mn ? a_hl.x : mn; mn = b_hl.x < mn ? b_hl.x : mn;
+        if (NOLL3) { mn = a_g2.x < mn ? a_g2.x : mn; mn = b_g2.x < mn ? b_g2.x : mn; mn = a_f2.x < mn ? a_f2.x : mn; mn = b_f2.x < mn ? b_f2.x : mn; }
+        if (__ballot(mn < T)) { V6_STAMP(8) return false; }
+    }
     V6_STAMP(1)
     Costs c;
     c.d0 = c.d1 = c.gnpv = c.gopv = c.gnph = c.goph = c.gnpv2 = c.gnph2 = 0;
@@ -355,59 +328,48 @@ __device__ __forceinline__ void v6_cell_pf(const DevProb &P, const LS6 &W, const
     // ---- "Y" merges: cf = the row's s list (registers), df = a column list (ring): diagonal part 0 (b.t, record hd),
     // vertical gnp / gop (b.r, records gu / hu), vertical2 (b.r, g2u) -- gfreq.cc:507-521 in rank form
     {
-        unsigned i_hd[V6_NS], i_gu[V6_NS], i_hu[V6_NS], i_g2[V6_NS];          // stretched keys
+        unsigned i_hd[N], i_gu[N], i_hu[N], i_g2[N];          // stretched keys
         unsigned m_hd = 0, m_gu = 0, m_hu = 0, m_g2 = 0;
-        {   // (the a-side heads live only while the row's keys are stretched; the b-side heads are read after that)
-            const DHn a_hd = dh_load6<6>(hdl), a_gu = dh_load6<6>(gul), a_hu = dh_load6<6>(hul), a_g2 = dh_load6<6>(NOLL3 ? g2ul : gul);
-            V6_UNROLL
-            for (int k = 0; k < V6_NS; ++k) {
-                i_hd[k] = i_gu[k] = i_hu[k] = i_g2[k] = 0u;
-                if (k < A.TAs) {
-                    // (slots behind the list: key 0xFFFF, freq 0 -- a hit there selects freq 0, which is what an exhausted cf adds)
-                    const unsigned key = A.sk[k];
-                    i_hd[k] = V6_STRA(key, a_hd);
-                    i_gu[k] = V6_STRA(key, a_gu);
-                    i_hu[k] = V6_STRA(key, a_hu);
-                    if (NOLL3) i_g2[k] = V6_STRA(key, a_g2);
-                    m_hd = i_hd[k] > m_hd ? i_hd[k] : m_hd;
-                    m_gu = i_gu[k] > m_gu ? i_gu[k] : m_gu;
-                    m_hu = i_hu[k] > m_hu ? i_hu[k] : m_hu;
-                    if (NOLL3) m_g2 = i_g2[k] > m_g2 ? i_g2[k] : m_g2;
-                }
+        V6_UNROLL
+        for (int k = 0; k < N; ++k) {
+            if (k < TAs) {
+                // (slots behind the list: key 0xFFFF, freq 0 -- a hit there selects freq 0, which is what an exhausted cf adds)
+                const unsigned key = A.sk[k];
+                i_hd[k] = dh_stretch<NE, SCAN>(key, a_hd, W, W.ia);
+                i_gu[k] = dh_stretch<NE, SCAN>(key, a_gu, W, W.ia);
+                i_hu[k] = dh_stretch<NE, SCAN>(key, a_hu, W, W.ia);
+                if (NOLL3) i_g2[k] = dh_stretch<NE, SCAN>(key, a_g2, W, W.ia);
+                m_hd = i_hd[k] > m_hd ? i_hd[k] : m_hd;
+                m_gu = i_gu[k] > m_gu ? i_gu[k] : m_gu;
+                m_hu = i_hu[k] > m_hu ? i_hu[k] : m_hu;
+                if (NOLL3) m_g2 = i_g2[k] > m_g2 ? i_g2[k] : m_g2;
             }
         }
-        asm volatile("" ::: "memory");
-        const DHn b_hd = dh_load6<6>(hdl + ca4), b_gu = dh_load6<6>(gul + ca4), b_hu = dh_load6<6>(hul + ca4), b_g2 = dh_load6<6>((NOLL3 ? g2ul : gul) + ca4);
         double g0 = 0, g1 = 0, g2 = 0, g3 = 0;
         bool l0 = true, l1 = do_vert, l2 = do_vert, l3 = do_vert && NOLL3;
-        const int rhas = B.lenr > B.lent ? 1 : 0;                                  // the column's r view starts with a head entry
-        SE6 et_n = se6_read(B.rt, B.ot), ert_n = et_n;                             // entry 0 of the t ring (= what d = 0 reads for both views)
         for (int d = 0; d < DL_GUARD; ++d) {
             if (wave_none(l0 || l1 || l2 || l3)) break;
-            const int dr = d - rhas;                                               // entry d of the r view: the head, or t entry d - 1 / d
-            const SE6 et = et_n, ert = ert_n;
-            et_n = se6_read(B.rt, B.ot + d + 1); ert_n = rhas ? et : et_n;                    // the next round's, fetched now (the r view lags one entry behind a head)
+            const int dr = d - (B.lenr > B.lent ? 1 : 0);                          // entry d of the r view: the head, or t entry d - 1 / d
+            const SE6 et = se6_read(B.rt, B.ot + d), ert = se6_read(B.rt, B.ot + (dr < 0 ? 0 : dr));
             SE6 er;
             er.key = dr < 0 ? 0xFFFFu : ert.key + 0x10000u; er.f = dr < 0 ? B.rhf : ert.f; er.g = (int) (er.key >> 16);
             l0 = l0 && d < B.lent;
             const bool lv = d < B.lenr;
             l1 = l1 && lv; l2 = l2 && lv; l3 = l3 && lv;
-            const unsigned j0 = V6_STRB(et.key, b_hd), j1 = V6_STRB(er.key, b_gu), j2 = V6_STRB(er.key, b_hu);
-            const unsigned j3 = NOLL3 ? V6_STRB(er.key, b_g2) : 0u;
+            const unsigned j0 = dh_stretch<NE, SCAN>(et.key, b_hd, W, W.ib), j1 = dh_stretch<NE, SCAN>(er.key, b_gu, W, W.ib), j2 = dh_stretch<NE, SCAN>(er.key, b_hu, W, W.ib);
+            const unsigned j3 = NOLL3 ? dh_stretch<NE, SCAN>(er.key, b_g2, W, W.ib) : 0u;
             l0 = l0 && m_hd >= j0; l1 = l1 && m_gu >= j1; l2 = l2 && m_hu >= j2; l3 = l3 && m_g2 >= j3;       // cf exhausted: break
-            // from the wave's last s entry down to entry 0 the chain keeps the INDEX of the lowest hit (a fall-through switch: the jump
-            // is wave-uniform); the entry's freq is then read from LDS -- a hit behind the lane's own list stands for "cf exhausted"
-            int K0 = -1, K1 = -1, K2 = -1, K3 = -1;
-#define V6_YCH(k) { K0 = i_hd[k] >= j0 ? (k) : K0; K1 = i_gu[k] >= j1 ? (k) : K1; K2 = i_hu[k] >= j2 ? (k) : K2; if (NOLL3) K3 = i_g2[k] >= j3 ? (k) : K3; }
-            switch (A.TAs) {
-            default: V6_YCH(11) case 11: V6_YCH(10) case 10: V6_YCH(9)
-            case 9: V6_YCH(8) case 8: V6_YCH(7) case 7: V6_YCH(6) case 6: V6_YCH(5) case 5: V6_YCH(4)
+            double S0 = 0, S1 = 0, S2 = 0, S3 = 0;
+            // from the wave's last s entry down to entry 0: a fall-through switch (a guarded unrolled loop is turned into
+            // selects over all N entries by the compiler; the jump is wave-uniform)
+#define V6_YCH(k) if (N > (k)) { S0 = i_hd[k] >= j0 ? A.sf[k] : S0; S1 = i_gu[k] >= j1 ? A.sf[k] : S1; S2 = i_hu[k] >= j2 ? A.sf[k] : S2; \
+                                 if (NOLL3) S3 = i_g2[k] >= j3 ? A.sf[k] : S3; }
+            switch (TAs) {
+            default: V6_YCH(15) case 15: V6_YCH(14) case 14: V6_YCH(13) case 13: V6_YCH(12) case 12: V6_YCH(11) case 11: V6_YCH(10)
+            case 10: V6_YCH(9) case 9: V6_YCH(8) case 8: V6_YCH(7) case 7: V6_YCH(6) case 6: V6_YCH(5) case 5: V6_YCH(4)
             case 4: V6_YCH(3) case 3: V6_YCH(2) case 2: V6_YCH(1) case 1: V6_YCH(0) case 0: ;
             }
 #undef V6_YCH
-#define V6_YSF(K) (((unsigned) (K) < (unsigned) A.ls) ? A.sf[A.as0 + (K)] : 0.)
-            const double S0 = V6_YSF(K0), S1 = V6_YSF(K1), S2 = V6_YSF(K2), S3 = NOLL3 ? V6_YSF(K3) : 0.;
-#undef V6_YSF
             g0 = l0 ? g0 + S0 * et.f : g0;
             g1 = l1 ? g1 + S1 * er.f : g1;
             g2 = l2 ? g2 + S2 * er.f : g2;
@@ -422,9 +384,10 @@ __device__ __forceinline__ void v6_cell_pf(const DevProb &P, const LS6 &W, const
     {
         int lmax = 0;
         while (__ballot(B.lens > lmax)) ++lmax;
-        double g_hd, g_fl, g_hl, g_f2;
-        v6_xmerges<NOLL3>(hdl, fll, hll, f2ll, A, B, lmax, W, g_hd, g_fl, g_hl, g_f2);
-        c.d1 = g_hd * P.basic_gop; c.gnph = g_fl * P.basic_gop; c.goph = g_hl * P.basic_gop; c.gnph2 = NOLL3 ? g_f2 * P.basic_gop : 0;
+        c.d1 = v6_xmerge<N, NE, SCAN, false>(a_hd, b_hd, A.tk, A.tf, 0., TAt, B, lmax, W) * P.basic_gop;
+        c.gnph = v6_xmerge<N, NE, SCAN, true>(a_fl, b_fl, A.tk, A.tf, A.rhf, TAt, B, lmax, W) * P.basic_gop;
+        c.goph = v6_xmerge<N, NE, SCAN, true>(a_hl, b_hl, A.tk, A.tf, A.rhf, TAt, B, lmax, W) * P.basic_gop;
+        c.gnph2 = NOLL3 ? v6_xmerge<N, NE, SCAN, true>(a_f2, b_f2, A.tk, A.tf, A.rhf, TAt, B, lmax, W) * P.basic_gop : 0;
     }
 #endif
     V6_STAMP(3)
@@ -432,68 +395,64 @@ __device__ __forceinline__ void v6_cell_pf(const DevProb &P, const LS6 &W, const
     const int win = d.win;
     V6_STAMP(4)
     // ---- list updates (update(), fwd2c.cc:216-231); the winner's lists are also the new H's -------------------
-    // Sources are read into heads BEFORE the destinations of the same side are written (the lane below reads this lane's
-    // lists of the previous step from the slots this step overwrites only in ITS next step).
     lu32 *const nul = (lu32 *) 0;
 #ifndef V6_SKIP_ND
     {   // a side: newdelta over a.t for G (G2) and a diagonal H; incdelta for F (F2)
-        const DHn h_gs = dh_load6<6>(d.g_from_h ? hul : gul), h_hd = dh_load6<6>(hdl), h_fi = dh_load6<6>(d.f_from_h ? hll : fll);
-        const DHn h_gs2 = dh_load6<6>(NOLL3 ? (d.g2_from_h ? hul : g2ul) : gul), h_fi2 = dh_load6<6>(NOLL3 ? (d.f2_from_h ? hll : f2ll) : fll);
+        const DHn h_gs = dh_sel6<NE>(d.g_from_h, a_hu, a_gu), h_gs2 = dh_sel6<NE>(d.g2_from_h, a_hu, a_g2);
         ND6 n_g = {0, 0, 0, do_vert}, n_h = {0, 0, 0, win == 0}, n_g2 = {0, 0, 0, do_vert && NOLL3};
         lu32 *const g_d2 = win == 1 ? dh : nul, *const g2_d2 = win == 2 ? dh : nul;
-        unsigned nkey = A.tk[A.at0];
-        for (int k = 0; k < A.TAt; ++k) {
-            if (wave_none(n_g.on || n_h.on || (NOLL3 && n_g2.on))) break;
-            const bool valid = k < A.lt;
-            const unsigned key = nkey;
-            nkey = A.tk[A.at0 + (k + 1 < A.lt ? k + 1 : 0)];                          // the next entry, fetched now
-            const int g = valid ? (int) (key >> 16) : -1;
-            if (__ballot(n_g.kd >= W.ia || n_h.kd >= W.ia || (NOLL3 && n_g2.kd >= W.ia))) {          // a result outgrows its inline part
-                nd6_step<6, true, true>(n_g, h_gs, g, key, dg, g_d2, sink, W, W.ia);
-                nd6_step<6, true, true>(n_h, h_hd, g, key, dh, nul, sink, W, W.ia);
-                if (NOLL3) nd6_step<6, true, true>(n_g2, h_gs2, g, key, dg2, g2_d2, sink, W, W.ia);
-            } else {
-                nd6_step<6, true, false>(n_g, h_gs, g, key, dg, g_d2, sink, W, W.ia);
-                nd6_step<6, true, false>(n_h, h_hd, g, key, dh, nul, sink, W, W.ia);
-                if (NOLL3) nd6_step<6, true, false>(n_g2, h_gs2, g, key, dg2, g2_d2, sink, W, W.ia);
+        // (an instance with five-entry heads only runs on lists of five entries at most: nothing leaves the inline parts there)
+        V6_UNROLL
+        for (int k = 0; k < N; ++k) {
+            if (k < TAt) {
+                const int g = k < A.lt ? (int) (A.tk[k] >> 16) : -1;
+                if (NE > 5 && __ballot(n_g.kd >= W.ia || n_h.kd >= W.ia || (NOLL3 && n_g2.kd >= W.ia))) {      // a result outgrows its inline part
+                    nd6_step<NE, SCAN, true>(n_g, h_gs, g, A.tk[k], dg, g_d2, sink, W, W.ia);
+                    nd6_step<NE, SCAN, true>(n_h, a_hd, g, A.tk[k], dh, nul, sink, W, W.ia);
+                    if (NOLL3) nd6_step<NE, SCAN, true>(n_g2, h_gs2, g, A.tk[k], dg2, g2_d2, sink, W, W.ia);
+                } else {
+                    nd6_step<NE, SCAN, false>(n_g, h_gs, g, A.tk[k], dg, g_d2, sink, W, W.ia);
+                    nd6_step<NE, SCAN, false>(n_h, a_hd, g, A.tk[k], dh, nul, sink, W, W.ia);
+                    if (NOLL3) nd6_step<NE, SCAN, false>(n_g2, h_gs2, g, A.tk[k], dg2, g2_d2, sink, W, W.ia);
+                }
             }
         }
-        nd6_fin(n_g, do_vert, dg, g_d2, sink, W, W.ia);
-        nd6_fin(n_h, win == 0, dh, nul, sink, W, W.ia);
-        if (NOLL3) nd6_fin(n_g2, do_vert, dg2, g2_d2, sink, W, W.ia);
-        v6_incdelta<6, true>(do_hori, h_fi, df, win == 3 ? dh : nul, sink16, W, W.ia);
-        if (NOLL3) v6_incdelta<6, true>(do_hori, h_fi2, df2, win == 4 ? dh : nul, sink16, W, W.ia);
+        nd6_fin<NE>(n_g, do_vert, dg, g_d2, sink, W, W.ia);
+        nd6_fin<NE>(n_h, win == 0, dh, nul, sink, W, W.ia);
+        if (NOLL3) nd6_fin<NE>(n_g2, do_vert, dg2, g2_d2, sink, W, W.ia);
+        v6_incdelta<NE, SCAN>(do_hori, dh_sel6<NE>(d.f_from_h, a_hl, a_fl), df, win == 3 ? dh : nul, sink16, W, W.ia);
+        if (NOLL3) v6_incdelta<NE, SCAN>(do_hori, dh_sel6<NE>(d.f2_from_h, a_hl, a_f2), df2, win == 4 ? dh : nul, sink16, W, W.ia);
     }
     V6_STAMP(5)
     {   // b side: newdelta over b.t for F (F2) and a diagonal H; incdelta for G (G2)
-        const DHn h_fs = dh_load6<6>((d.f_from_h ? hll : fll) + ca4), h_hd = dh_load6<6>(hdl + ca4), h_gi = dh_load6<6>((d.g_from_h ? hul : gul) + ca4);
-        const DHn h_fs2 = dh_load6<6>((NOLL3 ? (d.f2_from_h ? hll : f2ll) : fll) + ca4), h_gi2 = dh_load6<6>((NOLL3 ? (d.g2_from_h ? hul : g2ul) : gul) + ca4);
+        const DHn h_fs = dh_sel6<NE>(d.f_from_h, b_hl, b_fl), h_fs2 = dh_sel6<NE>(d.f2_from_h, b_hl, b_f2);
         ND6 n_f = {0, 0, 0, do_hori}, n_h = {0, 0, 0, win == 0}, n_f2 = {0, 0, 0, do_hori && NOLL3};
         lu32 *const f_d2 = win == 3 ? dh + ca4 : nul, *const f2_d2 = win == 4 ? dh + ca4 : nul;
         for (int k = 0; k < DL_GUARD; ++k) {
             if (wave_none(n_f.on || n_h.on || (NOLL3 && n_f2.on))) break;
             const SE6 e = se6_read(B.rt, B.ot + k);
             const int g = k < B.lent ? e.g : -1;
-            if (__ballot(n_f.kd >= W.ib || n_h.kd >= W.ib || (NOLL3 && n_f2.kd >= W.ib))) {
-                nd6_step<6, true, true>(n_f, h_fs, g, e.key, df + ca4, f_d2, sink, W, W.ib);
-                nd6_step<6, true, true>(n_h, h_hd, g, e.key, dh + ca4, nul, sink, W, W.ib);
-                if (NOLL3) nd6_step<6, true, true>(n_f2, h_fs2, g, e.key, df2 + ca4, f2_d2, sink, W, W.ib);
+            if (NE > 5 && __ballot(n_f.kd >= W.ib || n_h.kd >= W.ib || (NOLL3 && n_f2.kd >= W.ib))) {
+                nd6_step<NE, SCAN, true>(n_f, h_fs, g, e.key, df + ca4, f_d2, sink, W, W.ib);
+                nd6_step<NE, SCAN, true>(n_h, b_hd, g, e.key, dh + ca4, nul, sink, W, W.ib);
+                if (NOLL3) nd6_step<NE, SCAN, true>(n_f2, h_fs2, g, e.key, df2 + ca4, f2_d2, sink, W, W.ib);
             } else {
-                nd6_step<6, true, false>(n_f, h_fs, g, e.key, df + ca4, f_d2, sink, W, W.ib);
-                nd6_step<6, true, false>(n_h, h_hd, g, e.key, dh + ca4, nul, sink, W, W.ib);
-                if (NOLL3) nd6_step<6, true, false>(n_f2, h_fs2, g, e.key, df2 + ca4, f2_d2, sink, W, W.ib);
+                nd6_step<NE, SCAN, false>(n_f, h_fs, g, e.key, df + ca4, f_d2, sink, W, W.ib);
+                nd6_step<NE, SCAN, false>(n_h, b_hd, g, e.key, dh + ca4, nul, sink, W, W.ib);
+                if (NOLL3) nd6_step<NE, SCAN, false>(n_f2, h_fs2, g, e.key, df2 + ca4, f2_d2, sink, W, W.ib);
             }
         }
-        nd6_fin(n_f, do_hori, df + ca4, f_d2, sink, W, W.ib);
-        nd6_fin(n_h, win == 0, dh + ca4, nul, sink, W, W.ib);
-        if (NOLL3) nd6_fin(n_f2, do_hori, df2 + ca4, f2_d2, sink, W, W.ib);
-        v6_incdelta<6, true>(do_vert, h_gi, dg + ca4, win == 1 ? dh + ca4 : nul, sink16, W, W.ib);
-        if (NOLL3) v6_incdelta<6, true>(do_vert, h_gi2, dg2 + ca4, win == 2 ? dh + ca4 : nul, sink16, W, W.ib);
+        nd6_fin<NE>(n_f, do_hori, df + ca4, f_d2, sink, W, W.ib);
+        nd6_fin<NE>(n_h, win == 0, dh + ca4, nul, sink, W, W.ib);
+        if (NOLL3) nd6_fin<NE>(n_f2, do_hori, df2 + ca4, f2_d2, sink, W, W.ib);
+        v6_incdelta<NE, SCAN>(do_vert, dh_sel6<NE>(d.g_from_h, b_hu, b_gu), dg + ca4, win == 1 ? dh + ca4 : nul, sink16, W, W.ib);
+        if (NOLL3) v6_incdelta<NE, SCAN>(do_vert, dh_sel6<NE>(d.g2_from_h, b_hu, b_g2), dg2 + ca4, win == 2 ? dh + ca4 : nul, sink16, W, W.ib);
     }
 #endif
     V6_STAMP(6)
     v3_outputs<2, NOLL3>(d, 0, 0, do_vert, do_hori, oH, oG, oG2, oF, oF2, trb);
     V6_STAMP(7)
+    return true;
 }
 
 // ---- one STRIP (64 rows x all columns) by one wave, pipelined behind the strip above on progress counters -----------
@@ -511,7 +470,7 @@ __device__ __forceinline__ void v6_cell_pf(const DevProb &P, const LS6 &W, const
 #define V6_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #define V6_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
 #endif
-template <bool NOLL3>
+template <bool NOLL3, int NA>
 __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const V6Lds LO, const int ti, const int nsteps,
                                          const int *prog_up, int *prog_self, int *dbg, const int pgen, const int pint, const int *prog_left,
                                          double *simscr, int *failp, unsigned *twin)
@@ -576,48 +535,25 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
         p[0] = 0; p[1] = DL_END << 16;
         p[ca4] = 0; p[ca4 + 1] = DL_END << 16;
     }
-    // ---- the row's static lists: s -> registers (at most NS entries on this path), t -> LDS in compact form (the lists of the
-    // strip's rows follow each other; the terminators are left out); the wave's longest list per view bounds the loops
-    unsigned a_sk[V6_NS];
-    double a_rhf = 0;
-    int ls = 0, lt = 0, at0 = 0, as0 = 0;
-    lu32 *const atk = (lu32 *) (lds + LO.atk);
-    lf64 *const atf = (lf64 *) (lds + LO.atf);
-    lf64 *const asf = (lf64 *) (lds + LO.asf);
+    // ---- the row's static lists -> registers; the wave's longest list per view bounds the unrolled loops
+    unsigned a_sk[NA], a_tk[NA];
+    double a_sf[NA], a_tf[NA], a_rhf = 0;
+    int ls = 0, lt = 0;
     {
-        V6_UNROLL for (int k = 0; k < V6_NS; ++k) a_sk[k] = 0xFFFFu;
-        if (row_ok) {
-            const GLB int *so = glb(a.off[0]);
-            const int sbase = so[m0 + 1] - (m0 + 1);
-            const int k0 = so[m + 1];
-            ls = so[m + 2] - k0 - 1;
-            if (ls > V6_NS) ls = V6_NS;                            // (never: the host sends rows with longer s lists elsewhere)
-            as0 = k0 - (m + 1) - sbase;
-            if (as0 + ls > LO.ascap) ls = LO.ascap > as0 ? LO.ascap - as0 : 0;      // (never: sized by the host)
-            const GLB int *sg = glb(a.glen[0]);
-            const GLB double *sfq = glb(a.freq[0]);
-            V6_UNROLL for (int k = 0; k < V6_NS; ++k) if (k < ls) a_sk[k] = v6_key(sg[k0 + k]);
-            for (int e = 0; e < ls; ++e) asf[as0 + e] = sfq[k0 + e];
-        }
-        if (row_ok) {
-            const GLB int *to = glb(a.off[1]);
-            const int tbase = to[m0 + 1] - (m0 + 1);               // compact position of the strip's first t entry
-            const int k0 = to[m + 1];
-            lt = to[m + 2] - k0 - 1;
-            at0 = k0 - (m + 1) - tbase;
-            if (at0 + lt > LO.atcap) lt = LO.atcap > at0 ? LO.atcap - at0 : 0;      // (never: the host sized the area for the strip with the most entries)
-            const GLB int *tg = glb(a.glen[1]);
-            const GLB double *tf = glb(a.freq[1]);
-            for (int e = 0; e < lt; ++e) { atk[at0 + e] = v6_key(tg[k0 + e]); atf[at0 + e] = tf[k0 + e]; }
-            // the r view's head entry, if any (glen 0; the t entries follow with glen + 1)
+        int g[NA];
+        rl_load(g, a_sf, a, 0, m, row_ok);
+        V6_UNROLL for (int k = 0; k < NA; ++k) { a_sk[k] = v6_key(g[k]); ls += g[k] >= 0; }
+        rl_load(g, a_tf, a, 1, m, row_ok);
+        V6_UNROLL for (int k = 0; k < NA; ++k) { a_tk[k] = v6_key(g[k]); lt += g[k] >= 0; }
+        if (row_ok) {                                      // the r view's head entry, if any (glen 0; the t entries follow with glen + 1)
             const int o = a.off[2][m + 1];
             if (a.off[2][m + 2] - o - 1 > lt) a_rhf = a.freq[2][o];
         }
     }
+    const A6<NA> A = {a_sk, a_sf, a_tk, a_tf, a_rhf, ls, lt};
     int TAs = 0, TAt = 0;
     while (__ballot(ls > TAs)) ++TAs;
     while (__ballot(lt > TAt)) ++TAt;
-    const A6 A = {a_sk, asf, atk, atf, a_rhf, ls, lt, as0, at0, TAs, TAt};
     // ---- the ring of the columns' static lists
     Ring6 ring[3];
 #pragma unroll
@@ -625,8 +561,8 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
     int fedcol = cbase - 1;                                // columns <= fedcol are in the ring
     lf64 *const rhring = (lf64 *) (lds + LO.ringf[2]);     // head freq of the r list of column c at [c & (V6_RHCOLS - 1)] (-1: no head)
     auto refill = [&](int upto) {                          // wave-uniform; lane <-> column, one view after the other (the view is a
-        if (upto > b.right - 1) upto = b.right - 1;        // compile-time index: a per-lane choice among the descriptor's fields would
-#pragma unroll                                             // turn its register copy into an indexed object in scratch memory)
+        if (upto > b.right - 1) upto = b.right - 1;        // compile-time index: a per-lane choice among the descriptor's fields
+#pragma unroll                                             // turns its register copy into an indexed object in scratch memory)
         for (int v = 0; v < 2; ++v) {
             const GLB int *bo = v == 0 ? boff0 : boff1;
             const GLB int *bgl = glb(b.glen[v]);
@@ -848,8 +784,8 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
             B6 B;
             B.rs = ring[0]; B.rt = ring[1];
             B.os = os_cur - (n + 1); B.ot = ot_cur - (n + 1);                                     // compact positions (see Ring6)
-            { const double hv = rhring[n & (V6_RHCOLS - 1)]; B.rhf = hv >= 0 ? hv : 0.; B.lenr = te_cur - ot_cur - 1 + (hv >= 0 ? 1 : 0); }
             B.lens = oe_cur - os_cur - 1; B.lent = te_cur - ot_cur - 1;
+            { const double hv = rhring[n & (V6_RHCOLS - 1)]; B.rhf = hv >= 0 ? hv : 0.; B.lenr = B.lent + (hv >= 0 ? 1 : 0); }
             const bool up_in = do_vert && (n - (m - 1) <= P.up);          // cell (m-1, n) exists
             const bool left_in = (n - 1 - m >= P.lw);                      // cell (m, n-1) exists
             const RS bk = rs_black();
@@ -872,8 +808,13 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
             const double pua = a.nils ? unpa(P, m, n) : pua_row;
             const double pub = bc_cur * a_efq * -P.u;                       // unp1(bsi, asi), maln.h:185-187
             int trb = 0;
-            v6_cell_pf<NOLL3>(P, W, A, B, sink, sink16, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
-                              dh, dg, dg2, df, df2, do_vert, do_hori, sim_cur, pua, pub, myH, myG, myG2, oF, oF2, trb V6_STAMP_PASS);
+// three instances of the cell: heads of 5 entries, of 8, and 8 + scan (see dh_load6); the first that applies runs
+            if (!v6_cell_pf<NOLL3, NA, 5, false>(P, W, A, TAs, TAt, B, sink, sink16, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
+                                  dh, dg, dg2, df, df2, do_vert, do_hori, sim_cur, pua, pub, myH, myG, myG2, oF, oF2, trb V6_STAMP_PASS))
+                if (!v6_cell_pf<NOLL3, NA, 8, false>(P, W, A, TAs, TAt, B, sink, sink16, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
+                                  dh, dg, dg2, df, df2, do_vert, do_hori, sim_cur, pua, pub, myH, myG, myG2, oF, oF2, trb V6_STAMP_PASS))
+                    v6_cell_pf<NOLL3, NA, 8, true>(P, W, A, TAs, TAt, B, sink, sink16, hd, hdl, s_hu, hul, s_gu, gul, s_g2u, g2ul, s_hl, hll, s_fl, fll, s_f2l, f2ll,
+                                  dh, dg, dg2, df, df2, do_vert, do_hori, sim_cur, pua, pub, myH, myG, myG2, oF, oF2, trb V6_STAMP_PASS);
             const int d = m + n;
             int mlo, mhi;
             diag_rows(d, a.left, a.right, b.left, b.right, P.lw, P.up, &mlo, &mhi);
@@ -899,7 +840,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
 #undef V6_L
 }
 
-#define V6_KERNEL(NAME, N3, WPE)                                                                 \
+#define V6_KERNEL(NAME, N3, NA, WPE)                                                                 \
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))      \
 NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V6Lds LO, int pint, int pro_off, double *simscr, unsigned *twin, int twin_dw) \
 {                                                                                                   \
@@ -930,21 +871,21 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         const int *pl = T.dep_left >= 0 ? done + T.dep_left : (const int *) 0;                      \
         const int *pu = T.dep_up >= 0 ? done + T.dep_up : (const int *) 0;                          \
         __syncthreads();                                                                            \
-        v6_strip<N3>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, T.nsteps, pu, done + T.self, done + G2G_HDR, gen, pint, pl, \
+        v6_strip<N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, T.nsteps, pu, done + T.self, done + G2G_HDR, gen, pint, pl, \
                          simscr + (size_t) blockIdx.x * (3 * 4096), failp, twin + (size_t) blockIdx.x * twin_dw); \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
     }                                                                                               \
 }
 #ifndef G2G_V6_NA
-#define G2G_V6_NA 16                    /* the row's t lists: longest list (terminator included) this path takes */
+#define G2G_V6_NA 16
 #endif
-#ifndef G2G_V6_WPE
-#define G2G_V6_WPE 2                    /* waves per SIMD the register allocation aims at */
+#ifndef G2G_V6_NA3
+#define G2G_V6_NA3 10                   /* Noll 3: two more records per cell -- with 16-entry row lists the kernel would spill 94 registers */
 #endif
 #ifdef G2G_TU_V6
-V6_KERNEL(g2g_v6_pf2, false, G2G_V6_WPE)
-V6_KERNEL(g2g_v6_pf3, true, 1)                   // (Noll 3: two more records per cell; at two waves per SIMD it would spill 38 registers)
+V6_KERNEL(g2g_v6_pf2, false, G2G_V6_NA, 1)
+V6_KERNEL(g2g_v6_pf3, true, G2G_V6_NA3, 1)
 #else
 #define V6_KERNEL_DECL(NAME) extern "C" __global__ void NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *done, int gen, V6Lds LO, int pint, int pro_off, double *simscr, unsigned *twin, int twin_dw);
 V6_KERNEL_DECL(g2g_v6_pf2) V6_KERNEL_DECL(g2g_v6_pf3)

@@ -113,6 +113,7 @@ def test_injected_stall_costs_one_dp_and_is_recovered(ctx, monkeypatch):
     assert len(ds) >= 4
     hs = [_abi.problem_from_arrays(d) for d in ds]
     for victim in (0, 2):
+        before = ctx.counters()
         ctx.set_option("INJECT_STALL", victim)
         ctx.set_option("WAIT_LIMIT_MS", 300)
         t0 = time.time()
@@ -123,8 +124,34 @@ def test_injected_stall_costs_one_dp_and_is_recovered(ctx, monkeypatch):
         assert 0.25 < dt < 20, dt                      # it did wait for the limit, and for not much longer
         for d, (scr, cells, tr, st) in zip(ds, res):
             assert st == 0 and scr == d["scr"][0] and np.array_equal(tr, d["vmf_trace"])
+        # the event is VISIBLE: the context counts the waits that gave up and the DP that was re-run (g2g_ctx_counters; bench.py
+        # and g2g_refine report the same counters for every ordinary run, where they must be zero)
+        after = ctx.counters()
+        assert after["wait_timeouts"] > before["wait_timeouts"] and after["recovered_dps"] == before["recovered_dps"] + 1
+    quiet = ctx.counters()
     res = ctx.forward_batch(hs)                        # and the context is fine afterwards
     assert all(st == 0 and scr == d["scr"][0] for d, (scr, cells, tr, st) in zip(ds, res))
+    now = ctx.counters()
+    assert now["wait_timeouts"] == quiet["wait_timeouts"] and now["recovered_dps"] == quiet["recovered_dps"] and now["runs"] == quiet["runs"] + 1
+
+
+def test_cu_shares_do_not_change_results(ctx):
+    """Option CU_SHARES: 2 forces a share of the CUs per persistent launch (hipExtStreamCreateWithCUMask) even on a run that does
+    not fill the machine, 0 turns the shares off; the default decides by the run's size.  Same bits either way."""
+    import glob, os
+    from prrn_aln_amd import _abi
+    gold = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    ds = [dict(np.load(f)) for f in gold]
+    hs = [_abi.problem_from_arrays(d) for d in ds]
+    for mode in ("2", "0"):
+        ctx.set_option("CU_SHARES", mode)
+        ctx.set_option("V6_MIN_STRIPS", 0)
+        try:
+            res = ctx.forward_batch(hs)
+        finally:
+            ctx.reset_options()
+        for f, d, (scr, cells, tr, st) in zip(gold, ds, res):
+            assert st == 0 and scr == d["scr"][0] and np.array_equal(tr, d["vmf_trace"]), (mode, os.path.basename(f))
 
 
 def test_context_options(ctx, monkeypatch):
