@@ -204,9 +204,8 @@ def refinement_readout(ctx, args):
     refine_native(ctx, start, tree, ralp, seed=1, maxitr=1, window=2) if not use_big else None      # (warm: first use of the small-batch paths)
     c0 = ctx.counters()
     t1 = time.perf_counter()
-    # a window of speculative divisions costs one DP latency whatever its size while the GPU has room: the big family starts
-    # every window at 8 divisions (one in six is accepted), the small one at 2
-    final, rsteps, rstats = refine_native(ctx, start, tree, ralp, seed=1, maxitr=10, window=16, window_min=8 if use_big else 2)
+    # (g2g_refine starts every window of the big family at 8 speculative divisions, of the small one at 2: g2g_refine.cpp)
+    final, rsteps, rstats = refine_native(ctx, start, tree, ralp, seed=1, maxitr=10, window=16)
     rt = time.perf_counter() - t1
     c1 = ctx.counters()
     want = op.encode(f["final_rows"], f["molc"])

@@ -312,7 +312,8 @@ typedef struct g2g_refine_opts {
     void   *scorer_user;
     g2g_accept_fn on_accept;        /* optional: told about every accepted move, in order (what synthgap applies, src/prrn5.cc:536-541) */
     void   *on_accept_user;
-    int32_t window_min, reserved;   /* window after an accepted move (default 2); it doubles up to `window` while nothing is accepted */
+    int32_t window_min, reserved;   /* window after an accepted move (default: 8 for MSAs of 2048 columns or more, else 2); it doubles up
+                                       to `window` while nothing is accepted */
 } g2g_refine_opts;
 typedef struct g2g_refine_step {
     int32_t branch, na, nb, swp, accepted, skipped;   /* skipped: neither group had a column to drop -- no DP (prrn5.cc:497) */

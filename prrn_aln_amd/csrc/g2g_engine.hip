@@ -1104,7 +1104,8 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                 if (cnt) { ++nl; tot += work[v]; demand += (double) cnt / wpc_of(v); }
             }
             const char *opt = g2g_opt(ctx, "CU_SHARES");
-            const bool want = opt ? atoi(opt) != 0 : true;
+            const bool want = opt ? atoi(opt) != 0 : false;      // off by default: a launch bound by its DPs' critical path needs many CUs for a
+                                                                // short time, and a static share leaves them idle afterwards
             const bool force = opt && atoi(opt) >= 2;           // (test switch: shares even for a run that does not fill the machine)
             // only a run that fills the machine more than twice over is partitioned, and only if every launch can have a unit
             if (want && ncu == 256 && nl >= 2 && nl <= 16 && (force || demand >= 2.0 * ncu) && tot > 0 && !g2g_opt(ctx, "DEBUG")) {      // (256 CUs in 8 XCDs: the mask layout the shares are written for)

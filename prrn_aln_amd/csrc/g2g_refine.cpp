@@ -254,7 +254,10 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
     if (O.seed == 0) O.seed = 1;
     if (O.maxitr <= 0) O.maxitr = 10;
     if (O.window <= 0) O.window = 32;
-    if (O.window_min <= 0) O.window_min = 2;
+    // The first window after an accepted move.  A window costs ONE DP latency whatever its size while the GPU has room (a 5e6-cell
+    // DP takes 50-90 ms alone and sixteen of them take 60-100 ms together: a DP is a chain of rows + columns dependent steps), so
+    // with large DPs it pays to start wide and throw the speculation behind an acceptance away; small DPs start at 2.
+    if (O.window_min <= 0) O.window_min = (long long) len * len >= (1LL << 22) ? 8 : 2;
     if (O.window_min > O.window) O.window_min = O.window;
     if (O.world <= 0) { O.world = 1; O.rank = 0; }
     if (O.slot_cap <= 0) O.slot_cap = 4096;

@@ -127,7 +127,11 @@ def test_injected_stall_costs_one_dp_and_is_recovered(ctx, monkeypatch):
         # the event is VISIBLE: the context counts the waits that gave up and the DP that was re-run (g2g_ctx_counters; bench.py
         # and g2g_refine report the same counters for every ordinary run, where they must be zero)
         after = ctx.counters()
-        assert after["wait_timeouts"] > before["wait_timeouts"] and after["recovered_dps"] == before["recovered_dps"] + 1
+        # (victim 0 is also DP 0 of the one-DP retry batch, where the hook fires again: that DP is counted twice, the second
+        # time as a DP that needed the non-polling kernel)
+        assert after["wait_timeouts"] > before["wait_timeouts"]
+        assert after["recovered_dps"] - before["recovered_dps"] == (2 if victim == 0 else 1)
+        assert after["recovered_on_v1"] - before["recovered_on_v1"] == (1 if victim == 0 else 0)
     quiet = ctx.counters()
     res = ctx.forward_batch(hs)                        # and the context is fine afterwards
     assert all(st == 0 and scr == d["scr"][0] for d, (scr, cells, tr, st) in zip(ds, res))
