@@ -110,3 +110,40 @@ def test_dna_ls3_4096nt_divisions_vs_oracle(ctx):
     assert all(pw.problem.noll == 3 and pw.problem.codonk1 == 21 for pw in pwds)
     assert max(_maxlist(pw.problem) for pw in pwds) > 16
     _check_vs_oracle(ctx, pwds)
+
+
+def test_dna_ls3_resident_sweep_properties_and_sampled_parity(ctx):
+    """BASELINE configs[4] as far as ONE GPU goes: a whole randiv sweep of a DNA family under the double-affine penalty (-yl3:
+    Noll 3 kernels, codonk1 = 21) RESIDENT in HBM -- every tree-branch division of 160 sequences x 2048 nt in one batch (the full
+    2048 x 4096 nt sweep is 4093 such divisions sharded over 8 GPUs; unmeasured on hardware).  Size-independent properties on
+    EVERY division (a skeleton from (0, 0) to (ra, rb) made of diagonal and gap segments, the score of the sweep the same when
+    run again), oracle parity on a sample across the size range."""
+    n = 160
+    fam = make_family(n, 2048, 2, alphabet=DNA, indel=0.012, max_indel=8)
+    alp = op.AlnParam(ls=3, molc=op.DNA, max_code=17)
+    sw = sweep.Sweep(fam, alp, weighted=True)
+    assert len(sw) == 2 * n - 3 and all(pw.problem.noll == 3 for pw in sw.pwds)
+    assert {pw.alnmode for pw in sw.pwds} >= {9} and sw.cells.sum() > 2e9
+
+    class H:
+        def __init__(self, q): self.c = q
+    hs = [H(pw.problem) for pw in sw.pwds]
+    b = ctx.prepare(hs)                                   # inputs of all 317 divisions resident
+    b.run(); r1 = b.fetch()
+    b.run(); r2 = b.fetch()
+    assert b.recovery() == (0, 0, 0)
+    b.free()
+    from prrn_aln_amd import engine as eng
+    for pw, (scr, cells, tr, st), (scr2, _, tr2, st2) in zip(sw.pwds, r1, r2):
+        q = pw.problem
+        assert st == 0 and st2 == 0 and scr == scr2 and np.array_equal(tr, tr2) and np.isfinite(scr)
+        skl = eng.stdskl(tr)
+        assert tuple(skl[0]) == (q.a.left, q.b.left) and tuple(skl[-1]) == (q.a.right, q.b.right)
+        d = np.diff(skl, axis=0)
+        assert (d >= 0).all() and ((d[:, 0] == d[:, 1]) | (d[:, 0] == 0) | (d[:, 1] == 0)).all()
+    L = oraclelib.load()
+    order = list(sw.order)
+    for k in (order[0], order[len(order) // 2], order[-1]):
+        oscr, ocells, otr = oraclelib.forward(L, hs[k])
+        scr, cells, tr, st = r1[k]
+        assert scr == oscr and cells == ocells and np.array_equal(tr, otr), (k, sw.pwds[k].alnmode, scr, oscr)
