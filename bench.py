@@ -219,6 +219,7 @@ def refinement_readout(ctx, args):
            "wall_s": rt, "divisions_evaluated": rstats["divisions"], "align2_calls": len(dps), "accepted_moves": rstats["accepted"],
            "gpu_batches": rstats["batches"], "divisions_recomputed": rstats["divisions_wasted"],
            "wait_timeouts": int(c1["wait_timeouts"] - c0["wait_timeouts"]), "recovered_dps": int(c1["recovered_dps"] - c0["recovered_dps"]),
+           "last_timeout_report": (ctx.last_timeout()[:1500] if c1["recovered_dps"] > c0["recovered_dps"] else None),
            "same_branch_sequence_as_reference": [x["branch"] for x in rsteps] == f["branches"],
            "every_dp_score_and_fstat_val_equal_to_reference": bool(scr_same),
            "final_msa_identical_to_reference": same,

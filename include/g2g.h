@@ -186,6 +186,9 @@ size_t    g2g_batch_arena_bytes(const g2g_batch *b);
    run reports zeros. */
 void      g2g_batch_recovery(const g2g_batch *b, int *timeouts_last_run, int *recovered_last_run, int *recovered_total);
 void      g2g_ctx_counters(const g2g_ctx *ctx, long long out[4]);
+/* the report of the context's last recovered time-out (which DPs on which kernel, what the first waiting wave saw and where
+   its producer ran): "" if there was none; valid until the next event or g2g_destroy */
+const char *g2g_ctx_last_timeout(const g2g_ctx *ctx);
 void      g2g_batch_free(g2g_batch *b);
 
 /* stdskl(): sort + normalise a raw traceback into ascending unique corners (reference src/gaps.cc:139).

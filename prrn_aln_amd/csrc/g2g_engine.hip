@@ -3,6 +3,7 @@
 // No CPU fallback lives here: without a usable HIP device every entry point fails with G2G_ERR_NODEVICE.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
@@ -57,6 +58,7 @@ struct g2g_ctx {
     struct MStream { int lo, n; hipStream_t s; unsigned long long used; };
     std::vector<MStream> mstream;   // streams confined to a share of the CUs (units lo .. lo + n - 1 of 32; see cu_share_stream)
     unsigned long long mstamp;
+    std::string last_timeout;       // report of the last recovered time-out (g2g_ctx_last_timeout)
 };
 
 // Tuning and diagnostic switches belong to a context (g2g_set_option / g2g_get_option); a name a context has not set
@@ -1314,23 +1316,31 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             b->last_timeouts = rep[G2G_HDR]; b->last_recovered = (int) lost.size();
             ctx->n_timeouts += rep[G2G_HDR]; ctx->n_recovered += (long long) lost.size();
             if (b->is_retry) ctx->n_v1 += (long long) lost.size();
-            if (g2g_opt(ctx, "DEBUG") || g2g_opt(ctx, "WARN")) {
-                fprintf(stderr, "[g2g] s_memrealtime: %.0f ticks/ms; ", ctx->rt_ticks_per_ms);
-                fprintf(stderr, "[g2g] %d waits timed out (first: queue slot %d, gen %d): re-running %zu DP(s) %s:", rep[G2G_HDR], rep[G2G_HDR + 1], b->gen, lost.size(), b->is_retry ? "on g2g_forward_kernel" : "(first on the ordinary kernels)");
-                for (size_t k = 0; k < lost.size() && k < 12; ++k) fprintf(stderr, " %d(kernel %d, %d x %d)", lost[k], b->dp[lost[k]].v2_ok, b->dp[lost[k]].a.right - b->dp[lost[k]].a.left, b->dp[lost[k]].b.right - b->dp[lost[k]].b.left);
-                fprintf(stderr, "\n");
+            {   // the report of the event: kept in the context (g2g_ctx_last_timeout: every ordinary run that meets one carries the
+                // evidence), printed under WARN / DEBUG
+                char buf[2048];
+                int o = 0;
+                auto add = [&](const char *fmt, ...) { va_list ap; va_start(ap, fmt); if (o < (int) sizeof buf - 1) { const int w = vsnprintf(buf + o, sizeof buf - o, fmt, ap); if (w > 0) o += w; } va_end(ap); if (o > (int) sizeof buf - 1) o = (int) sizeof buf - 1; };
+                int kinds[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i : lost) { const int k = b->dp[i].v2_ok; if (k >= 0 && k < 10) ++kinds[k]; }
+                add("%d waits timed out (first: queue slot %d, gen %d, batch of %d DPs): re-running %zu DP(s) %s; by kernel (0 v1, 1 v2, 2 v3, 3 v3r, 6 v6, 7 v7, 8 v8):",
+                    rep[G2G_HDR], rep[G2G_HDR + 1], b->gen, b->n, lost.size(), b->is_retry ? "on g2g_forward_kernel" : "(first on the ordinary kernels)");
+                for (int k = 0; k < 10; ++k) if (kinds[k]) add(" %d x kernel %d", kinds[k], k);
+                add("; the first:");
+                for (size_t k = 0; k < lost.size() && k < 6; ++k) add(" %d(kernel %d, %d x %d)", lost[k], b->dp[lost[k]].v2_ok, b->dp[lost[k]].a.right - b->dp[lost[k]].a.left, b->dp[lost[k]].b.right - b->dp[lost[k]].b.left);
                 const int *x = rep + G2G_HDR;                 // the first time-out's snapshot (g2g_wait_ge)
-                fprintf(stderr, "[g2g] first time-out: DP %d, wanted gen %d col %d of word %d, saw gen %d col %d; the words at and below it (gen:col):",
-                        x[7] - b->fail_off, (x[4] >> 20) & 0x7FF, x[4] & 0xFFFFF, x[6], (x[5] >> 20) & 0x7FF, x[5] & 0xFFFFF);
-                for (int k = 0; k < 8; ++k) fprintf(stderr, " %d:%d", (x[8 + k] >> 20) & 0x7FF, x[8 + k] & 0xFFFFF);
-                if (x[16] == 0x7fffffff || (x[16] == 0 && x[17] == 0)) fprintf(stderr, "; no heartbeat (build with G2G_EXTRA_FLAGS=-DG2G_V6_HEARTBEAT to have the v6 strips keep one)");
-                else fprintf(stderr, "; producer's heartbeat: step %d place %d, 50 us later step %d place %d", x[16], x[17], x[18], x[19]);
-                fprintf(stderr, "; producer HW_ID %08x XCC %d, waiter HW_ID %08x XCC %d; waiters per XCC:", x[20], x[21] & 15, x[22], x[23] & 15);
-                for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", x[24 + k] / 64);
-                fprintf(stderr, "; their producers per XCC:");
-                for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", x[32 + k] / 64);
-                fprintf(stderr, "; by RMW %d:%d, loaded again %d:%d", (x[46] >> 20) & 0x7FF, x[46] & 0xFFFFF, (x[47] >> 20) & 0x7FF, x[47] & 0xFFFFF);
-                fprintf(stderr, "\n"); fflush(stderr);
+                add(". First time-out: DP %d, wanted gen %d col %d of word %d, saw gen %d col %d; the words at and below it (gen:col):",
+                    x[7] - b->fail_off, (x[4] >> 20) & 0x7FF, x[4] & 0xFFFFF, x[6], (x[5] >> 20) & 0x7FF, x[5] & 0xFFFFF);
+                for (int k = 0; k < 8; ++k) add(" %d:%d", (x[8 + k] >> 20) & 0x7FF, x[8 + k] & 0xFFFFF);
+                if (!(x[16] == 0x7fffffff || (x[16] == 0 && x[17] == 0))) add("; producer's heartbeat: step %d place %d, 50 us later step %d place %d", x[16], x[17], x[18], x[19]);
+                add("; producer HW_ID %08x XCC %d, waiter HW_ID %08x XCC %d; waiters per XCC:", x[20], x[21] & 15, x[22], x[23] & 15);
+                for (int k = 0; k < 8; ++k) add(" %d", x[24 + k] / 64);
+                add("; their producers per XCC:");
+                for (int k = 0; k < 8; ++k) add(" %d", x[32 + k] / 64);
+                add("; by RMW %d:%d, loaded again %d:%d", (x[46] >> 20) & 0x7FF, x[46] & 0xFFFFF, (x[47] >> 20) & 0x7FF, x[47] & 0xFFFFF);
+                buf[o] = 0;
+                if (!b->is_retry || ctx->last_timeout.empty()) ctx->last_timeout = buf;
+                if (g2g_opt(ctx, "DEBUG") || g2g_opt(ctx, "WARN")) { fprintf(stderr, "[g2g] s_memrealtime: %.0f ticks/ms; %s\n", ctx->rt_ticks_per_ms, buf); fflush(stderr); }
             }
             if (b->force_v1 || lost.empty()) { g2g_set_error("%s", "scheduler: a wait timed out and no DP could be singled out"); return G2G_ERR_DEVICE; }
             std::vector<const g2g_problem *> pp;
@@ -1413,6 +1423,7 @@ extern "C" void g2g_batch_recovery(const g2g_batch *b, int *timeouts_last_run, i
     if (recovered_last_run) *recovered_last_run = b ? b->last_recovered : 0;
     if (recovered_total) *recovered_total = b ? b->n_recovered : 0;
 }
+extern "C" const char *g2g_ctx_last_timeout(const g2g_ctx *c) { return c ? c->last_timeout.c_str() : ""; }
 extern "C" void g2g_ctx_counters(const g2g_ctx *c, long long out[4])
 {
     if (!out) return;

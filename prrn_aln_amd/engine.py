@@ -44,6 +44,10 @@ class Context:
         lib().g2g_ctx_counters(self._h, out)
         return {"runs": out[0], "wait_timeouts": out[1], "recovered_dps": out[2], "recovered_on_v1": out[3]}
 
+    def last_timeout(self) -> str:
+        """g2g_ctx_last_timeout: the report of the last recovered time-out of the scheduler's waits ("" if none)"""
+        return lib().g2g_ctx_last_timeout(self._h).decode()
+
     def close(self):
         if self._h:
             lib().g2g_destroy(self._h)

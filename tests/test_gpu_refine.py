@@ -31,7 +31,7 @@ def test_native_refinement_walks_the_reference_trajectory(ctx, path):
     refinelib.check_against_trace(f, final, steps, stats)
     assert stats["batches"] < len(f["align2"])                          # the DPs really ran in batches
     # every run is evidence about the scheduler's waits: an ordinary run has none that gave up
-    print("wait_timeouts %d, recovered_dps %d" % (stats["wait_timeouts"], stats["recovered_dps"]))
+    print("wait_timeouts %d, recovered_dps %d %s" % (stats["wait_timeouts"], stats["recovered_dps"], ctx.last_timeout() if stats["recovered_dps"] else ""))
 
 
 def _native_rank(rank, world, port, path, q):
