@@ -189,6 +189,10 @@ void      g2g_ctx_counters(const g2g_ctx *ctx, long long out[4]);
 /* the report of the context's last recovered time-out (which DPs on which kernel, what the first waiting wave saw and where
    its producer ran): "" if there was none; valid until the next event or g2g_destroy */
 const char *g2g_ctx_last_timeout(const g2g_ctx *ctx);
+/* The waits count the time the waiting wave itself was running: a wave that finds more than 4 ms between two looks at the clock
+   was off the machine (with, as a rule, the rest of its kernel) and counts 4 ms of it.  count = such gaps seen by waiting
+   waves since g2g_create, longest_ms = the longest: zeros on an undisturbed device. */
+void      g2g_ctx_wait_gaps(const g2g_ctx *ctx, long long *count, double *longest_ms);
 void      g2g_batch_free(g2g_batch *b);
 
 /* stdskl(): sort + normalise a raw traceback into ascending unique corners (reference src/gaps.cc:139).

@@ -50,6 +50,7 @@ struct g2g_ctx {
     hipEvent_t ev[4];
     hipEvent_t vev[G2G_NVS + 1];    // join events of those streams; [G2G_NVS]: the fork event
     char *stage; size_t stage_cap;  // pinned host staging buffer of g2g_batch_prepare, kept between calls
+    long long n_gaps; double max_gap_ms;   // waiters that found themselves off the machine for more than 4 ms between two looks at the clock (g2g_wait_ge), longest such gap
     double rt_ticks_per_ms;         // rate of s_memrealtime on this device, measured at g2g_create (the waits' time limit is wall clock)
     std::map<std::string, std::pair<bool, std::string>> opt;   // g2g_set_option: name -> (present, value); see g2g_opt
     char *spare; size_t spare_bytes; // one device arena kept from the last freed batch (hipMalloc/hipFree of tens of GB per
@@ -118,6 +119,7 @@ extern "C" g2g_ctx *g2g_create(int device)
     c->stage = 0; c->stage_cap = 0;
     c->spare = 0; c->spare_bytes = 0;
     c->n_runs = c->n_timeouts = c->n_recovered = c->n_v1 = 0;
+    c->n_gaps = 0; c->max_gap_ms = 0;
     c->mstamp = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; g2g_set_error("%s", "stream"); return NULL; }
     for (int i = 0; i < 4; ++i) hipEventCreate(&c->ev[i]);
@@ -1306,6 +1308,12 @@ extern "C" int g2g_batch_run(g2g_batch *b)
     if (b->d_flags) {
         int rep[G2G_HDR + G2G_HDRN];
         HIPCHK(hipMemcpy(rep, b->d_flags, sizeof rep, hipMemcpyDeviceToHost));
+        if (rep[G2G_HDR + 40]) {             // waves that were off the machine while they waited: evidence, not an error
+            const double gap_ms = rep[G2G_HDR + 41] * 1024. / ctx->rt_ticks_per_ms;
+            ctx->n_gaps += rep[G2G_HDR + 40];
+            if (gap_ms > ctx->max_gap_ms) ctx->max_gap_ms = gap_ms;
+            if (g2g_opt(ctx, "DEBUG") || g2g_opt(ctx, "WARN")) { fprintf(stderr, "[g2g] %d waiting wave(s) were off the machine for more than 4 ms at a stretch (longest %.1f ms); batch of %d DPs, %d wait(s) lost\n", rep[G2G_HDR + 40], gap_ms, b->n, rep[G2G_HDR]); fflush(stderr); }
+        }
         if (rep[G2G_HDR]) {
             // Some wait ran into the wall-clock limit.  Only the DPs marked in the fail array are lost; they are re-run here, in
             // the same call, on the kernel that polls nothing (one workgroup per DP, state in HBM).
@@ -1338,6 +1346,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                 add("; their producers per XCC:");
                 for (int k = 0; k < 8; ++k) add(" %d", x[32 + k] / 64);
                 add("; by RMW %d:%d, loaded again %d:%d", (x[46] >> 20) & 0x7FF, x[46] & 0xFFFFF, (x[47] >> 20) & 0x7FF, x[47] & 0xFFFFF);
+                add("; waiting waves off the machine for > 4 ms at a stretch in this run: %d (longest %.1f ms)", x[40], x[41] * 1024. / ctx->rt_ticks_per_ms);
                 buf[o] = 0;
                 if (!b->is_retry || ctx->last_timeout.empty()) ctx->last_timeout = buf;
                 if (g2g_opt(ctx, "DEBUG") || g2g_opt(ctx, "WARN")) { fprintf(stderr, "[g2g] s_memrealtime: %.0f ticks/ms; %s\n", ctx->rt_ticks_per_ms, buf); fflush(stderr); }
@@ -1424,6 +1433,11 @@ extern "C" void g2g_batch_recovery(const g2g_batch *b, int *timeouts_last_run, i
     if (recovered_total) *recovered_total = b ? b->n_recovered : 0;
 }
 extern "C" const char *g2g_ctx_last_timeout(const g2g_ctx *c) { return c ? c->last_timeout.c_str() : ""; }
+extern "C" void g2g_ctx_wait_gaps(const g2g_ctx *c, long long *count, double *longest_ms)
+{
+    if (count) *count = c ? c->n_gaps : 0;
+    if (longest_ms) *longest_ms = c ? c->max_gap_ms : 0;
+}
 extern "C" void g2g_ctx_counters(const g2g_ctx *c, long long out[4])
 {
     if (!out) return;

@@ -42,12 +42,17 @@ __device__ unsigned long long g2g_stamp_acc[16];
 #define G2G_HDR 24                   // d_flags: [0, 24) queue heads of the kernel variants, [24, 28) this header, [28, 72) snapshot of the first time-out, tile flags behind
 #define G2G_FSTRIDE 32               // ints between two tile flags / progress words: one 128-byte line each, so that no two workgroups (in
                                      // different XCDs, behind different L2s) ever store into the same line
+#define G2G_GAP_TICKS 400000ull       // 4 ms of s_memrealtime: more than ten times what 64 polls take
 #define G2G_HDRN 48                  // header words: 4 + the snapshot (want, seen, offset of the polled word, the 40 words at and below it)
 __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hdr, int *failp, const int slot)
 {
     int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v >= want) return v;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    // The limit counts the time THIS wave was running: a gap of more than G2G_GAP_TICKS between two looks at the clock (64 polls:
+    // 0.3 ms when the wave runs) means the wave itself was off the machine -- and with it, as a rule, the rest of its kernel, the
+    // producer included -- so only G2G_GAP_TICKS of it count.  Gaps are counted in hdr[40] (longest, in units of 1024 ticks, in
+    // hdr[41]): the host reports them whether or not a wait was lost.
+    unsigned long long tl = __builtin_amdgcn_s_memrealtime(), run = 0;
     for (unsigned it = 1; ; ++it) {
         // back off: the first polls come 0.2 us apart, later ones 2-3 us with a phase that differs from wave to wave (hundreds of
         // waits per sweep last tens of ms -- strips pulled long before their producers get going: no point in hammering the fabric)
@@ -57,8 +62,16 @@ __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hd
         if (v >= want) return v;
         if ((it & 63) == 0) {
             if (__hip_atomic_load(failp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 0x7fffffff;      // this DP is lost already
-            const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
-            if ((dt >> 16) > (unsigned long long) (unsigned) __hip_atomic_load(hdr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            const unsigned long long tn = __builtin_amdgcn_s_memrealtime();
+            unsigned long long d = tn - tl;
+            tl = tn;
+            if (d > G2G_GAP_TICKS) {
+                atomicAdd(hdr + 40, 1);
+                atomicMax(hdr + 41, (int) (d >> 10 > 0x7fffffffull ? 0x7fffffffull : d >> 10));
+                d = G2G_GAP_TICKS;
+            }
+            run += d;
+            if ((run >> 16) > (unsigned long long) (unsigned) __hip_atomic_load(hdr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 __hip_atomic_store(failp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 {   // where the waves that gave up sit, and where their producers sit (v6 strips leave HW_ID / XCC_ID next to their progress word)
                     const int my_xcc = (int) __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15;

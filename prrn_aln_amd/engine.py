@@ -48,6 +48,12 @@ class Context:
         """g2g_ctx_last_timeout: the report of the last recovered time-out of the scheduler's waits ("" if none)"""
         return lib().g2g_ctx_last_timeout(self._h).decode()
 
+    def wait_gaps(self):
+        """g2g_ctx_wait_gaps: (gaps of more than 4 ms that waiting waves found in their own running time, the longest in ms)"""
+        n = C.c_longlong(); ms = C.c_double()
+        lib().g2g_ctx_wait_gaps(self._h, C.byref(n), C.byref(ms))
+        return n.value, ms.value
+
     def close(self):
         if self._h:
             lib().g2g_destroy(self._h)
