@@ -475,7 +475,7 @@ def main():
                        "arena_bytes_per_cell": (batch.arena_bytes() / my_cells) if (batch is not None and my_cells) else None},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "g2g_v3r_hf2 + g2g_v6_pf2 + g2g_v2_pf2 (persistent strip kernels incl. boundary chains and their own column scores, concurrent)", "kernel_ms": fwd_avg_ms, "traceback_ms": tb_ms / args.steps,
+                         "kernel": "g2g_v3r_hf2 + g2g_v6_pf2 (persistent strip kernels incl. boundary chains and their own column scores, concurrent)", "kernel_ms": fwd_avg_ms, "traceback_ms": tb_ms / args.steps,
                          "bytes_per_cell": BYTES_PER_CELL[noll], "cells_per_launch": my_cells},
         }
         if prog is not None:

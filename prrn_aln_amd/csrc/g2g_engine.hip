@@ -1178,12 +1178,12 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             int wpc2 = 2048 / T2;              // workgroups per CU the grid provides (LDS decides how many are resident)
             if (const char *e = g2g_opt(ctx, "V2_WPC")) { const int w = atoi(e); if (w >= 1 && w <= 32) wpc2 = w; }
             const int grid = std::min(cnt, ncu2 * wpc2);
-            // sweep mode: the kernel argument is the publish interval.  A DP's critical path is columns + strips x
-            // interval: 32 steps when the strips outnumber the resident workgroups several times over (throughput
-            // bound, fewer fences), 16 when they do not (a shard of a sweep: -8 % at 1/8 of the bench sweep), 4 when the
-            // strips fill less than a quarter of the chip (a handful of DPs: latency is all that counts, -10 %).
+            // sweep mode: the kernel argument is the publish interval.  A DP's critical path is columns + strips x (rows of a
+            // strip + interval): 32 steps when the strips outnumber the resident workgroups many times over (throughput bound,
+            // fewer fences), 8 / 4 when they do not (a window of g2g_refine: the batch is as slow as its longest pipeline; measured on
+            // batches of 1-16 full-size DPs with tools/latency_probe.py: 4 beats 16 by 14 % at 8 DPs, 2 gains nothing more).
             const int res2 = ncu2 * std::max(1, std::min(wpc2, (int) (V2_LDS_MAX / (b->lds2 + 4 * (size_t) T2))));
-            const int pint2 = !b->v2_sweep ? 0 : b->v2_sweep >= 2 ? b->v2_sweep : 4 * cnt <= res2 ? 4 : cnt < 4 * res2 ? 16 : 32;
+            const int pint2 = !b->v2_sweep ? 0 : b->v2_sweep >= 2 ? b->v2_sweep : cnt <= 2 * res2 ? 4 : cnt <= 4 * res2 ? 8 : 32;
             if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] variant %d: %d tiles, grid %d x %d threads, lds %zu, cols %d, gen %d\n", v, cnt, grid, T2, b->lds2, b->v2_cols, b->gen); fflush(stderr); }
             double *simscr2 = 0;
             if (b->v2_sweep && !g2g_opt(ctx, "NO_SIMBLK")) {
@@ -1223,7 +1223,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             hipLaunchKernelGGL(v3k[v], dim3(grid), dim3(64), (size_t) LO.total, vs,
                                (const DevProb *) b->d_probs, (const V2Tile *) (b->d_tiles + b->var_off[v + 4]), cnt,
                                b->d_flags + 4 + v, b->d_flags, b->gen, LO, (swpv && b->v3_sweep) ? (1 << 20) : b->v3_cols,
-                               !(swpv && b->v3_sweep) ? 0 : b->v3_sweep >= 2 ? b->v3_sweep : 4 * cnt <= ncu3 * std::min(wpc, 8) ? 4 : cnt < 4 * ncu3 * std::min(wpc, 8) ? 16 : 32,
+                               !(swpv && b->v3_sweep) ? 0 : b->v3_sweep >= 2 ? b->v3_sweep : cnt <= ncu3 * std::min(wpc, 8) ? 4 : cnt < 4 * ncu3 * std::min(wpc, 8) ? 16 : 32,
                                (pro_off && pro_off + (int) PRO_LDS_BYTES <= LO.svals) ? pro_off : 0, simscr3);
             HIPCHK(hipGetLastError());
             if (g2g_opt(ctx, "DEBUG")) { const auto t0 = std::chrono::steady_clock::now(); hipError_t e3 = hipStreamSynchronize(vs); fprintf(stderr, "[g2g] v3 variant %d done: %s, %.1f ms\n", v, hipGetErrorString(e3), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr); }
