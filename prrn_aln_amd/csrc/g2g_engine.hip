@@ -50,6 +50,7 @@ struct g2g_ctx {
     hipEvent_t ev[4];
     hipEvent_t vev[G2G_NVS + 1];    // join events of those streams; [G2G_NVS]: the fork event
     char *stage; size_t stage_cap;  // pinned host staging buffer of g2g_batch_prepare, kept between calls
+    void *sp_slots; size_t sp_slots_cap;   // g2g_batch_spscore: the slots of the streamed walks (kept between calls, grows)
     long long n_gaps; double max_gap_ms;   // waiters that found themselves off the machine for more than 4 ms between two looks at the clock (g2g_wait_ge), longest such gap
     double rt_ticks_per_ms;         // rate of s_memrealtime on this device, measured at g2g_create (the waits' time limit is wall clock)
     std::map<std::string, std::pair<bool, std::string>> opt;   // g2g_set_option: name -> (present, value); see g2g_opt
@@ -120,6 +121,7 @@ extern "C" g2g_ctx *g2g_create(int device)
     c->spare = 0; c->spare_bytes = 0;
     c->n_runs = c->n_timeouts = c->n_recovered = c->n_v1 = 0;
     c->n_gaps = 0; c->max_gap_ms = 0;
+    c->sp_slots = 0; c->sp_slots_cap = 0;
     c->mstamp = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; g2g_set_error("%s", "stream"); return NULL; }
     for (int i = 0; i < 4; ++i) hipEventCreate(&c->ev[i]);
@@ -164,6 +166,7 @@ extern "C" void g2g_destroy(g2g_ctx *c)
     hipStreamDestroy(c->stream);
     if (c->stage) hipHostFree(c->stage);
     if (c->spare) hipFree(c->spare);
+    if (c->sp_slots) hipFree(c->sp_slots);
     delete c;
 }
 
@@ -1499,8 +1502,39 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
             if (rings) gints += (size_t) (dp.a.many + dp.b.many) * ((size_t) dp.codonk1 + 1);
         }
     }
+    // the streamed walk (kinds 1 and 2: g2g_spprep_kernel lays the position-only inputs of every path column out in path order):
+    // colpre = path columns up to and including each skeleton segment, soff = first slot of each alignment (-1: walks unstreamed)
+    std::vector<int> colpre(all.size(), 0);
+    std::vector<long long> soff(n, -1);
+    size_t nslots = 0;
+    int maxcols = 0;
+    const bool streamed = !g2g_opt(ctx, "NO_SPSTREAM");
+    for (int i = 0; i < n && streamed; ++i) {
+        const DevProb &dp = b->dp[i];
+        if ((dp.kind != 1 && dp.kind != 2) || cnt[i] < 2 || b->status[i]) continue;
+        long long cols = 0;
+        bool good = true;
+        for (int k = 1; k < cnt[i] && good; ++k) {
+            const int mi = all[off[i] + k].m - all[off[i] + k - 1].m, ni = all[off[i] + k].n - all[off[i] + k - 1].n;
+            if (mi < 0 || ni < 0) good = false;
+            cols += std::max(mi, ni);
+            if (cols > (1 << 28)) good = false;
+            colpre[off[i] + k] = (int) cols;
+        }
+        if (!good || cols == 0) continue;
+        soff[i] = (long long) nslots; nslots += (size_t) cols; maxcols = std::max(maxcols, (int) cols);
+    }
+    if (nslots * sizeof(SpSlot) > ((size_t) 4 << 30)) { std::fill(soff.begin(), soff.end(), -1LL); nslots = 0; }
+    if (nslots * sizeof(SpSlot) > ctx->sp_slots_cap) {
+        if (ctx->sp_slots) hipFree(ctx->sp_slots);
+        ctx->sp_slots = 0; ctx->sp_slots_cap = 0;
+        const size_t want = nslots * sizeof(SpSlot) + (nslots * sizeof(SpSlot)) / 4;
+        if (hipMalloc(&ctx->sp_slots, want) == hipSuccess) ctx->sp_slots_cap = want;
+        else { (void) hipGetLastError(); std::fill(soff.begin(), soff.end(), -1LL); nslots = 0; }       // no room: the walks read in place
+    }
     const size_t b_goff = sizeof(long long) * n, o_goff = (o_st + b_int + 15) & ~(size_t) 15,
-                 o_gws = (o_goff + b_goff + 15) & ~(size_t) 15, total = o_gws + sizeof(int) * (gints ? gints : 1);
+                 o_gws = (o_goff + b_goff + 15) & ~(size_t) 15, o_cpre = (o_gws + sizeof(int) * (gints ? gints : 1) + 15) & ~(size_t) 15,
+                 o_soff = (o_cpre + sizeof(int) * colpre.size() + 15) & ~(size_t) 15, total = o_soff + b_goff;
     HIPCHK(hipMalloc((void **) &d, total));
     hipError_t e = hipMemcpyAsync(d + o_skl, all.data(), b_skl, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_off, off.data(), b_int, hipMemcpyHostToDevice, ctx->stream);
@@ -1508,11 +1542,20 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_sp, sp, b_sp, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_goff, goff.data(), b_goff, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && gints) e = hipMemsetAsync(d + o_gws, 0, sizeof(int) * gints, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_cpre, colpre.data(), sizeof(int) * colpre.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_soff, soff.data(), b_goff, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && nslots) {
+        hipLaunchKernelGGL(g2g_spprep_kernel, dim3((unsigned) std::min(64, (maxcols + 255) / 256), (unsigned) n), dim3(256), 0, ctx->stream,
+                           (const DevProb *) b->d_probs, n, (const int2 *) (d + o_skl), (const int *) (d + o_off), (const int *) (d + o_cnt),
+                           (const int *) (d + o_cpre), (const long long *) (d + o_soff), (SpSlot *) ctx->sp_slots);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(g2g_spscore_kernel, dim3(n), dim3(64), 0, ctx->stream, (const DevProb *) b->d_probs, n,
                            (const SpParamsDev *) (d + o_sp), (const int2 *) (d + o_skl), (const int *) (d + o_off),
                            (const int *) (d + o_cnt), (double *) (d + o_out), (int *) (d + o_st),
-                           gints ? (int *) (d + o_gws) : (int *) 0, (const long long *) (d + o_goff));
+                           gints ? (int *) (d + o_gws) : (int *) 0, (const long long *) (d + o_goff),
+                           (const int *) (d + o_cpre), (const long long *) (d + o_soff), nslots ? (const SpSlot *) ctx->sp_slots : (const SpSlot *) 0);
         e = hipGetLastError();
     }
     std::vector<double> ho(6 * (size_t) n);

@@ -778,6 +778,44 @@ __device__ __forceinline__ SList sp_staged(const SpStage &G, const DevSide &sd, 
     return l;
 }
 __device__ __forceinline__ void sp_stage_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// ---- the walk's position-only inputs as a stream ------------------------------------------------------------------------
+// What a column of the path needs that does NOT depend on the walk's state -- its score (sim2 / unpa / unpb) and the static
+// lists of its positions -- is laid out by a parallel pre-pass (g2g_spprep_kernel: one thread per path column) as one 512-byte
+// slot per column, in path order.  The walking wave then reads its inputs through one LDS chunk of SPS_CH slots, fetched with
+// full-width loads a chunk ahead, instead of paying several dependent global round trips per column (3.8 us per column before;
+// the merges themselves are 0.3 us of instruction issue).  Lists longer than SPS_W entries are marked and read in place.
+#define SPS_W 8                       // entries of a packed list, terminator included
+#define SPS_CH 16                     // slots per LDS chunk
+struct SpSlot { double cs; int len[5]; int pad; int glen[5][SPS_W]; double freq[5][SPS_W]; };   // 512 bytes; len: entries, 0 unused, -1 read in place
+struct SpStream { const SpSlot *g; SpSlot *lds; int ncols; int4 r[8]; };
+// which list sits where: 0 a.s  1 a.t  2 b.s (_pf) / a.r (_hf)  3 b.t  4 the other side's r (_pf)
+__device__ __forceinline__ void sps_fetch(SpStream &S, const int j)
+{
+    const int4 *src = (const int4 *) (S.g + (size_t) j * SPS_CH);
+    const int n16 = min(SPS_CH, S.ncols - j * SPS_CH) * (int) (sizeof(SpSlot) / 16);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int i = q * 64 + (int) (threadIdx.x & 63); S.r[q] = i < n16 ? src[i] : make_int4(0, 0, 0, 0); }
+}
+__device__ __forceinline__ const SpSlot *sps_col(SpStream &S, const int c)
+{
+    if ((c & (SPS_CH - 1)) == 0) {                    // first column of a chunk: every read of the previous chunk is behind us
+        const int j = c / SPS_CH;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+        int4 *dst = (int4 *) S.lds;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dst[q * 64 + (int) (threadIdx.x & 63)] = S.r[q];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+        if ((j + 1) * SPS_CH < S.ncols) sps_fetch(S, j + 1);
+    }
+    return S.lds + (c & (SPS_CH - 1));
+}
+__device__ __forceinline__ SList sps_list(const SpSlot *sl, const int l, const DevSide &sd, const int view, const int pos)
+{
+    SList r;
+    if (sl->len[l] < 0) return gfq_at(sd, view, pos);
+    r.glen = sl->glen[l]; r.freq = sl->freq[l];
+    return r;
+}
 // ---- PwdM::stt?? (src/maln2.cc:627-850, 1300-1450): matched / mismatched / unpaired member pairs of a column pair -> FSTAT.
 // ha / hb false: the "zero" iterator of a gap segment (res = vss = NULL, thickness {sumwt, 0, sumwt}).  Every lane replays it.
 struct SpStat { double mch, mmc, unp; };
@@ -927,12 +965,17 @@ __device__ void sp_stt2(const DevProb &P, const int apos, const int bpos, const 
 #undef SP_NOTGAP
 #undef SP_TRUEGAP
 }
-template <int KIND>
+template <int KIND, bool STREAM>
 __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int ni, int &apos, int &bpos, int &glb,
                           const DList dla, const DList dlb, double &scr, double &tgap,
-                          const bool gep, const GepDev &agep, const GepDev &bgep, double &lunp, SpStat &St, const SpStage &G)
+                          const bool gep, const GepDev &agep, const GepDev &bgep, double &lunp, SpStat &St, const SpStage &G,
+                          SpStream &S, int &c)
 {
     const DevSide &a = P.a, &b = P.b;
+    // the inputs of the next column: from its slot of the stream (STREAM), or staged from the profiles here
+#define SP_SLOT const SpSlot *sl = STREAM ? sps_col(S, c) : (const SpSlot *) 0; ++c
+#define SP_LIST(l, side, view, pos, stg) (STREAM ? sps_list(sl, l, side, view, pos) : sp_staged(G, side, view, pos, stg))
+#define SP_SYNC if (!STREAM) sp_stage_sync()
     if (KIND == 0) {
         if (mi == ni) {
             while (mi--) { ++apos; ++bpos; scr += sim2(P, apos, bpos); if (!(sp.flags & 1)) sp_stt2(P, apos, bpos, true, true, St); }
@@ -957,50 +1000,56 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
         if (mi == ni) {
             while (mi--) {
                 ++apos; ++bpos;
-                const SList at = sp_staged(G, a, 1, apos, 1);
-                sp_stage_sync();
-                scr += sim2(P, apos, bpos);
+                SP_SLOT;
+                const SList at = SP_LIST(1, a, 1, apos, 1);
+                SP_SYNC;
+                scr += STREAM ? sl->cs : sim2(P, apos, bpos);
                 tgap += newgap_di(at, glb, dla);
                 if (!(sp.flags & 1)) sp_stt2(P, apos, bpos, true, true, St);
                 newdelta(dla, at, dla);
                 if (gep) { lunp += gep_longup_half(bgep, at, dla, bpos); gep_shift(agep, res_at(a, apos), apos); }
                 glb = 0;
-                sp_stage_sync();
+                SP_SYNC;
             }
         } else if (mi) {
             while (mi--) {
                 ++apos;
-                const SList as = sp_staged(G, a, 0, apos, 0), at = sp_staged(G, a, 1, apos, 1);
-                sp_stage_sync();
-                scr += unpa(P, apos, bpos);
+                SP_SLOT;
+                const SList as = SP_LIST(0, a, 0, apos, 0), at = SP_LIST(1, a, 1, apos, 1);
+                SP_SYNC;
+                scr += STREAM ? sl->cs : unpa(P, apos, bpos);
                 tgap += newgap_cj(as, dla, glb);
                 if (!(sp.flags & 1)) sp_stt2(P, apos, bpos, true, false, St);
                 newdelta(dla, at, dla);
                 ++glb;
                 if (gep) lunp += gep_longup_res(agep, res_at(a, apos), apos, glb, true);
-                sp_stage_sync();
+                SP_SYNC;
             }
         } else if (ni) {
-            const SList ar = sp_staged(G, a, 2, apos, 2);      // (apos does not move in this segment)
-            sp_stage_sync();
+            SList ar; ar.glen = 0; ar.freq = 0;
+            if (!STREAM) ar = sp_staged(G, a, 2, apos, 2);      // (apos does not move in this segment)
+            SP_SYNC;
             while (ni--) {
                 ++bpos;
-                scr += unpb(P, bpos, apos);
+                SP_SLOT;
+                if (STREAM) ar = sps_list(sl, 2, a, 2, apos);              // (every slot of the run carries the list)
+                scr += STREAM ? sl->cs : unpb(P, bpos, apos);
                 tgap += newgap_di(ar, glb, dla);
                 if (!(sp.flags & 1)) sp_stt2(P, apos, bpos, false, true, St);
                 incdelta2(dla, dla);
                 if (gep) lunp += gep_longup_half(bgep, ar, dla, bpos);
             }
-            sp_stage_sync();
+            SP_SYNC;
         }
     } else {
         if (mi == ni) {
             while (mi--) {
                 ++apos; ++bpos;
-                const SList as = sp_staged(G, a, 0, apos, 0), at = sp_staged(G, a, 1, apos, 1);
-                const SList bs = sp_staged(G, b, 0, bpos, 3), bt = sp_staged(G, b, 1, bpos, 4);
-                sp_stage_sync();
-                scr += sim2(P, apos, bpos);
+                SP_SLOT;
+                const SList as = SP_LIST(0, a, 0, apos, 0), at = SP_LIST(1, a, 1, apos, 1);
+                const SList bs = SP_LIST(2, b, 0, bpos, 3), bt = SP_LIST(3, b, 1, bpos, 4);
+                SP_SYNC;
+                scr += STREAM ? sl->cs : sim2(P, apos, bpos);
                 tgap += newgap4(as, dla, bt, dlb)
                       + newgap4(bs, dlb, at, dla);
                 if (!(sp.flags & 1)) sp_stt2(P, apos, bpos, true, true, St);
@@ -1010,40 +1059,48 @@ __device__ void sp_calscr(const DevProb &P, const SpParamsDev &sp, int mi, int n
                     lunp += gep_longup_both(agep, bt, dlb, res_at(a, apos), apos);
                     lunp += gep_longup_both(bgep, at, dla, res_at(b, bpos), bpos);
                 }
-                sp_stage_sync();
+                SP_SYNC;
             }
         } else if (mi) {
-            const SList br = sp_staged(G, b, 2, bpos, 5);      // (bpos does not move in this segment)
+            SList br; br.glen = 0; br.freq = 0;
+            if (!STREAM) br = sp_staged(G, b, 2, bpos, 5);      // (bpos does not move in this segment)
             while (mi--) {
                 ++apos;
-                const SList as = sp_staged(G, a, 0, apos, 0), at = sp_staged(G, a, 1, apos, 1);
-                sp_stage_sync();
-                scr += unpa(P, apos, bpos);
+                SP_SLOT;
+                const SList as = SP_LIST(0, a, 0, apos, 0), at = SP_LIST(1, a, 1, apos, 1);
+                if (STREAM) br = sps_list(sl, 4, b, 2, bpos);
+                SP_SYNC;
+                scr += STREAM ? sl->cs : unpa(P, apos, bpos);
                 tgap += newgap4(as, dla, br, dlb);
                 if (!(sp.flags & 1)) sp_stt2(P, apos, bpos, true, false, St);
                 newdelta(dla, at, dla);
                 incdelta2(dlb, dlb);
                 if (gep) lunp += gep_longup_both(agep, br, dlb, res_at(a, apos), apos);
-                sp_stage_sync();
+                SP_SYNC;
             }
         } else if (ni) {
-            const SList ar = sp_staged(G, a, 2, apos, 2);
+            SList ar; ar.glen = 0; ar.freq = 0;
+            if (!STREAM) ar = sp_staged(G, a, 2, apos, 2);
             while (ni--) {
                 ++bpos;
-                const SList bs = sp_staged(G, b, 0, bpos, 3), bt = sp_staged(G, b, 1, bpos, 4);
-                sp_stage_sync();
-                scr += unpb(P, bpos, apos);
+                SP_SLOT;
+                const SList bs = SP_LIST(2, b, 0, bpos, 3), bt = SP_LIST(3, b, 1, bpos, 4);
+                if (STREAM) ar = sps_list(sl, 4, a, 2, apos);
+                SP_SYNC;
+                scr += STREAM ? sl->cs : unpb(P, bpos, apos);
                 tgap += newgap4(bs, dlb, ar, dla);
                 if (!(sp.flags & 1)) sp_stt2(P, apos, bpos, false, true, St);
                 newdelta(dlb, bt, dlb);
                 incdelta2(dla, dla);
                 if (gep) lunp += gep_longup_both(bgep, ar, dla, res_at(b, bpos), bpos);
-                sp_stage_sync();
+                SP_SYNC;
             }
         }
     }
+#undef SP_SLOT
+#undef SP_LIST
+#undef SP_SYNC
 }
-
 // ---- naive units of calcSpScore (NTV modes): SPunit_nv / _w11 / _w22, reference src/fspscore.h:34-78, calcstat
 // src/fspscore.cc:60-340, calscr :365-470.  Groups are tiny (2 nj + ni < 8): every lane replays everything.
 struct NtvState { int unit; int *gla, *glb; };            // unit: 0 nv, 1 w11, 2 w22, 3 w21; per member running gap lengths
@@ -1273,8 +1330,8 @@ __device__ double ii_store(IiDev &I, int m, int n)
     return I.spb * scr;
 }
 #define SP_FAST_LIST 192
-template <int KIND>
-__device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *skl, int nskl, double *out, int *gepws, int2 *fast_lists, const SpStage &G)
+template <int KIND, bool STREAM>
+__device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *skl, int nskl, double *out, int *gepws, int2 *fast_lists, const SpStage &G, SpStream &S)
 {
     // Gep1st of both sides (fspscore.h:146-147: alprm.ls > 2); the workspace arrives zeroed
     const bool gep = KIND >= 1 && P.noll == 3 && gepws != 0;
@@ -1306,11 +1363,13 @@ __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *
     SpStat St; St.mch = St.mmc = St.unp = 0;
     IiDev II;
     ii_init(II, P);
+    int col = 0;                                               // path columns walked so far = index of the next slot of the stream
+    if (STREAM) sps_fetch(S, 0);
     for (int k = 1; k < nskl; ++k) {
         const int mi = skl[k].x - m, ni = skl[k].y - n, i = mi - ni;
         auto run = [&](int mi_, int ni_) {
             if (KIND == 3) sp_calscr_ntv(P, N, mi_, ni_, apos, bpos, scr, tgap, gep, agep, bgep, lunp, St);
-            else sp_calscr<(KIND == 3 ? 0 : KIND)>(P, sp, mi_, ni_, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp, St, G);
+            else sp_calscr<(KIND == 3 ? 0 : KIND), STREAM>(P, sp, mi_, ni_, apos, bpos, glb, dla, dlb, scr, tgap, gep, agep, bgep, lunp, St, G, S, col);
         };
         if (!i || !mi || !ni) run(mi, ni);
         else if (i > 0) { run(ni, ni); run(i, 0); }
@@ -1333,10 +1392,55 @@ __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *
     out[2] = scr;
     out[3] = St.mch / sp.vab; out[4] = St.mmc / sp.vab; out[5] = St.unp / sp.vab;     // PwdM::rescale, maln2.cc:249-250
 }
+// The pre-pass of the streamed walk: one thread per path column of every streamed alignment.  colpre[k] = path columns of the
+// skeleton's segments 1..k (host: a segment from corner k-1 to corner k has max(rows, columns) of them, its diagonal part first).
+__device__ __forceinline__ void sps_pack(SpSlot &o, const int l, const DevSide &sd, const int view, const int pos)
+{
+    const int off = sd.off[view][pos + 1], len = sd.off[view][pos + 2] - off;       // entries incl. the terminator
+    if (len > SPS_W) { o.len[l] = -1; return; }
+    o.len[l] = len;
+    for (int k = 0; k < len; ++k) { o.glen[l][k] = sd.glen[view][off + k]; o.freq[l][k] = sd.freq[view][off + k]; }
+}
 #ifdef G2G_TU_V1
+extern "C" __global__ void __launch_bounds__(256)
+g2g_spprep_kernel(const DevProb *probs, int nprob, const int2 *skl, const int *skl_off, const int *nskl, const int *colpre,
+                  const long long *slot_off, SpSlot *slots)
+{
+    const int ip = blockIdx.y;
+    if (ip >= nprob || slot_off[ip] < 0) return;
+    const DevProb &P = probs[ip];
+    const int2 *s = skl + skl_off[ip];
+    const int *cp = colpre + skl_off[ip];
+    const int ns = nskl[ip], ncols = cp[ns - 1];
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += gridDim.x * blockDim.x) {
+        int lo = 1, hi = ns - 1;                               // the segment of column c: the first k with colpre[k] > c
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cp[mid] > c) hi = mid; else lo = mid + 1; }
+        const int k = lo, t = c - cp[k - 1];
+        const int m0 = s[k - 1].x, n0 = s[k - 1].y, mi = s[k].x - m0, ni = s[k].y - n0;
+        const int d = mi < ni ? mi : ni;                       // the diagonal part comes first (fspscore.h:222-230)
+        int apos, bpos, type;                                  // type: 0 both advance, 1 a alone, 2 b alone
+        if (t < d) { type = 0; apos = m0 + t; bpos = n0 + t; }
+        else if (mi > ni) { type = 1; apos = m0 + t; bpos = n0 + d - 1; }
+        else { type = 2; bpos = n0 + t; apos = m0 + d - 1; }
+        SpSlot &o = slots[slot_off[ip] + c];
+        for (int l = 0; l < 5; ++l) o.len[l] = 0;
+        o.pad = 0;
+        o.cs = type == 0 ? sim2(P, apos, bpos) : type == 1 ? unpa(P, apos, bpos) : unpb(P, bpos, apos);
+        if (P.kind == 1) {
+            if (type == 0) sps_pack(o, 1, P.a, 1, apos);
+            else if (type == 1) { sps_pack(o, 0, P.a, 0, apos); sps_pack(o, 1, P.a, 1, apos); }
+            else sps_pack(o, 2, P.a, 2, apos);
+        } else {
+            if (type != 2) { sps_pack(o, 0, P.a, 0, apos); sps_pack(o, 1, P.a, 1, apos); }
+            if (type != 1) { sps_pack(o, 2, P.b, 0, bpos); sps_pack(o, 3, P.b, 1, bpos); }
+            if (type == 1) sps_pack(o, 4, P.b, 2, bpos);
+            if (type == 2) sps_pack(o, 4, P.a, 2, apos);
+        }
+    }
+}
 extern "C" __global__ void __launch_bounds__(64)
 g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const int2 *skl, const int *skl_off, const int *nskl,
-                   double *out, int *status, int *gepws, const long long *gep_off)
+                   double *out, int *status, int *gepws, const long long *gep_off, const int *colpre, const long long *slot_off, const SpSlot *slots)
 {
     const int ip = blockIdx.x;
     if (ip >= nprob) return;                                   // (all 64 lanes walk the chain in lockstep, see GepDev)
@@ -1351,15 +1455,21 @@ g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const
     __shared__ int2 sp_lists[2 * SP_FAST_LIST];
     __shared__ int sp_sgl[6 * SP_STAGE];
     __shared__ double sp_sfq[6 * SP_STAGE];
+    __shared__ SpSlot sp_chunk[SPS_CH];
     int2 *fl = (int2 *) sp_lists;
     SpStage G; G.gl = (int *) sp_sgl; G.fq = (double *) sp_sfq;
-    if (P.kind == 0) sp_calcskl<0>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G);
-    else if (P.kind == 1) sp_calcskl<1>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G);
-    else if (P.kind == 2) sp_calcskl<2>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G);
-    else sp_calcskl<3>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G);
+    SpStream S;
+    const bool stream = slots && slot_off[ip] >= 0 && (P.kind == 1 || P.kind == 2);
+    S.g = stream ? slots + slot_off[ip] : (const SpSlot *) 0; S.lds = (SpSlot *) sp_chunk; S.ncols = stream ? colpre[skl_off[ip] + nskl[ip] - 1] : 0;
+    if (P.kind == 0) sp_calcskl<0, false>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S);
+    else if (P.kind == 1) { if (stream) sp_calcskl<1, true>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S); else sp_calcskl<1, false>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S); }
+    else if (P.kind == 2) { if (stream) sp_calcskl<2, true>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S); else sp_calcskl<2, false>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S); }
+    else sp_calcskl<3, false>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S);
     status[ip] = 0;
 }
 #else
+extern "C" __global__ void g2g_spprep_kernel(const DevProb *probs, int nprob, const int2 *skl, const int *skl_off, const int *nskl, const int *colpre,
+                                             const long long *slot_off, SpSlot *slots);
 extern "C" __global__ void g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const int2 *skl, const int *skl_off, const int *nskl,
-                                              double *out, int *status, int *gepws, const long long *gep_off);
+                                              double *out, int *status, int *gepws, const long long *gep_off, const int *colpre, const long long *slot_off, const SpSlot *slots);
 #endif
