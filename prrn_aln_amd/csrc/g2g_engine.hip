@@ -1555,7 +1555,8 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
                            (const SpParamsDev *) (d + o_sp), (const int2 *) (d + o_skl), (const int *) (d + o_off),
                            (const int *) (d + o_cnt), (double *) (d + o_out), (int *) (d + o_st),
                            gints ? (int *) (d + o_gws) : (int *) 0, (const long long *) (d + o_goff),
-                           (const int *) (d + o_cpre), (const long long *) (d + o_soff), nslots ? (const SpSlot *) ctx->sp_slots : (const SpSlot *) 0);
+                           (const int *) (d + o_cpre), (const long long *) (d + o_soff), nslots ? (const SpSlot *) ctx->sp_slots : (const SpSlot *) 0,
+                           g2g_opt(ctx, "NO_SPLANES") ? 1 : 0);
         e = hipGetLastError();
     }
     std::vector<double> ho(6 * (size_t) n);

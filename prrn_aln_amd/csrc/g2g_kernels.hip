@@ -1392,6 +1392,214 @@ __device__ void sp_calcskl(const DevProb &P, const SpParamsDev &sp, const int2 *
     out[2] = scr;
     out[3] = St.mch / sp.vab; out[4] = St.mmc / sp.vab; out[5] = St.unp / sp.vab;     // PwdM::rescale, maln2.cc:249-250
 }
+// ---- the streamed walk with the lists ACROSS the lanes -----------------------------------------------------------------------
+// What is carried from column to column are the two running lists; the walker above keeps them in LDS and every lane replays
+// the same scalar merges, entry after entry, each entry a dependent LDS read.  Here lane j holds entry j of a running list
+// ({glen, nins}; the terminator {INT_MAX, 0} and everything behind it likewise) and lane i entry i of a column's static list, and
+// the merges of gfreq.cc become a few uniform steps over the lanes:
+//   GapLenSD(g, D)      = g + nins of the last entry of D whose glen <= g: a loop over D's entries (2-4), v_readlane each;
+//   newgap(cf, Dc, df, Dd): both stretched sequences ascend strictly (glen ascends, nins ascends: newdelta only emits larger
+//                         ones, incdelta adds one to all), so the reference's trailing cursor into cf is, for entry d of df,
+//                         the NUMBER of cf entries stretched shorter than it; the products are then added in d order;
+//   newdelta(D, df)     : the new list is {0, 0}, then {g + 1, nins} of every df entry whose looked-up nins exceeds its
+//                         predecessor's, then the terminator -- a ballot and one pass over its set bits.
+// Every floating-point operation is the reference's, in its order.  Lists of more than 62 entries, Noll 3 (the Gep1st rings read
+// the lists through memory) and unstreamed alignments stay with the walker above; so does an alignment this one gives up on.
+struct LaneList { int g, n, cnt; };                               // cnt (uniform): entries in front of the terminator
+struct LaneStat { int g; double f; int cnt; };                    // a static list: cnt entries in front of its terminator
+__device__ __forceinline__ int ll_rl(const int v, const int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double ll_rld(const double v, const int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ void ll_clear(LaneList &D) { const int lane = threadIdx.x & 63; D.g = lane == 0 ? 0 : INT_MAX; D.n = 0; D.cnt = 1; }
+__device__ __forceinline__ int ll_nins_at(const LaneList &D, const int g)
+{
+    int r = ll_rl(D.n, 0);
+    for (int j = 1; j < D.cnt; ++j) { const int gj = ll_rl(D.g, j), nj = ll_rl(D.n, j); r = g >= gj ? nj : r; }
+    return r;
+}
+__device__ __forceinline__ LaneStat ll_static(const SpSlot *sl, const int l, const DevSide &sd, const int view, const int pos, bool &ok)
+{
+    const int lane = threadIdx.x & 63;
+    LaneStat L;
+    int len = sl->len[l];
+    if (len >= 0) {
+        L.g = lane < len ? sl->glen[l][lane & (SPS_W - 1)] : -1;
+        L.f = lane < len ? sl->freq[l][lane & (SPS_W - 1)] : 0;
+    } else {                                                   // longer than a slot holds: read in place
+        const int o = sd.off[view][pos + 1];
+        len = sd.off[view][pos + 2] - o;
+        L.g = lane < len ? sd.glen[view][o + lane] : -1;
+        L.f = lane < len ? sd.freq[view][o + lane] : 0;
+    }
+    const unsigned long long neg = __ballot(L.g < 0);          // the terminator ends the list, wherever the count says it is
+    L.cnt = neg ? (int) __ffsll((long long) neg) - 1 : 64;
+    if (L.cnt >= 63) ok = false;
+    return L;
+}
+__device__ __forceinline__ double ll_newgap4(const LaneStat &cf, const LaneList &Dc, const LaneStat &df, const LaneList &Dd)
+{   // newgap(cf, dlc, df, dld), gfreq.cc:507-521
+    if (cf.cnt == 0 || df.cnt == 0) return 0;
+    const int ic = cf.g + ll_nins_at(Dc, cf.g), jd = df.g + ll_nins_at(Dd, df.g);
+    int cur = 0;                                               // lane d: the cursor into cf when df's entry d is reached
+    double cfq = ll_rld(cf.f, 0);
+    for (int c = 0; c < cf.cnt; ++c) {
+        const bool shorter = ll_rl(ic, c) < jd;
+        cur += shorter ? 1 : 0;
+        const double nxt = c + 1 < cf.cnt ? ll_rld(cf.f, c + 1) : 0;
+        cfq = shorter ? nxt : cfq;                             // = cf.freq[cur] while cur < cf.cnt
+    }
+    const double term = cfq * df.f;
+    double g = 0;
+    for (int d = 0; d < df.cnt; ++d) {
+        if (ll_rl(cur, d) >= cf.cnt) break;
+        g += ll_rld(term, d);
+    }
+    return g;
+}
+__device__ __forceinline__ double ll_newgap_cj(const LaneStat &cf, const LaneList &Dc, const int j)
+{   // newgap(cf, dlc, j), gfreq.cc:523-532
+    const int lane = threadIdx.x & 63;
+    const int ic = cf.g + ll_nins_at(Dc, cf.g);
+    const unsigned long long hit = __ballot(lane < cf.cnt && ic >= j);
+    return hit ? ll_rld(cf.f, (int) __ffsll((long long) hit) - 1) : 0;
+}
+__device__ __forceinline__ double ll_newgap_di(const LaneStat &df, const int i, const LaneList &Dd)
+{   // newgap(df, i, dld), gfreq.cc:534-545
+    const int lane = threadIdx.x & 63;
+    const int jd = df.g + ll_nins_at(Dd, df.g);
+    const unsigned long long stop = __ballot(lane < df.cnt && i < jd);
+    const int lim = stop ? (int) __ffsll((long long) stop) - 1 : df.cnt;
+    double g = 0;
+    for (int d = 0; d < lim; ++d) g += ll_rld(df.f, d);
+    return g;
+}
+__device__ __forceinline__ void ll_newdelta(LaneList &D, const LaneStat &df, bool &ok)
+{   // newdelta(dlt, df, dln, 1), gfreq.cc:570-587, in place
+    const int lane = threadIdx.x & 63;
+    const int sn = lane < df.cnt ? ll_nins_at(D, df.g) : 0;
+    const int up = __builtin_amdgcn_update_dpp(0, sn, 0x138, 0xf, 0xf, false);      // wave_shr:1 -- lane i gets lane i - 1's, lane 0 gets 0
+    unsigned long long m = __ballot(lane < df.cnt && sn > (lane == 0 ? 0 : up));
+    int ng = lane == 0 ? 0 : INT_MAX, nn = 0, p = 1;
+    while (m) {
+        const int src = (int) __ffsll((long long) m) - 1;
+        m &= m - 1;
+        const int gg = ll_rl(df.g, src) + 1, sv = ll_rl(sn, src);
+        ng = lane == p ? gg : ng;
+        nn = lane == p ? sv : nn;
+        ++p;
+    }
+    if (p >= 63) ok = false;
+    D.g = ng; D.n = nn; D.cnt = p;
+}
+__device__ __forceinline__ void ll_incdelta(LaneList &D)
+{   // incdelta(dlt, dln, 1), gfreq.cc:598-605, in place
+    const int lane = threadIdx.x & 63;
+    D.n += lane < D.cnt ? 1 : 0;
+}
+template <int KIND>
+__device__ bool sp_calcskl_lanes(const DevProb &P, const SpParamsDev &sp, const int2 *skl, const int nskl, double *out, SpStream &S)
+{
+    const DevSide &a = P.a, &b = P.b;
+    bool ok = true;
+    LaneList Da, Db;
+    ll_clear(Da); ll_clear(Db);
+    int m = skl[0].x, n = skl[0].y, glb = 0;
+    int apos = m - 1, bpos = n - 1;
+    double scr = 0, tgap = 0;
+    SpStat St; St.mch = St.mmc = St.unp = 0;
+    IiDev II;
+    ii_init(II, P);
+    int col = 0;
+    sps_fetch(S, 0);
+    const bool stats = !(sp.flags & 1);
+    auto run = [&](int mi, int ni) {
+        if (mi == ni) {
+            while (mi-- && ok) {
+                ++apos; ++bpos;
+                const SpSlot *sl = sps_col(S, col); ++col;
+                scr += sl->cs;
+                if (KIND == 1) {
+                    const LaneStat at = ll_static(sl, 1, a, 1, apos, ok);
+                    tgap += ll_newgap_di(at, glb, Da);
+                    if (stats) sp_stt2(P, apos, bpos, true, true, St);
+                    ll_newdelta(Da, at, ok);
+                    glb = 0;
+                } else {
+                    const LaneStat as = ll_static(sl, 0, a, 0, apos, ok), at = ll_static(sl, 1, a, 1, apos, ok);
+                    const LaneStat bs = ll_static(sl, 2, b, 0, bpos, ok), bt = ll_static(sl, 3, b, 1, bpos, ok);
+                    tgap += ll_newgap4(as, Da, bt, Db)
+                          + ll_newgap4(bs, Db, at, Da);
+                    if (stats) sp_stt2(P, apos, bpos, true, true, St);
+                    ll_newdelta(Da, at, ok);
+                    ll_newdelta(Db, bt, ok);
+                }
+            }
+        } else if (mi) {
+            while (mi-- && ok) {
+                ++apos;
+                const SpSlot *sl = sps_col(S, col); ++col;
+                const LaneStat as = ll_static(sl, 0, a, 0, apos, ok), at = ll_static(sl, 1, a, 1, apos, ok);
+                scr += sl->cs;
+                if (KIND == 1) {
+                    tgap += ll_newgap_cj(as, Da, glb);
+                    if (stats) sp_stt2(P, apos, bpos, true, false, St);
+                    ll_newdelta(Da, at, ok);
+                    ++glb;
+                } else {
+                    const LaneStat br = ll_static(sl, 4, b, 2, bpos, ok);
+                    tgap += ll_newgap4(as, Da, br, Db);
+                    if (stats) sp_stt2(P, apos, bpos, true, false, St);
+                    ll_newdelta(Da, at, ok);
+                    ll_incdelta(Db);
+                }
+            }
+        } else if (ni) {
+            while (ni-- && ok) {
+                ++bpos;
+                const SpSlot *sl = sps_col(S, col); ++col;
+                scr += sl->cs;
+                if (KIND == 1) {
+                    const LaneStat ar = ll_static(sl, 2, a, 2, apos, ok);
+                    tgap += ll_newgap_di(ar, glb, Da);
+                    if (stats) sp_stt2(P, apos, bpos, false, true, St);
+                    ll_incdelta(Da);
+                } else {
+                    const LaneStat bs = ll_static(sl, 2, b, 0, bpos, ok), bt = ll_static(sl, 3, b, 1, bpos, ok);
+                    const LaneStat ar = ll_static(sl, 4, a, 2, apos, ok);
+                    tgap += ll_newgap4(bs, Db, ar, Da);
+                    if (stats) sp_stt2(P, apos, bpos, false, true, St);
+                    ll_newdelta(Db, bt, ok);
+                    ll_incdelta(Da);
+                }
+            }
+        }
+    };
+    for (int k = 1; k < nskl && ok; ++k) {
+        const int mi = skl[k].x - m, ni = skl[k].y - n, i = mi - ni;
+        if (!i || !mi || !ni) run(mi, ni);
+        else if (i > 0) { run(ni, ni); run(i, 0); }
+        else { run(mi, mi); run(0, -i); }
+        if (II.on) {                                               // fspscore.h:231-247
+            int d = i >= 0 ? ni : mi;
+            if (d) { m += d; n += d; scr += ii_store(II, m, n); }
+            if (i < 0) { d = -i; n -= i; } else if (i > 0) { d = i; m += i; } else d = 0;
+            if (d) {
+                if (i > 0) II.bgap += (long long) d * II.step; else II.agap += (long long) d * II.step;
+                scr += ii_store(II, m, n);
+            }
+        }
+        m = skl[k].x; n = skl[k].y;
+    }
+    if (!ok) return false;
+    scr += tgap * (KIND == 1 ? P.weighted_gop : P.basic_gop) + sp.diff_u * 0.;      // wgop(tgap, lunp), maln.h:321-325 (lunp = 0 without Gep1st)
+    out[0] = scr / sp.vab;
+    out[1] = tgap / sp.vab;
+    out[2] = scr;
+    out[3] = St.mch / sp.vab; out[4] = St.mmc / sp.vab; out[5] = St.unp / sp.vab;
+    return true;
+}
 // The pre-pass of the streamed walk: one thread per path column of every streamed alignment.  colpre[k] = path columns of the
 // skeleton's segments 1..k (host: a segment from corner k-1 to corner k has max(rows, columns) of them, its diagonal part first).
 __device__ __forceinline__ void sps_pack(SpSlot &o, const int l, const DevSide &sd, const int view, const int pos)
@@ -1440,7 +1648,7 @@ g2g_spprep_kernel(const DevProb *probs, int nprob, const int2 *skl, const int *s
 }
 extern "C" __global__ void __launch_bounds__(64)
 g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const int2 *skl, const int *skl_off, const int *nskl,
-                   double *out, int *status, int *gepws, const long long *gep_off, const int *colpre, const long long *slot_off, const SpSlot *slots)
+                   double *out, int *status, int *gepws, const long long *gep_off, const int *colpre, const long long *slot_off, const SpSlot *slots, int nolanes)
 {
     const int ip = blockIdx.x;
     if (ip >= nprob) return;                                   // (all 64 lanes walk the chain in lockstep, see GepDev)
@@ -1462,8 +1670,17 @@ g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const
     const bool stream = slots && slot_off[ip] >= 0 && (P.kind == 1 || P.kind == 2);
     S.g = stream ? slots + slot_off[ip] : (const SpSlot *) 0; S.lds = (SpSlot *) sp_chunk; S.ncols = stream ? colpre[skl_off[ip] + nskl[ip] - 1] : 0;
     if (P.kind == 0) sp_calcskl<0, false>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S);
-    else if (P.kind == 1) { if (stream) sp_calcskl<1, true>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S); else sp_calcskl<1, false>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S); }
-    else if (P.kind == 2) { if (stream) sp_calcskl<2, true>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S); else sp_calcskl<2, false>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S); }
+    else if (P.kind == 1) {
+        const bool lanes = stream && !(P.noll == 3 && ws) && !nolanes;
+        if (lanes && sp_calcskl_lanes<1>(P, sp[ip], s, nskl[ip], out + 6 * ip, S)) { }
+        else if (stream) sp_calcskl<1, true>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S);
+        else sp_calcskl<1, false>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S);
+    } else if (P.kind == 2) {
+        const bool lanes = stream && !(P.noll == 3 && ws) && !nolanes;
+        if (lanes && sp_calcskl_lanes<2>(P, sp[ip], s, nskl[ip], out + 6 * ip, S)) { }
+        else if (stream) sp_calcskl<2, true>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S);
+        else sp_calcskl<2, false>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S);
+    }
     else sp_calcskl<3, false>(P, sp[ip], s, nskl[ip], out + 6 * ip, ws, fl, G, S);
     status[ip] = 0;
 }
@@ -1471,5 +1688,5 @@ g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const
 extern "C" __global__ void g2g_spprep_kernel(const DevProb *probs, int nprob, const int2 *skl, const int *skl_off, const int *nskl, const int *colpre,
                                              const long long *slot_off, SpSlot *slots);
 extern "C" __global__ void g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const int2 *skl, const int *skl_off, const int *nskl,
-                                              double *out, int *status, int *gepws, const long long *gep_off, const int *colpre, const long long *slot_off, const SpSlot *slots);
+                                              double *out, int *status, int *gepws, const long long *gep_off, const int *colpre, const long long *slot_off, const SpSlot *slots, int nolanes);
 #endif

@@ -75,6 +75,42 @@ def test_calcspscore_matches_reference_goldens(ctx):
     assert n_ok == len(GOLD) >= 59
 
 
+@pytest.mark.parametrize("opts", [{"NO_SPLANES": "1"}, {"NO_SPSTREAM": "1"}], ids=["stream_scalar_walk", "unstreamed_walk"])
+def test_calcspscore_walkers_agree(opts):
+    """The three walkers of g2g_spscore_kernel -- lists across the lanes (default for half / full profile units without Gep1st),
+    the scalar walk over the streamed inputs (its fallback: Noll 3, very long lists) and the unstreamed walk (no workspace) --
+    give the reference's fstat (val, gap and the counters) on every golden and the checker's on a sweep of larger divisions."""
+    c = engine.Context()
+    for k, v in opts.items():
+        c.set_option(k, v)
+    try:
+        pws, want = [], []
+        for f in GOLD:
+            d = dict(np.load(f))
+            alp = params_from_golden(d)
+            ga, gb = groups_from_golden(d, alp)
+            pws.append(op.PwdM([ga, gb], alp)); want.append(d)
+        res = op.align2_batch(c, pws)
+        fs = op.calcSpScore_batch(c, pws, [skl for (_, skl, _) in res], stats=True)
+        for d, f in zip(want, fs):
+            assert f[2] == 0 and f[0] == d["fstat_val"][0] and f[1] == d["fstat_gap"][0]
+            assert tuple(f[4:7]) == (d["fstat_mch"][0], d["fstat_mmc"][0], d["fstat_unp"][0])
+        fam = make_family(40, 160, 23)
+        sw = sweep.Sweep(fam, op.AlnParam())
+        res = op.align2_batch(c, sw.pwds)
+        fs = op.calcSpScore_batch(c, sw.pwds, [skl for (_, skl, _) in res])
+        L = oraclelib.load()
+        for pw, (scr, skl, st), (val, gap, fst, _raw) in zip(sw.pwds, res, fs):
+            class H:
+                c = pw.problem
+            rc, oval, ogap = oraclelib.spscore(L, H, op.spparams(pw), skl)
+            assert (fst == 0) == (rc == 0)
+            if rc == 0:
+                assert val == oval and gap == ogap
+    finally:
+        c.close()
+
+
 def test_calcspscore_sweep_vs_oracle(ctx):
     """... and on a sweep of larger divisions against the CPU restatement."""
     fam = make_family(40, 160, 23)
