@@ -1184,9 +1184,10 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             // sweep mode: the kernel argument is the publish interval.  A DP's critical path is columns + strips x (rows of a
             // strip + interval): 32 steps when the strips outnumber the resident workgroups many times over (throughput bound,
             // fewer fences), 8 / 4 when they do not (a window of g2g_refine: the batch is as slow as its longest pipeline; measured on
-            // batches of 1-16 full-size DPs with tools/latency_probe.py: 4 beats 16 by 14 % at 8 DPs, 2 gains nothing more).
+            // batches of 1-16 full-size DPs with tools/latency_probe.py: 4 beats 16 by 14 % at 8 DPs, 2 gains nothing more), 16 for a
+            // rank's share of a sharded sweep (1/8 of the bench sweep: 180 ms against 195 with 32).
             const int res2 = ncu2 * std::max(1, std::min(wpc2, (int) (V2_LDS_MAX / (b->lds2 + 4 * (size_t) T2))));
-            const int pint2 = !b->v2_sweep ? 0 : b->v2_sweep >= 2 ? b->v2_sweep : cnt <= 2 * res2 ? 4 : cnt <= 4 * res2 ? 8 : 32;
+            const int pint2 = !b->v2_sweep ? 0 : b->v2_sweep >= 2 ? b->v2_sweep : cnt <= 2 * res2 ? 4 : cnt <= 4 * res2 ? 8 : cnt <= 16 * res2 ? 16 : 32;
             if (g2g_opt(ctx, "DEBUG")) { fprintf(stderr, "[g2g] variant %d: %d tiles, grid %d x %d threads, lds %zu, cols %d, gen %d\n", v, cnt, grid, T2, b->lds2, b->v2_cols, b->gen); fflush(stderr); }
             double *simscr2 = 0;
             if (b->v2_sweep && !g2g_opt(ctx, "NO_SIMBLK")) {
@@ -1202,6 +1203,8 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             HIPCHK(hipEventRecord(ctx->vev[sk2], vs2));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->vev[sk2], 0));
         }
+        // (the _hf launch goes first on purpose: submitted behind the _pf launches -- whose persistent workgroups hold the LDS of every
+        //  CU until their queues are empty -- it runs after them instead of beside them: 845 ms per bench sweep instead of 757)
         for (int v = 0; v < 8; ++v) {
             const int cnt = b->var_off[v + 5] - b->var_off[v + 4];
             if (!cnt || !v3k[v]) continue;
