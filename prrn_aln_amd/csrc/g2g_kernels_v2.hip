@@ -104,6 +104,22 @@ __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hd
     }
 }
 __device__ __forceinline__ bool g2g_dp_failed(const int *failp) { return __hip_atomic_load(failp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
+// Strip-boundary records cross workgroups (and XCDs: each has its own L2).  Plain accesses ordered by agent-scope release /
+// acquire fences cost a write-back of the whole L2 (buffer_wbl2) per publish and an invalidate (buffer_inv) per consumed
+// publish: 2-6 us each, which is most of a step when a handful of DPs publish every 4 steps (g2g_refine's windows).  With
+// G2G_NOFENCE the records themselves are written with agent-scope (write-through) stores and read with agent-scope loads, and
+// publishing is: wait for the stores, store the progress word.
+#ifdef G2G_NOFENCE
+#define G2G_XLD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define G2G_XST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define G2G_ACQUIRE()
+#define G2G_RELEASE()
+#else
+#define G2G_XLD(p) (*(p))
+#define G2G_XST(p, v) (*(p) = (v))
+#define G2G_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define G2G_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#endif
 #define DL_GUARD 128                         // no list is this long: a corrupted one must not hang the wave
 
 // Everything below lives in LDS and says so in its pointer types (address space 3): generic pointers
@@ -303,6 +319,17 @@ __device__ __forceinline__ void rec_l2g(unsigned *dst, LRec src, int ndw, int la
 {
     const lu32 *s = (const lu32 *) src.p;
     for (int k = lane; k < ndw; k += TEAM) dst[k] = s[k];
+}
+// ... of records that cross strips (G2G_XLD / G2G_XST)
+__device__ __forceinline__ void rec_g2l_x(LRec dst, const unsigned *src, int ndw, int lane)
+{
+    lu32 *d = (lu32 *) dst.p;
+    for (int k = lane; k < ndw; k += TEAM) d[k] = G2G_XLD(src + k);
+}
+__device__ __forceinline__ void rec_l2g_x(unsigned *dst, LRec src, int ndw, int lane)
+{
+    const lu32 *q = (const lu32 *) src.p;
+    for (int k = lane; k < ndw; k += TEAM) G2G_XST(dst + k, q[k]);
 }
 
 struct V2Geom {
@@ -947,13 +974,13 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         const int want = penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF);
         if (prog_up && want > avail) {
             avail = g2g_wait_ge(prog_up, want, dbg, failp, ti);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            G2G_ACQUIRE();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     };
     auto publish = [&](const int col) {                    // (a barrier inside: call it uniformly)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        G2G_RELEASE();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         __hip_atomic_store(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1016,13 +1043,13 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
                 const bool up_in = do_vert && (n - (m - 1) <= P.up);       // cell (m-1, n) exists
                 if (n == lo || !stage_regs) {                               // first cell of the row in this block
                     if (n == lo) {
-                        if (n == b.left && m > a.left) rec_g2l(hcur, colH + (size_t) (m - a.left) * G.ndw, G.ndw, lane);
-                        else rec_g2l(hcur, rowHp + (size_t) n * G.ndw, G.ndw, lane);
+                        if (n == b.left && m > a.left) rec_g2l_x(hcur, colH + (size_t) (m - a.left) * G.ndw, G.ndw, lane);
+                        else rec_g2l_x(hcur, rowHp + (size_t) n * G.ndw, G.ndw, lane);
                     }
-                    if (up_in || (!do_vert && n + 1 < nhi)) rec_g2l(hnxt, rowHp + (size_t) (n + 1) * G.ndw, G.ndw, lane);
+                    if (up_in || (!do_vert && n + 1 < nhi)) rec_g2l_x(hnxt, rowHp + (size_t) (n + 1) * G.ndw, G.ndw, lane);
                     if (up_in) {
-                        rec_g2l(gu, rowGp + (size_t) (n + 1) * G.ndw, G.ndw, lane);
-                        if (NOLL3) rec_g2l(g2u, rowG2p + (size_t) (n + 1) * G.ndw, G.ndw, lane);
+                        rec_g2l_x(gu, rowGp + (size_t) (n + 1) * G.ndw, G.ndw, lane);
+                        if (NOLL3) rec_g2l_x(g2u, rowG2p + (size_t) (n + 1) * G.ndw, G.ndw, lane);
                     }
                 }
                 if (stage_regs && n + 1 < hi) {
@@ -1033,9 +1060,9 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
                     for (int j = 0; j < 4; ++j) {
                         const int k = lane + j * TEAM;
                         if (k < G.ndw) {
-                            if (pf_h) pfh[j] = rowHp[(size_t) (n + 2) * G.ndw + k];
-                            if (pf_gu) pfgu[j] = rowGp[(size_t) (n + 2) * G.ndw + k];
-                            if (NOLL3 && pf_gu) pfg2u[j] = rowG2p[(size_t) (n + 2) * G.ndw + k];
+                            if (pf_h) pfh[j] = G2G_XLD(rowHp + (size_t) (n + 2) * G.ndw + k);
+                            if (pf_gu) pfgu[j] = G2G_XLD(rowGp + (size_t) (n + 2) * G.ndw + k);
+                            if (NOLL3 && pf_gu) pfg2u[j] = G2G_XLD(rowG2p + (size_t) (n + 2) * G.ndw + k);
                         }
                     }
                 }
@@ -1086,13 +1113,13 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
             // the row below starts at b.left with the left-boundary corner (m+1, b.left) as its
             // diagonal source: park it in this row's H ring where that row will look for it
             if (n == b.left && team + 1 < R && m + 1 < a.right && m + 1 <= m_left_last && (m + 1 + P.lw) <= b.left) {
-                rec_g2l(G.row(team, SLOT_H(b.left)), colH + (size_t) (m + 1 - a.left) * G.ndw, G.ndw, lane);
+                rec_g2l_x(G.row(team, SLOT_H(b.left)), colH + (size_t) (m + 1 - a.left) * G.ndw, G.ndw, lane);
             }
             // strip boundary: the last row's corners go to HBM for the strip below
             if (team == R - 1 || m == a.right - 1) {
-                rec_l2g(rowHc + (size_t) (n + 1) * G.ndw, D.h, G.ndw, lane);
-                rec_l2g(rowGc + (size_t) (n + 1) * G.ndw, D.g, G.ndw, lane);
-                if (NOLL3) rec_l2g(rowG2c + (size_t) (n + 1) * G.ndw, D.g2, G.ndw, lane);
+                rec_l2g_x(rowHc + (size_t) (n + 1) * G.ndw, D.h, G.ndw, lane);
+                rec_l2g_x(rowGc + (size_t) (n + 1) * G.ndw, D.g, G.ndw, lane);
+                if (NOLL3) rec_l2g_x(rowG2c + (size_t) (n + 1) * G.ndw, D.g2, G.ndw, lane);
             }
             // block boundary: this row's corner and F records for the block on the right
             if (n == c1 - 1 && c1 < b.right) {

@@ -661,8 +661,8 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
     auto stage_load = [&](int col, bool wantG, unsigned &rh, unsigned &rg, unsigned &rg2) {
         if (lane < ndw) {
             const unsigned *s = (col == b.left && vert0) ? colH + (size_t) (m0 - a.left) * ndw : rowHp + (size_t) col * ndw;
-            rh = s[lane];
-            if (wantG) { rg = rowGp[(size_t) col * ndw + lane]; if (NOLL3) rg2 = rowG2p[(size_t) col * ndw + lane]; }
+            rh = G2G_XLD(s + lane);
+            if (wantG) { rg = G2G_XLD(rowGp + (size_t) col * ndw + lane); if (NOLL3) rg2 = G2G_XLD(rowG2p + (size_t) col * ndw + lane); }
         }
     };
     auto stage_put = [&](int slot, int sid, unsigned v) {
@@ -683,14 +683,14 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
         const int want = penc | (col < 0xFFFFF ? col : 0xFFFFF);
         if (prog_up && want > avail) {
             avail = g2g_wait_ge(prog_up, want, dbg, failp, ti);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            G2G_ACQUIRE();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     };
     auto publish = [&](const int col) {                    // corners <= col of this strip's last row are in HBM
         if (prog_self) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            G2G_RELEASE();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -754,7 +754,7 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
                     v = (j < capa) ? p[j] : (j < capa + capb) ? p[ca4 + j - capa] : 0;
                 }
                 unsigned *dst = (x == 0) ? rowHc : (x == 1) ? rowGc : rowG2c;
-                if (lane < ndw) dst[(size_t) col * ndw + lane] = v;
+                if (lane < ndw) G2G_XST(dst + (size_t) col * ndw + lane, v);
             }
         }
     };
