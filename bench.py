@@ -220,6 +220,7 @@ def refinement_readout(ctx, args):
            "gpu_batches": rstats["batches"], "divisions_recomputed": rstats["divisions_wasted"],
            "wait_timeouts": int(c1["wait_timeouts"] - c0["wait_timeouts"]), "recovered_dps": int(c1["recovered_dps"] - c0["recovered_dps"]),
            "last_timeout_report": (ctx.last_timeout()[:1500] if c1["recovered_dps"] > c0["recovered_dps"] else None),
+           "wait_gaps": list(ctx.wait_gaps()),
            "same_branch_sequence_as_reference": [x["branch"] for x in rsteps] == f["branches"],
            "every_dp_score_and_fstat_val_equal_to_reference": bool(scr_same),
            "final_msa_identical_to_reference": same,
@@ -468,6 +469,9 @@ def main():
                        # every run is evidence about the scheduler's waits: per timed step, the waits that ran into
                        # their wall-clock limit and the DPs re-run because of it (rank 0's share); an ordinary run shows zeros
                        "wait_timeouts": wait_timeouts, "recovered_dps": recovered_dps,
+                       # ... and the stretches of more than 4 ms a waiting wave spent off the machine since the context was created
+                       # (count, longest in ms: g2g_ctx_wait_gaps)
+                       "wait_gaps": list(ctx.wait_gaps()),
                        # checksum of the last timed step's results (this rank's divisions): the same workload must give the same
                        # two numbers in every run, with or without a recovered time-out in it
                        "score_sum": float(sum(scr for (scr, _, st) in out if st == 0)),
