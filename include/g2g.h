@@ -264,12 +264,21 @@ typedef struct {
  * (g2g_stdskl output: corners ascending, first = (a.left, b.left), last = (a.right, b.right))              */
 int        g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl,
                              g2g_fstat *out);
+/* ... nsets skeletons per problem of the batch in one launch: entry e (of nsets * n) is set e / n of problem e % n */
+int        g2g_batch_spscore_sets(g2g_batch *b, int nsets, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl,
+                                  g2g_fstat *out);
 /* level 1 */
 int        g2g_pwdm_spparams(const g2g_pwdm *p, g2g_spparams *sp);
 int        g2g_spscore_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *p, const g2g_skl *const *skl, const int *nskl,
                              g2g_fstat *out);
 int        g2g_spscore_batch_flags(g2g_ctx *ctx, int n, g2g_pwdm *const *p, const g2g_skl *const *skl, const int *nskl,
                                    int flags, g2g_fstat *out);       /* the same with g2g_spparams::flags set for every item */
+/* What a refinement needs of a window of divisions in one call: align2() of every pair (as g2g_align2_batch: scr, skl,
+   nskl, status) plus calcSpScore of its CURRENT alignment `cur` (fs_cur) and of the new one (fs_new), flags as for
+   g2g_spscore_batch_flags (<-> Prrn::onecycle, src/prrn5.cc:522-535).  Same results as the two calls; the problems are
+   packed and uploaded once. */
+int        g2g_align2_score_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *pw, const g2g_skl *const *cur, const int *ncur, int flags,
+                                  double *scr, g2g_skl **skl, int *nskl, int *status, g2g_fstat *fs_cur, g2g_fstat *fs_new);
 int        g2g_align2(g2g_ctx *ctx, g2g_pwdm *p, double *scr, g2g_skl **skl, int *nskl);
 /* <-> VTYPE HomScore(mSeq* seqs[], PwdM* pwdm, long rr[]) (src/maln2.cc:1837): score only; rr may be NULL. */
 int        g2g_homscore(g2g_ctx *ctx, g2g_pwdm *p, double *scr, int64_t rr[2]);

@@ -53,6 +53,9 @@ def lib():
     L.g2g_ctx_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     L.g2g_ctx_last_timeout.restype = C.c_char_p
     L.g2g_ctx_last_timeout.argtypes = [C.c_void_p]
+    L.g2g_align2_score_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int), C.c_int,
+                                         C.POINTER(C.c_double), C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                         C.POINTER(_abi.Fstat), C.POINTER(_abi.Fstat)]
     L.g2g_ctx_wait_gaps.restype = None
     L.g2g_ctx_wait_gaps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
     L.g2g_batch_spscore.argtypes = [C.c_void_p, C.POINTER(_abi.SpParams), C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int), C.POINTER(_abi.Fstat)]

@@ -1476,13 +1476,29 @@ extern "C" void g2g_waits(unsigned long long *out) { hipMemcpyFromSymbol(out, HI
 #endif
 
 // f1: PreSpScore::calcSpScore on the problems of a prepared batch (their inputs are resident in HBM)
-extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl, g2g_fstat *out)
+// nsets skeletons per problem of the batch in ONE launch (entry e = set e / b->n of problem e % b->n): the windows of g2g_refine
+// score the current and the new alignment of every division on the batch the DPs ran on, without packing the problems again
+extern "C" int g2g_batch_spscore_sets(g2g_batch *b, int nsets, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl, g2g_fstat *out)
 {
-    if (!b || !sp || !skl || !nskl || !out) return G2G_ERR_ARG;
+    if (!b || nsets < 1 || !sp || !skl || !nskl || !out) return G2G_ERR_ARG;
     g2g_ctx *ctx = b->ctx;
     HIPCHK(hipSetDevice(ctx->device));
-    const int n = b->n;
-    if (n == 0) return G2G_OK;
+    const int nb = b->n;
+    if (nb == 0) return G2G_OK;
+    if (nsets > 1) {
+        // two walks of one problem must not share list storage: the walkers keep their running lists in LDS unless the problem's
+        // capacities exceed SP_FAST_LIST entries -- then they use the problem's own state arrays, and the sets go one by one
+        bool one_by_one = false;
+        for (int i = 0; i < nb; ++i) if (b->dp[i].capa + 1 > SP_FAST_LIST || b->dp[i].capb + 1 > SP_FAST_LIST) one_by_one = true;
+        if (one_by_one) {
+            for (int k = 0; k < nsets; ++k) {
+                const int rc = g2g_batch_spscore_sets(b, 1, sp + (size_t) k * nb, skl + (size_t) k * nb, nskl + (size_t) k * nb, out + (size_t) k * nb);
+                if (rc) return rc;
+            }
+            return G2G_OK;
+        }
+    }
+    const int n = nsets * nb;
     std::vector<int> off(n), cnt(n);
     size_t tot = 0;
     for (int i = 0; i < n; ++i) { off[i] = (int) tot; cnt[i] = (skl[i] && nskl[i] > 0) ? nskl[i] : 0; tot += cnt[i]; }
@@ -1497,7 +1513,7 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
     std::vector<long long> goff(n, -1);
     size_t gints = 0;
     for (int i = 0; i < n; ++i) {
-        const DevProb &dp = b->dp[i];
+        const DevProb &dp = b->dp[i % nb];
         const bool rings = dp.kind >= 1 && dp.noll == 3 && dp.codonk1 > 0 && dp.codonk1 < (1 << 20);
         if (rings || dp.kind == 3) {                      // kind 3 (naive units): + gla[an], glb[bn] in front of the rings
             goff[i] = (long long) gints;
@@ -1513,8 +1529,8 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
     int maxcols = 0;
     const bool streamed = !g2g_opt(ctx, "NO_SPSTREAM");
     for (int i = 0; i < n && streamed; ++i) {
-        const DevProb &dp = b->dp[i];
-        if ((dp.kind != 1 && dp.kind != 2) || cnt[i] < 2 || b->status[i]) continue;
+        const DevProb &dp = b->dp[i % nb];
+        if ((dp.kind != 1 && dp.kind != 2) || cnt[i] < 2 || b->status[i % nb]) continue;
         long long cols = 0;
         bool good = true;
         for (int k = 1; k < cnt[i] && good; ++k) {
@@ -1549,12 +1565,12 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_soff, soff.data(), b_goff, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && nslots) {
         hipLaunchKernelGGL(g2g_spprep_kernel, dim3((unsigned) std::min(64, (maxcols + 255) / 256), (unsigned) n), dim3(256), 0, ctx->stream,
-                           (const DevProb *) b->d_probs, n, (const int2 *) (d + o_skl), (const int *) (d + o_off), (const int *) (d + o_cnt),
+                           (const DevProb *) b->d_probs, n, nb, (const int2 *) (d + o_skl), (const int *) (d + o_off), (const int *) (d + o_cnt),
                            (const int *) (d + o_cpre), (const long long *) (d + o_soff), (SpSlot *) ctx->sp_slots);
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(g2g_spscore_kernel, dim3(n), dim3(64), 0, ctx->stream, (const DevProb *) b->d_probs, n,
+        hipLaunchKernelGGL(g2g_spscore_kernel, dim3(n), dim3(64), 0, ctx->stream, (const DevProb *) b->d_probs, n, nb,
                            (const SpParamsDev *) (d + o_sp), (const int2 *) (d + o_skl), (const int *) (d + o_off),
                            (const int *) (d + o_cnt), (double *) (d + o_out), (int *) (d + o_st),
                            gints ? (int *) (d + o_gws) : (int *) 0, (const long long *) (d + o_goff),
@@ -1572,9 +1588,14 @@ extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g
     for (int i = 0; i < n; ++i) {
         out[i].val = ho[6 * i]; out[i].gap = ho[6 * i + 1]; out[i].raw = ho[6 * i + 2]; out[i].reserved = 0;
         out[i].mch = ho[6 * i + 3]; out[i].mmc = ho[6 * i + 4]; out[i].unp = ho[6 * i + 5];
-        out[i].status = b->status[i] ? b->status[i] : hs[i] == 0 ? G2G_OK : hs[i] == -2 ? G2G_ERR_MODE : G2G_ERR_ARG;
+        out[i].status = b->status[i % nb] ? b->status[i % nb] : hs[i] == 0 ? G2G_OK : hs[i] == -2 ? G2G_ERR_MODE : G2G_ERR_ARG;
     }
     return G2G_OK;
+}
+
+extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl, g2g_fstat *out)
+{
+    return g2g_batch_spscore_sets(b, 1, sp, skl, nskl, out);
 }
 
 // upper estimate of the arena bytes one problem takes in a batch (inputs + state + trace + column scores)

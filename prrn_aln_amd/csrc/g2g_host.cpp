@@ -780,6 +780,69 @@ extern "C" int g2g_align2_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *pw, double
     return status ? G2G_OK : worst;
 }
 
+// One window of the refinement per call: align2() of every pair plus calcSpScore of its CURRENT alignment (`cur`) and of the new
+// one (<-> what Prrn::onecycle needs of a division, src/prrn5.cc:522-535).  Same results as g2g_align2_batch followed by
+// g2g_spscore_batch_flags on 2 n (PwdM, skeleton) pairs -- and that is what runs when a DP needs the sh = -100 retry, fails, or the
+// window does not fit one batch -- but here the problems are packed and uploaded once and both sets of walks share one launch.
+extern "C" int g2g_batch_spscore_sets(g2g_batch *b, int nsets, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl, g2g_fstat *out);
+extern "C" int g2g_align2_score_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *pw, const g2g_skl *const *cur, const int *ncur, int flags,
+                                      double *scr, g2g_skl **skl, int *nskl, int *status, g2g_fstat *fs_cur, g2g_fstat *fs_new)
+{
+    if (!ctx || n < 0 || (n && (!pw || !cur || !ncur || !scr || !skl || !nskl || !status || !fs_cur || !fs_new))) return G2G_ERR_ARG;
+    if (n == 0) return G2G_OK;
+    for (int i = 0; i < n; ++i) { if (!pw[i]) return G2G_ERR_ARG; skl[i] = 0; nskl[i] = 0; scr[i] = 0; status[i] = G2G_OK; }
+    bool plain = n <= 4096 && !g2g_get_option(ctx, "NO_SCORE_BATCH");      // (the option: a test seat for the general route)
+    g2g_batch *b = 0;
+    if (plain) {
+        std::vector<const g2g_problem *> pp(n);
+        for (int i = 0; i < n; ++i) pp[i] = &pw[i]->prob;
+        std::vector<g2g_result> rr(n);
+        for (auto &r : rr) { r.trace = 0; r.ntrace = 0; }
+        int rc = g2g_batch_prepare(ctx, n, pp.data(), &b);
+        if (!rc) rc = g2g_batch_run(b);
+        if (!rc) rc = g2g_batch_fetch(b, rr.data());
+        if (rc) plain = false;
+        for (int i = 0; i < n && plain; ++i) {
+            if (rr[i].status) { plain = false; break; }
+            int ns = 0;
+            g2g_skl *s = g2g_stdskl(rr[i].trace, rr[i].ntrace, &ns);
+            const g2g_group &a = *pw[i]->a, &bb = *pw[i]->b;
+            if (!s || ns < 1 || s[0].m != a.left || s[ns - 1].m != a.right || s[0].n != bb.left || s[ns - 1].n != bb.right) { g2g_free(s); plain = false; break; }
+            scr[i] = rr[i].score; skl[i] = s; nskl[i] = ns;
+        }
+        for (auto &r : rr) g2g_free(r.trace);
+        if (plain) {
+            std::vector<g2g_spparams> sp((size_t) 2 * n);
+            std::vector<const g2g_skl *> sk((size_t) 2 * n);
+            std::vector<int> ns((size_t) 2 * n);
+            std::vector<g2g_fstat> fs((size_t) 2 * n);
+            for (int i = 0; i < n; ++i) {
+                sp[i] = pw[i]->sp; sp[i].flags = flags; sp[n + i] = sp[i];
+                sk[i] = cur[i]; ns[i] = ncur[i]; sk[n + i] = skl[i]; ns[n + i] = nskl[i];
+            }
+            rc = g2g_batch_spscore_sets(b, 2, sp.data(), sk.data(), ns.data(), fs.data());
+            g2g_batch_free(b);
+            if (rc) { for (int i = 0; i < n; ++i) { g2g_free(skl[i]); skl[i] = 0; nskl[i] = 0; scr[i] = 0; } return rc; }
+            for (int i = 0; i < n; ++i) { fs_cur[i] = fs[i]; fs_new[i] = fs[n + i]; }
+            return G2G_OK;
+        }
+        if (b) g2g_batch_free(b);
+        for (int i = 0; i < n; ++i) { g2g_free(skl[i]); skl[i] = 0; nskl[i] = 0; scr[i] = 0; }
+    }
+    // the general route
+    int rc = g2g_align2_batch(ctx, n, pw, scr, skl, nskl, status);
+    if (rc) return rc;
+    std::vector<g2g_pwdm *> pw2(pw, pw + n); pw2.insert(pw2.end(), pw, pw + n);
+    std::vector<const g2g_skl *> sk((size_t) 2 * n);
+    std::vector<int> ns((size_t) 2 * n);
+    std::vector<g2g_fstat> fs((size_t) 2 * n);
+    for (int i = 0; i < n; ++i) { sk[i] = cur[i]; ns[i] = ncur[i]; sk[n + i] = skl[i]; ns[n + i] = nskl[i]; }
+    rc = g2g_spscore_batch_flags(ctx, 2 * n, pw2.data(), sk.data(), ns.data(), flags, fs.data());
+    if (rc) { for (int i = 0; i < n; ++i) { g2g_free(skl[i]); skl[i] = 0; nskl[i] = 0; } return rc; }
+    for (int i = 0; i < n; ++i) { fs_cur[i] = fs[i]; fs_new[i] = fs[n + i]; }
+    return G2G_OK;
+}
+
 extern "C" int g2g_homscore(g2g_ctx *ctx, g2g_pwdm *p, double *scr, int64_t rr[2])
 {
     if (!ctx || !p || !scr) return G2G_ERR_ARG;

@@ -1611,12 +1611,12 @@ __device__ __forceinline__ void sps_pack(SpSlot &o, const int l, const DevSide &
 }
 #ifdef G2G_TU_V1
 extern "C" __global__ void __launch_bounds__(256)
-g2g_spprep_kernel(const DevProb *probs, int nprob, const int2 *skl, const int *skl_off, const int *nskl, const int *colpre,
+g2g_spprep_kernel(const DevProb *probs, int nprob, int nreal, const int2 *skl, const int *skl_off, const int *nskl, const int *colpre,
                   const long long *slot_off, SpSlot *slots)
 {
-    const int ip = blockIdx.y;
+    const int ip = blockIdx.y;                               // entry ip walks problem ip % nreal (g2g_batch_spscore_sets)
     if (ip >= nprob || slot_off[ip] < 0) return;
-    const DevProb &P = probs[ip];
+    const DevProb &P = probs[ip % nreal];
     const int2 *s = skl + skl_off[ip];
     const int *cp = colpre + skl_off[ip];
     const int ns = nskl[ip], ncols = cp[ns - 1];
@@ -1647,12 +1647,12 @@ g2g_spprep_kernel(const DevProb *probs, int nprob, const int2 *skl, const int *s
     }
 }
 extern "C" __global__ void __launch_bounds__(64)
-g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const int2 *skl, const int *skl_off, const int *nskl,
+g2g_spscore_kernel(const DevProb *probs, int nprob, int nreal, const SpParamsDev *sp, const int2 *skl, const int *skl_off, const int *nskl,
                    double *out, int *status, int *gepws, const long long *gep_off, const int *colpre, const long long *slot_off, const SpSlot *slots, int nolanes)
 {
     const int ip = blockIdx.x;
     if (ip >= nprob) return;                                   // (all 64 lanes walk the chain in lockstep, see GepDev)
-    const DevProb &P = probs[ip];
+    const DevProb &P = probs[ip % nreal];
     for (int k = 0; k < 6; ++k) out[6 * ip + k] = 0;
     if (P.kind < 0) { status[ip] = -1; return; }
     int *ws = (gepws && gep_off[ip] >= 0) ? gepws + gep_off[ip] : (int *) 0;
@@ -1685,8 +1685,8 @@ g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const
     status[ip] = 0;
 }
 #else
-extern "C" __global__ void g2g_spprep_kernel(const DevProb *probs, int nprob, const int2 *skl, const int *skl_off, const int *nskl, const int *colpre,
+extern "C" __global__ void g2g_spprep_kernel(const DevProb *probs, int nprob, int nreal, const int2 *skl, const int *skl_off, const int *nskl, const int *colpre,
                                              const long long *slot_off, SpSlot *slots);
-extern "C" __global__ void g2g_spscore_kernel(const DevProb *probs, int nprob, const SpParamsDev *sp, const int2 *skl, const int *skl_off, const int *nskl,
+extern "C" __global__ void g2g_spscore_kernel(const DevProb *probs, int nprob, int nreal, const SpParamsDev *sp, const int2 *skl, const int *skl_off, const int *nskl,
                                               double *out, int *status, int *gepws, const long long *gep_off, const int *colpre, const long long *slot_off, const SpSlot *slots, int nolanes);
 #endif

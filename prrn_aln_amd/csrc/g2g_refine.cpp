@@ -290,7 +290,7 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
     if (nthr > 16) nthr = 16;
     if (nthr < 1) nthr = 1;
 
-    double t_build = 0, t_align = 0, t_sp = 0, t_rest = 0;
+    double t_build = 0, t_align = 0, t_rest = 0;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
     while (it < maxi && rc_all == G2G_OK) {
@@ -375,32 +375,23 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
                     d.neu.assign(skl[i], skl[i] + nskl[i]);
                 }
             } else {
+                // DPs, then calcSpScore of the current and of the new alignment of every division, on one resident batch
+                std::vector<const g2g_skl *> cur((size_t) nm);
+                std::vector<int> ncur((size_t) nm);
+                for (int i = 0; i < nm; ++i) { const Division &d = D[live[mine[i]]]; cur[i] = d.old.data(); ncur[i] = (int) d.old.size(); }
+                std::vector<g2g_fstat> fc((size_t) nm), fn((size_t) nm);
                 const double t1 = now();
-                rc = g2g_align2_batch(ctx, nm, pw.data(), scr.data(), skl.data(), nskl.data(), st.data());
+                rc = g2g_align2_score_batch(ctx, nm, pw.data(), cur.data(), ncur.data(), G2G_SP_NOSTATS, scr.data(), skl.data(), nskl.data(), st.data(), fc.data(), fn.data());
                 t_align += now() - t1;
-                if (rc == G2G_OK) {
-                    std::vector<g2g_pwdm *> pw2(pw); pw2.insert(pw2.end(), pw.begin(), pw.end());
-                    std::vector<const g2g_skl *> sk2((size_t) 2 * nm);
-                    std::vector<int> ns2((size_t) 2 * nm);
-                    for (int i = 0; i < nm; ++i) {
-                        Division &d = D[live[mine[i]]];
-                        sk2[i] = d.old.data(); ns2[i] = (int) d.old.size();
-                        sk2[nm + i] = skl[i]; ns2[nm + i] = nskl[i];
+                for (int i = 0; i < nm && rc == G2G_OK; ++i) {
+                    Division &d = D[live[mine[i]]];
+                    if (st[i] != 0 || fc[i].status != 0 || fn[i].status != 0) {
+                        rc = st[i] ? st[i] : fc[i].status ? fc[i].status : fn[i].status;
+                        g2g_set_error("%s", "g2g_refine: a division's DP or its sum-of-pairs score failed");
+                        break;
                     }
-                    std::vector<g2g_fstat> fs((size_t) 2 * nm);
-                    const double t2 = now();
-                    rc = g2g_spscore_batch_flags(ctx, 2 * nm, pw2.data(), sk2.data(), ns2.data(), G2G_SP_NOSTATS, fs.data());
-                    t_sp += now() - t2;
-                    for (int i = 0; i < nm && rc == G2G_OK; ++i) {
-                        Division &d = D[live[mine[i]]];
-                        if (st[i] != 0 || fs[i].status != 0 || fs[nm + i].status != 0) {
-                            rc = st[i] ? st[i] : fs[i].status ? fs[i].status : fs[nm + i].status;
-                            g2g_set_error("%s", "g2g_refine: a division's DP or its sum-of-pairs score failed");
-                            break;
-                        }
-                        d.scr = scr[i]; d.val_old = fs[i].raw; d.val_new = fs[nm + i].val;
-                        d.neu.assign(skl[i], skl[i] + nskl[i]);
-                    }
+                    d.scr = scr[i]; d.val_old = fc[i].raw; d.val_new = fn[i].val;
+                    d.neu.assign(skl[i], skl[i] + nskl[i]);
                 }
             }
             for (int i = 0; i < nm; ++i) g2g_free(skl[i]);
@@ -508,8 +499,8 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
         win = accepted ? O.window_min : std::min(O.window, 2 * win);
     }
     if (rc_all != G2G_OK) return rc_all;
-    t_rest = now() - t_begin - t_build - t_align - t_sp;
-    if (getenv("G2G_REFINE_TIMES")) fprintf(stderr, "[g2g_refine] %d batches: build %.0f ms, align2 %.0f ms, calcSpScore %.0f ms, rest %.0f ms\n", S.batches, t_build, t_align, t_sp, t_rest);
+    t_rest = now() - t_begin - t_build - t_align;
+    if (getenv("G2G_REFINE_TIMES")) fprintf(stderr, "[g2g_refine] %d batches: build %.0f ms, scoring (align2 + calcSpScore, or the scorer callback) %.0f ms, rest %.0f ms\n", S.batches, t_build, t_align, t_rest);
     S.divisions = (int) log.size();
     if (ctx) {        // waits of the DP scheduler that ran into their limit during this call, and the DPs re-run for it (0 in an ordinary run)
         long long cnt1[4] = {0, 0, 0, 0};

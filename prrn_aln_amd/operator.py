@@ -150,6 +150,33 @@ def align2(ctx, pwd: PwdM):
     return align2_batch(ctx, [pwd])[0]
 
 
+def align2_score_batch(ctx, pwds: Sequence[PwdM], cur_skls, flags: int = 0):
+    """g2g_align2_score_batch: align2() of every PwdM plus calcSpScore of its current alignment (cur_skls) and of the new one --
+    what a window of the refinement needs, on one resident batch.  [(scr, skl, status, (val, gap, status, raw) of the current
+    alignment, the same of the new one)]."""
+    L = lib()
+    n = len(pwds)
+    hs = (C.c_void_p * n)(*[p._h for p in pwds])
+    _bufs, cptr, ccnt = _skl_arrays(cur_skls)
+    scr = (C.c_double * n)()
+    skl = (C.POINTER(_abi.Skl) * n)()
+    nskl = (C.c_int * n)()
+    st = (C.c_int * n)()
+    fc = (_abi.Fstat * max(1, n))()
+    fn = (_abi.Fstat * max(1, n))()
+    rc = L.g2g_align2_score_batch(ctx._h, n, hs, cptr, ccnt, flags, scr, skl, nskl, st, fc, fn)
+    if rc:
+        raise G2GError("g2g_align2_score_batch rc=%d: %s" % (rc, last_error()))
+    out = []
+    for i in range(n):
+        s = np.zeros((nskl[i], 2), np.int32)
+        if nskl[i]:
+            s[:] = np.ctypeslib.as_array(C.cast(skl[i], C.POINTER(C.c_int32)), shape=(nskl[i] * 2,)).reshape(-1, 2)
+            L.g2g_free(skl[i])
+        out.append((scr[i], s, st[i], (fc[i].val, fc[i].gap, fc[i].status, fc[i].raw), (fn[i].val, fn[i].gap, fn[i].status, fn[i].raw)))
+    return out
+
+
 def HomScore(ctx, pwd: PwdM):
     """<-> VTYPE HomScore(seqs, pwdm, rr) (reference src/maln2.cc:1837): (score, (rr0, rr1))."""
     L = lib()

@@ -111,6 +111,36 @@ def test_calcspscore_walkers_agree(opts):
         c.close()
 
 
+@pytest.mark.parametrize("general", [False, True], ids=["one_resident_batch", "general_route"])
+def test_align2_score_batch_equals_the_separate_calls(general):
+    """g2g_align2_score_batch (what a window of g2g_refine calls: DPs + calcSpScore of the current and of the new alignment on
+    one resident batch, both sets of walks in one launch) against g2g_align2_batch + g2g_spscore_batch on the same pairs -- the
+    goldens (every mode) and a sweep of larger divisions whose 'current' alignments are the start MSA's own."""
+    c = engine.Context()
+    if general:
+        c.set_option("NO_SCORE_BATCH", "1")
+    try:
+        pws = []
+        for f in GOLD:
+            d = dict(np.load(f))
+            alp = params_from_golden(d)
+            ga, gb = groups_from_golden(d, alp)
+            pws.append(op.PwdM([ga, gb], alp))
+        fam = make_family(24, 120, 5)
+        sw = sweep.Sweep(fam, op.AlnParam())
+        pws += list(sw.pwds)
+        ref = op.align2_batch(c, pws)
+        cur = [skl for (_, skl, _) in ref]                       # any valid skeleton serves as the 'current' one: the DP's own
+        fs = op.calcSpScore_batch(c, pws, cur)
+        got = op.align2_score_batch(c, pws, cur)
+        assert len(got) == len(pws)
+        for (scr, skl, st), f, (gscr, gskl, gst, fc, fn) in zip(ref, fs, got):
+            assert gst == st and gscr == scr and np.array_equal(gskl, skl)
+            assert fc == tuple(f) and fn == tuple(f)
+    finally:
+        c.close()
+
+
 def test_calcspscore_sweep_vs_oracle(ctx):
     """... and on a sweep of larger divisions against the CPU restatement."""
     fam = make_family(40, 160, 23)
