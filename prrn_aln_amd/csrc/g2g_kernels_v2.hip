@@ -23,7 +23,7 @@
 
 #define TEAM 8
 #ifdef G2G_V2_STAMP
-__device__ unsigned long long g2g_stamp_acc[16];
+static __device__ unsigned long long g2g_stamp_acc[16];      // (one copy per translation unit: g2g_tu_v2.hip reads its own, g2g_v2_stamps)
 #define STAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += t_ - stamp_t; stamp_t = t_; }
 #else
 #define STAMP(k)
@@ -964,7 +964,7 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
     bool have = false;
     int rslot = (RC - team % RC) % RC;                     // ring slot of column cbase + s - team
     int wslot = 1 % RC;                                    // ring slot of column cbase + s + 1
-    const bool stage_regs = G.ndw <= 4 * TEAM;            // record fits 4 dwords per lane (128 B)
+    const bool stage_regs = G.ndw <= 64;                   // the records of the strip above are fetched a step ahead by the first wave, one dword per lane
     int avail = prog_up ? 0 : 0x7fffffff;
     const int penc = (pgen & 0x7FF) << 20;
     int hi0 = m0 + P.up + 1; if (hi0 > b.right) hi0 = b.right; if (hi0 > c1) hi0 = c1;    // the first team's hi
@@ -1021,6 +1021,25 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
                 if (k < pf_n) { pf_g[j] = pf_glen[o + k]; pf_f[j] = pf_freq[o + k]; }
             }
         }
+        // the first row's upper neighbours for the column after next: fetched now by the whole first wave (lane k: dword k of each
+        // record), parked in LDS after this step's cells -- nothing that comes from HBM is waited for in the step that uses it.
+        // (Four dwords per lane of the first team only covered records of 128 bytes; with longer ones that row loaded three records
+        //  synchronously in every step, and the other rows of the strip waited for it at the barrier.)
+        const int n0 = cbase + s;                          // the first row's column in this step
+        bool pf_h = false, pf_gu = false;
+        unsigned pfh1 = 0, pfgu1 = 0, pfg2u1 = 0;
+        if (stage_regs && m0 < a.right && n0 < hi0 && n0 + 1 < hi0) {
+            const bool vert0 = m0 > a.left;
+            int nhi0 = m0 + P.up + 1; if (nhi0 > b.right) nhi0 = b.right;
+            const bool up_nx = vert0 && (n0 + 1 - (m0 - 1) <= P.up);
+            pf_h = up_nx || (!vert0 && n0 + 2 < nhi0);
+            pf_gu = up_nx;
+            if (tid < 64 && tid < G.ndw) {
+                if (pf_h) pfh1 = G2G_XLD(rowHp + (size_t) (n0 + 2) * G.ndw + tid);
+                if (pf_gu) pfgu1 = G2G_XLD(rowGp + (size_t) (n0 + 2) * G.ndw + tid);
+                if (NOLL3 && pf_gu) pfg2u1 = G2G_XLD(rowG2p + (size_t) (n0 + 2) * G.ndw + tid);
+            }
+        }
         if (active) {
             CellSrc S; CellDst D;
             const bool do_vert = m > a.left, do_hori = n > b.left;
@@ -1033,8 +1052,6 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
                 L.br.glen = bg + 2 * mlb; L.br.freq = bf + 2 * mlb;
             }
             // -- sources -----------------------------------------------------------------------
-            unsigned pfh[4], pfgu[4], pfg2u[4];
-            bool pf_h = false, pf_gu = false;
             if (team == 0) {
                 // the row above lives in HBM (previous strip's last row / the top boundary chain); its
                 // records for the NEXT column are fetched into registers now and parked in LDS after the cell
@@ -1050,20 +1067,6 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
                     if (up_in) {
                         rec_g2l_x(gu, rowGp + (size_t) (n + 1) * G.ndw, G.ndw, lane);
                         if (NOLL3) rec_g2l_x(g2u, rowG2p + (size_t) (n + 1) * G.ndw, G.ndw, lane);
-                    }
-                }
-                if (stage_regs && n + 1 < hi) {
-                    const bool up_nx = do_vert && (n + 1 - (m - 1) <= P.up);
-                    pf_h = up_nx || (!do_vert && n + 2 < nhi);
-                    pf_gu = up_nx;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int k = lane + j * TEAM;
-                        if (k < G.ndw) {
-                            if (pf_h) pfh[j] = G2G_XLD(rowHp + (size_t) (n + 2) * G.ndw + k);
-                            if (pf_gu) pfgu[j] = G2G_XLD(rowGp + (size_t) (n + 2) * G.ndw + k);
-                            if (NOLL3 && pf_gu) pfg2u[j] = G2G_XLD(rowG2p + (size_t) (n + 2) * G.ndw + k);
-                        }
                     }
                 }
                 team_sync();
@@ -1097,18 +1100,6 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
 #endif
                                  );
             STAMP(5)
-            if (team == 0 && (pf_h || pf_gu)) {                             // park the prefetched neighbours
-                const LRec hslot = (n & 1) ? G.extra(EX_H1) : G.extra(EX_H0);   // corner n+2 shares corner n's slot
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = lane + j * TEAM;
-                    if (k < G.ndw) {
-                        if (pf_h) ((lu32 *) hslot.p)[k] = pfh[j];
-                        if (pf_gu) ((lu32 *) G.extra(EX_GU).p)[k] = pfgu[j];
-                        if (NOLL3 && pf_gu) ((lu32 *) G.extra(EX_G2U).p)[k] = pfg2u[j];
-                    }
-                }
-            }
             sim_cur = sim_nx; bc_cur = bc_nx; have = (n + 1 < hi);
             // the row below starts at b.left with the left-boundary corner (m+1, b.left) as its
             // diagonal source: park it in this row's H ring where that row will look for it
@@ -1128,6 +1119,12 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
                 if (NOLL3) rec_l2g(cbF2 + (size_t) (m - a.left) * G.ndw, D.f2, G.ndw, lane);
             }
             if (m == a.right - 1 && n == b.right - 1 && lane == 0) *P.score = lval(D.h);
+        }
+        if ((pf_h || pf_gu) && tid < 64 && tid < G.ndw) {      // park the prefetched neighbours (corner n0 + 2 shares corner n0's slot)
+            const LRec hslot = (n0 & 1) ? G.extra(EX_H1) : G.extra(EX_H0);
+            if (pf_h) ((lu32 *) hslot.p)[tid] = pfh1;
+            if (pf_gu) ((lu32 *) G.extra(EX_GU).p)[tid] = pfgu1;
+            if (NOLL3 && pf_gu) ((lu32 *) G.extra(EX_G2U).p)[tid] = pfg2u1;
         }
         if (pf_on) {
 #pragma unroll
