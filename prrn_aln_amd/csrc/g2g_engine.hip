@@ -1110,10 +1110,18 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                 sh_lo[v] = 0; sh_n[v] = 0;
                 if (cnt) { ++nl; tot += work[v]; demand += (double) cnt / wpc_of(v); }
             }
+            // Default: shares when no v6 launch is in the run -- the regime of a window of g2g_refine and of a rank's share of a sharded
+            // sweep (_pf on v2 beside _hf on v3r: the two kernels slow each other down on a shared CU; 1/8 of the bench sweep 179 -> 140 ms,
+            // 1/4 266 -> 245 ms, a window of the 256 x 1024 refinement 107 -> 102 ms).  Not with v6 in the run: its class of the most
+            // balanced divisions is bound by its DPs' critical path, needs many CUs for a short time, and a static share leaves them idle
+            // afterwards (a full sweep 1563 ms instead of 760, half of one 734 instead of 437).  CU_SHARES=0 / 1 / 2: never /
+            // for runs that fill the machine twice over / always.
+            bool has_v6 = false;
+            for (int v = 12; v < G2G_HDR; ++v) if ((v < 16 || v >= 20) && b->var_off[v + 1] - b->var_off[v] > 0) has_v6 = true;
             const char *opt = g2g_opt(ctx, "CU_SHARES");
-            const bool want = opt ? atoi(opt) != 0 : false;      // off by default: a launch bound by its DPs' critical path needs many CUs for a
-                                                                // short time, and a static share leaves them idle afterwards
-            const bool force = opt && atoi(opt) >= 2;           // (test switch: shares even for a run that does not fill the machine)
+            const bool autosh = !opt && !has_v6;
+            const bool want = opt ? atoi(opt) != 0 : autosh;
+            const bool force = (opt && atoi(opt) >= 2) || autosh;
             // only a run that fills the machine more than twice over is partitioned, and only if every launch can have a unit
             if (want && ncu == 256 && nl >= 2 && nl <= 16 && (force || demand >= 2.0 * ncu) && tot > 0 && !g2g_opt(ctx, "DEBUG")) {      // (256 CUs in 8 XCDs: the mask layout the shares are written for)
                 int left = 32;
