@@ -60,6 +60,7 @@ struct g2g_ctx {
     struct MStream { int lo, n; hipStream_t s; unsigned long long used; };
     std::vector<MStream> mstream;   // streams confined to a share of the CUs (units lo .. lo + n - 1 of 32; see cu_share_stream)
     unsigned long long mstamp;
+    long long n_mstreams;           // CU-mask streams created so far
     std::string last_timeout;       // report of the last recovered time-out (g2g_ctx_last_timeout)
 };
 
@@ -120,7 +121,7 @@ extern "C" g2g_ctx *g2g_create(int device)
     c->stage = 0; c->stage_cap = 0;
     c->spare = 0; c->spare_bytes = 0;
     c->n_runs = c->n_timeouts = c->n_recovered = c->n_v1 = 0;
-    c->n_gaps = 0; c->max_gap_ms = 0;
+    c->n_gaps = 0; c->max_gap_ms = 0; c->n_mstreams = 0;
     c->sp_slots = 0; c->sp_slots_cap = 0;
     c->mstamp = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; g2g_set_error("%s", "stream"); return NULL; }
@@ -973,7 +974,12 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
 static hipStream_t cu_share_stream(g2g_ctx *c, int lo, int n)
 {
     for (auto &m : c->mstream) if (m.lo == lo && m.n == n) { m.used = ++c->mstamp; return m.s; }
-    if (c->mstream.size() >= 24) {                          // forget the least recently used share
+    // Every share is a hardware queue of its own, on top of the launch streams' (GPU_MAX_HW_QUEUES).  Somewhere above twenty queues the
+    // hardware scheduler starts to take queues off the machine in turn -- persistent launches then stand still for tens to hundreds of
+    // ms at a time (seen as gaps by the waiting waves: g2g_ctx_wait_gaps) -- so the shares in use are kept few.
+    size_t cap = 8;
+    if (const char *e = g2g_opt(c, "MSTREAM_MAX")) { const int v = atoi(e); if (v >= 2 && v <= 64) cap = (size_t) v; }
+    if (c->mstream.size() >= cap) {                         // forget the least recently used share
         size_t k = 0;
         for (size_t i = 1; i < c->mstream.size(); ++i) if (c->mstream[i].used < c->mstream[k].used) k = i;
         hipStreamSynchronize(c->mstream[k].s); hipStreamDestroy(c->mstream[k].s);
@@ -984,6 +990,7 @@ static hipStream_t cu_share_stream(g2g_ctx *c, int lo, int n)
     g2g_ctx::MStream m; m.lo = lo; m.n = n; m.s = 0; m.used = ++c->mstamp;
     if (hipExtStreamCreateWithCUMask(&m.s, 8, mask) != hipSuccess || !m.s) { (void) hipGetLastError(); return 0; }
     c->mstream.push_back(m);
+    ++c->n_mstreams;
     return m.s;
 }
 // relative cost of a cell on the kernel of variant slot v (what the shares are proportional to)
@@ -1164,6 +1171,22 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                         --sh_n[big]; --given;
                     }
                     if (given == left) {
+                        // two launches (the common case: _pf on v2 beside _hf on v3r): a split within one unit of one already in use is
+                        // as good, and keeps the number of queues down
+                        if (nl == 2) {
+                            int v0 = -1, v1 = -1;
+                            for (int v = 0; v < G2G_HDR; ++v) if (sh_n[v]) { if (v0 < 0) v0 = v; else v1 = v; }
+                            if (v0 >= 0 && v1 >= 0 && sh_n[v0] + sh_n[v1] == 32) {
+                                int best = -1;
+                                for (const auto &m : ctx->mstream) {
+                                    if (m.lo != 0 || m.n < 1 || m.n > 31 || abs(m.n - sh_n[v0]) > 1) continue;
+                                    bool partner = false;
+                                    for (const auto &q : ctx->mstream) if (q.lo == m.n && q.n == 32 - m.n) partner = true;
+                                    if (partner && (best < 0 || abs(m.n - sh_n[v0]) < abs(best - sh_n[v0]))) best = m.n;
+                                }
+                                if (best > 0) { sh_n[v0] = best; sh_n[v1] = 32 - best; }
+                            }
+                        }
                         int lo = 0;
                         shares = true;
                         for (int v = 0; v < G2G_HDR; ++v) if (sh_n[v]) { sh_lo[v] = lo; lo += sh_n[v]; if (!cu_share_stream(ctx, sh_lo[v], sh_n[v])) shares = false; }
@@ -1326,7 +1349,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             const double gap_ms = rep[G2G_HDR + 41] * 1024. / ctx->rt_ticks_per_ms;
             ctx->n_gaps += rep[G2G_HDR + 40];
             if (gap_ms > ctx->max_gap_ms) ctx->max_gap_ms = gap_ms;
-            if (g2g_opt(ctx, "DEBUG") || g2g_opt(ctx, "WARN")) { fprintf(stderr, "[g2g] %d waiting wave(s) were off the machine for more than 4 ms at a stretch (longest %.1f ms); batch of %d DPs, %d wait(s) lost\n", rep[G2G_HDR + 40], gap_ms, b->n, rep[G2G_HDR]); fflush(stderr); }
+            if (g2g_opt(ctx, "DEBUG") || g2g_opt(ctx, "WARN")) { fprintf(stderr, "[g2g] %d waiting wave(s) were off the machine for more than 4 ms at a stretch (longest %.1f ms); batch of %d DPs, %d wait(s) lost; %zu CU-mask streams alive, %lld created\n", rep[G2G_HDR + 40], gap_ms, b->n, rep[G2G_HDR], ctx->mstream.size(), ctx->n_mstreams); fflush(stderr); }
         }
         if (rep[G2G_HDR]) {
             // Some wait ran into the wall-clock limit.  Only the DPs marked in the fail array are lost; they are re-run here, in
