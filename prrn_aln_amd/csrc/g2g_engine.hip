@@ -1177,9 +1177,15 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                             int v0 = -1, v1 = -1;
                             for (int v = 0; v < G2G_HDR; ++v) if (sh_n[v]) { if (v0 < 0) v0 = v; else v1 = v; }
                             if (v0 >= 0 && v1 >= 0 && sh_n[v0] + sh_n[v1] == 32) {
+                                // (once the context holds its fill of shares, the nearest one is taken whatever the distance: creating and
+                                //  destroying queues while launches are resident makes the scheduler rebuild its run list, which the waiting
+                                //  waves see as a pause of some 10 ms)
+                                size_t capm = 8;
+                                if (const char *e = g2g_opt(ctx, "MSTREAM_MAX")) { const int v = atoi(e); if (v >= 2 && v <= 64) capm = (size_t) v; }
+                                const int tol = ctx->mstream.size() + 2 > capm ? 32 : 1;
                                 int best = -1;
                                 for (const auto &m : ctx->mstream) {
-                                    if (m.lo != 0 || m.n < 1 || m.n > 31 || abs(m.n - sh_n[v0]) > 1) continue;
+                                    if (m.lo != 0 || m.n < 1 || m.n > 31 || abs(m.n - sh_n[v0]) > tol) continue;
                                     bool partner = false;
                                     for (const auto &q : ctx->mstream) if (q.lo == m.n && q.n == 32 - m.n) partner = true;
                                     if (partner && (best < 0 || abs(m.n - sh_n[v0]) < abs(best - sh_n[v0]))) best = m.n;
