@@ -333,8 +333,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     fwd_ms = tb_ms = 0.0
-    wait_timeouts, recovered_dps = [], []                 # per timed step: scheduler waits that ran into their limit / DPs re-run for it
-    cnt_before = ctx.counters()
+    wait_timeouts, recovered_dps, gaps_step = [], [], []  # per timed step: scheduler waits that ran into their limit / DPs re-run for it /
+    cnt_before = ctx.counters()                           # waiting waves that found themselves off the machine for > 4 ms
+    gaps_before = ctx.wait_gaps()[0]
     for _ in range(args.steps):
         out, gathered = step()
         f, t = batch.times_ms() if batch is not None else (0.0, 0.0)
@@ -343,6 +344,9 @@ def main():
         wait_timeouts.append(int(cnt_now["wait_timeouts"] - cnt_before["wait_timeouts"]))
         recovered_dps.append(int(cnt_now["recovered_dps"] - cnt_before["recovered_dps"]))
         cnt_before = cnt_now
+        g_now = ctx.wait_gaps()[0]
+        gaps_step.append(int(g_now - gaps_before))
+        gaps_before = g_now
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -471,7 +475,7 @@ def main():
                        "wait_timeouts": wait_timeouts, "recovered_dps": recovered_dps,
                        # ... and the stretches of more than 4 ms a waiting wave spent off the machine since the context was created
                        # (count, longest in ms: g2g_ctx_wait_gaps)
-                       "wait_gaps": list(ctx.wait_gaps()),
+                       "wait_gaps": list(ctx.wait_gaps()), "wait_gaps_per_timed_step": gaps_step,
                        # checksum of the last timed step's results (this rank's divisions): the same workload must give the same
                        # two numbers in every run, with or without a recovered time-out in it
                        "score_sum": float(sum(scr for (scr, _, st) in out if st == 0)),
