@@ -106,9 +106,14 @@ __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hd
 __device__ __forceinline__ bool g2g_dp_failed(const int *failp) { return __hip_atomic_load(failp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
 // Strip-boundary records cross workgroups (and XCDs: each has its own L2).  Plain accesses ordered by agent-scope release /
 // acquire fences cost a write-back of the whole L2 (buffer_wbl2) per publish and an invalidate (buffer_inv) per consumed
-// publish: 2-6 us each, which is most of a step when a handful of DPs publish every 4 steps (g2g_refine's windows).  With
-// G2G_NOFENCE the records themselves are written with agent-scope (write-through) stores and read with agent-scope loads, and
-// publishing is: wait for the stores, store the progress word.
+// publish -- from hundreds of workgroups, every few steps when a handful of DPs publish every 4 steps (g2g_refine's windows).
+// The records themselves are therefore written with agent-scope (write-through) stores and read with agent-scope loads, and
+// publishing is: wait for the stores, store the progress word -- no cache-maintenance operation in the step loop.  Measured
+// speed-neutral; adopted because the producers that were seen to stop stopped where a wave
+// can only be waiting for its own memory operations.  -DG2G_FENCE restores the fenced form.
+#ifndef G2G_FENCE
+#define G2G_NOFENCE 1
+#endif
 #ifdef G2G_NOFENCE
 #define G2G_XLD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define G2G_XST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
