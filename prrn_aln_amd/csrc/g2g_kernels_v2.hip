@@ -991,6 +991,10 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         __hip_atomic_store(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     need(cbase + 2);
+    if (prog_self && tid < 64) {                           // (the whole first wave, same value: no one-lane branch) where this strip runs: for the time-out report of whoever waits for it (g2g_wait_ge)
+        __hip_atomic_store(prog_self + 3, (int) __builtin_amdgcn_s_getreg((31 << 11) | 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(prog_self + 4, 0x100 | ((int) __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #ifdef G2G_V2_STAMP
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t = __builtin_amdgcn_s_memtime();

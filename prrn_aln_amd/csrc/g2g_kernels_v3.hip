@@ -698,6 +698,10 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
     if (lane < 28) stsc[lane] = 0;
     team_sync();
     need(cbase + 1 <= c1 ? cbase + 1 : cbase);
+    if (prog_self) {                                       // where this strip runs: for the time-out report of whoever waits for it (g2g_wait_ge)
+        __hip_atomic_store(prog_self + 3, (int) __builtin_amdgcn_s_getreg((31 << 11) | 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(prog_self + 4, 0x100 | ((int) __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     {
         unsigned rh = 0, rg = 0, rg2 = 0;
         stage_load(cbase, false, rh, rg, rg2);
