@@ -107,6 +107,9 @@ struct RandStateGuard {
 extern "C" g2g_ctx *g2g_create(int device)
 {
     RandStateGuard keep_host_rand;
+    // one hardware queue per concurrent persistent launch: HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES queues (4 by
+    // default) and reads the variable when it initialises -- which this call does if nothing in the process did before
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         g2g_set_error("%s", "no HIP device visible");
