@@ -1392,6 +1392,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                 add("; their producers per XCC:");
                 for (int k = 0; k < 8; ++k) add(" %d", x[32 + k] / 64);
                 add("; by RMW %d:%d, loaded again %d:%d", (x[46] >> 20) & 0x7FF, x[46] & 0xFFFFF, (x[47] >> 20) & 0x7FF, x[47] & 0xFFFFF);
+                add("; columns the producer's waves left at their last publish (v2 / v3 strips): %d %d %d %d", x[42], x[43], x[44], x[45]);
                 add("; waiting waves off the machine for > 4 ms at a stretch in this run: %d (longest %.1f ms)", x[40], x[41] * 1024. / ctx->rt_ticks_per_ms);
                 buf[o] = 0;
                 if (!b->is_retry || ctx->last_timeout.empty()) ctx->last_timeout = buf;

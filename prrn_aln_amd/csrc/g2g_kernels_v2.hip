@@ -95,6 +95,7 @@ __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hd
                     for (int k = 0; k < 256; ++k) __builtin_amdgcn_s_sleep(8);
                     hdr[18] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     hdr[19] = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int w = 0; w < 4; ++w) hdr[42 + w] = __hip_atomic_load(p + 8 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the producer's waves at their last publish (v2 / v3 strips)
                     hdr[8 + 38] = atomicAdd((int *) p, 0);          // the same word through a read-modify-write (executes at the coherent point)
                     hdr[8 + 39] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -987,6 +988,9 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         G2G_RELEASE();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // every wave leaves the column it publishes at before it enters the barrier (all lanes, same word, same value): if this
+        // workgroup ever stops here, the report of whoever waits for it shows which wave did not arrive (g2g_wait_ge, hdr[42..45])
+        __hip_atomic_store(prog_self + 8 + (tid >> 6), col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         __hip_atomic_store(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };

@@ -692,6 +692,7 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             G2G_RELEASE();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(prog_self + 8, col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (as the v2 strips: the wave's last publish, for the time-out report)
             __hip_atomic_store(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
