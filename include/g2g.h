@@ -140,7 +140,7 @@ typedef struct g2g_result {
 typedef struct g2g_ctx g2g_ctx;
 
 /* Create a context bound to one HIP device (device < 0: current device).  Returns NULL on failure.
-   Threading: a context (its streams, its pinned staging buffer and its spare device arena) serves ONE host thread at a
+   Threading: a context (its streams, its pinned staging buffer and its pool of device memory) serves ONE host thread at a
    time -- callers with several threads serialise their calls or batch them (integration/g2g_bind.cc does the latter);
    the group / PwdM builders (g2g_group_create, g2g_pwdm_create) touch only their own objects and may run on any
    number of threads.  g2g_last_error() is per thread.  One process per GPU: the persistent kernels poll flags
@@ -193,6 +193,17 @@ const char *g2g_ctx_last_timeout(const g2g_ctx *ctx);
    was off the machine (with, as a rule, the rest of its kernel) and counts 4 ms of it.  count = such gaps seen by waiting
    waves since g2g_create, longest_ms = the longest: zeros on an undisturbed device. */
 void      g2g_ctx_wait_gaps(const g2g_ctx *ctx, long long *count, double *longest_ms);
+/* The same over the whole PROCESS (every context, also destroyed ones): out[0] = batch runs, [1] = waits that gave up, [2] = DPs
+   re-run, [3] = of those on the non-polling kernel, [4] = gaps seen by waiting waves, [5] / [6] = the part of [1] / [2] that
+   came from batches prepared with the INJECT_STALL test hook, [7] reserved.  A host (or a test session: tests/conftest.py)
+   that wants a recovery to be an ERROR rather than a counter compares [2] with [6] at its end.  g2g_process_last_timeout copies
+   the report of the last event that was NOT injected into buf (NUL-terminated, truncated to cap) and returns its full length. */
+void      g2g_process_counters(long long out[8]);
+size_t    g2g_process_last_timeout(char *buf, size_t cap);
+/* Device memory is owned by the context (a pool of blocks that batches take from and give back to): out[0] = hipMalloc calls
+   made for it since g2g_create, [1] = hipFree calls, [2] = requests served from the pool, [3] = bytes free in the pool now.
+   A steady-state loop (a refinement: one batch per window) shows [0] standing still. */
+void      g2g_ctx_mem_counters(const g2g_ctx *ctx, long long out[4]);
 void      g2g_batch_free(g2g_batch *b);
 
 /* stdskl(): sort + normalise a raw traceback into ascending unique corners (reference src/gaps.cc:139).

@@ -206,6 +206,8 @@ int ref_init_prrn(int molc, int ls, int sh)
 }
 
 void ref_set_tgapf(double f) {alprm.tgapf = (float) f;}
+// gap extension / opening penalties as -u / -v set them (alprm is read by Fwd2d / PwdB at construction)
+void ref_set_uv(double u, double v) {alprm.u = (float) u; alprm.v = (float) v;}
 void ref_set_band(int bnd) {algmode.bnd = bnd? 1: 0;}
 void ref_set_quick(int q) {algmode.qck = q;}
 // per-cell trace of forwardB to stdout: "m n dir H diag G F1 [G2 F2]" (fwd2c.h:454-464)

@@ -56,6 +56,12 @@ def lib():
     L.g2g_align2_score_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int), C.c_int,
                                          C.POINTER(C.c_double), C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                          C.POINTER(_abi.Fstat), C.POINTER(_abi.Fstat)]
+    L.g2g_process_counters.restype = None
+    L.g2g_process_counters.argtypes = [C.POINTER(C.c_longlong)]
+    L.g2g_process_last_timeout.restype = C.c_size_t
+    L.g2g_process_last_timeout.argtypes = [C.c_char_p, C.c_size_t]
+    L.g2g_ctx_mem_counters.restype = None
+    L.g2g_ctx_mem_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     L.g2g_ctx_wait_gaps.restype = None
     L.g2g_ctx_wait_gaps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
     L.g2g_batch_spscore.argtypes = [C.c_void_p, C.POINTER(_abi.SpParams), C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int), C.POINTER(_abi.Fstat)]

@@ -59,8 +59,13 @@ def _unit_stale(unit) -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in _deps(unit))
 
 
+def _flags_changed() -> bool:
+    stamp = " ".join(FLAGS + _extra())
+    return not os.path.exists(_flags_stamp()) or open(_flags_stamp()).read() != stamp
+
+
 def stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or _flags_changed():     # (G2G_EXTRA_FLAGS=... python -m prrn_aln_amd.build must rebuild)
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.exists(d) and os.path.getmtime(d) > t for u in UNITS for d in _deps(u))
@@ -73,7 +78,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     flags = FLAGS + _extra()
     stamp = " ".join(flags)
-    if not os.path.exists(_flags_stamp()) or open(_flags_stamp()).read() != stamp:
+    if _flags_changed():
         force = True                                        # other flags than the objects were built with: everything again
     todo = [u for u in UNITS if force or _unit_stale(u)]
 

@@ -54,6 +54,13 @@ class Context:
         lib().g2g_ctx_wait_gaps(self._h, C.byref(n), C.byref(ms))
         return n.value, ms.value
 
+    def mem_counters(self) -> dict:
+        """g2g_ctx_mem_counters: hipMalloc / hipFree calls made for the context's device-memory pool, requests served from it,
+        bytes free in it"""
+        out = (C.c_longlong * 4)()
+        lib().g2g_ctx_mem_counters(self._h, out)
+        return {"hip_malloc": out[0], "hip_free": out[1], "pool_hits": out[2], "pool_free_bytes": out[3]}
+
     def close(self):
         if self._h:
             lib().g2g_destroy(self._h)
@@ -187,3 +194,19 @@ def stdskl(trace: np.ndarray) -> np.ndarray:
         if nout.value else np.zeros((0, 2), np.int32)
     L.g2g_free(p)
     return out
+
+
+def process_counters() -> dict:
+    """g2g_process_counters: the scheduler's counters over every context this process has had (destroyed ones included)"""
+    out = (C.c_longlong * 8)()
+    lib().g2g_process_counters(out)
+    return {"runs": out[0], "wait_timeouts": out[1], "recovered_dps": out[2], "recovered_on_v1": out[3], "wait_gaps": out[4],
+            "injected_timeouts": out[5], "injected_recovered_dps": out[6]}
+
+
+def process_last_timeout() -> str:
+    """the report of the process's last time-out that no test hook injected ("" if none)"""
+    n = lib().g2g_process_last_timeout(None, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib().g2g_process_last_timeout(buf, n + 1)
+    return buf.value.decode()

@@ -13,7 +13,12 @@ GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "dist"
 
 
 def test_fixtures_present():
-    assert len(GOLD) >= 7
+    assert len(GOLD) >= 12
+    # the branches of Fwd2d's boundary / lastD (fwd2d1.cc:58-134) need fixtures of their own: discounted terminal gaps
+    # (tgapf < 1, incl. 0) and penalties whose partial sums round
+    tg = {os.path.basename(p): float(np.load(p)["tgapf"][0]) for p in GOLD}
+    assert sum(1 for v in tg.values() if 0 < v < 1) >= 3 and any(v == 0 for v in tg.values())
+    assert any(float(np.load(p)["u"][0]) not in (2.0,) for p in GOLD)
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])

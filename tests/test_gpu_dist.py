@@ -46,9 +46,17 @@ def test_distance_matrix_matches_reference_dpscore(ctx):
         assert np.array_equal(dist, 100.0 * d["dist"]), path
 
 
-@pytest.mark.parametrize("case", ["prot", "dna", "ragged"])
+@pytest.mark.parametrize("case", ["prot", "dna", "ragged", "ragged_tgapf05", "ragged_uv_tgapf03", "dna_tgapf05_ls3"])
 def test_larger_families_vs_oracle(ctx, case):
-    g = dict(np.load([p for p in GOLD if ("dna" in p) == (case == "dna")][0]))        # parameters + matrix of the molecule type
+    """(the last three take their parameters from the fixtures with discounted terminal gaps / non-dyadic penalties: walks of
+    several hundred cells through dist_tail_walk and the accumulating branch of dist_edge, reference src/fwd2d1.cc:58-134)"""
+    pick = {"ragged_tgapf05": "prot8_tgapf05", "ragged_uv_tgapf03": "prot8_u21_v93_tgapf03", "dna_tgapf05_ls3": "dna8_tgapf05_ls3"}.get(case)
+    if pick:
+        g = dict(np.load([p for p in GOLD if os.path.basename(p) == pick + ".npz"][0]))
+        assert float(g["tgapf"][0]) < 1
+        case = "dna" if "dna" in case else "ragged"
+    else:
+        g = dict(np.load([p for p in GOLD if ("dna" in p) == (case == "dna") and float(np.load(p)["tgapf"][0]) == 1 and float(np.load(p)["u"][0]) == 2][0]))        # parameters + matrix of the molecule type
     if case == "dna":
         fam = make_family(40, 700, 51, alphabet=DNA, indel=0.03, max_indel=30)
     else:

@@ -22,10 +22,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 GOLD = os.path.join(ROOT, "tests", "golden", "dist")
 
 
-def run(name, molc, ls, sh, tgapf, seqs):
+def run(name, molc, ls, sh, tgapf, seqs, uv=None):
     import refdump
     R = refdump.RefLib(molc=molc, ls=ls, sh=sh, tgapf=tgapf)
     L = R.lib
+    if uv is not None:                   # non-dyadic penalties: partial sums of the boundary ramps round (Fwd2d ctor, fwd2d1.cc:58-98)
+        L.ref_set_uv.argtypes = [C.c_double, C.c_double]
+        L.ref_set_uv(*uv)
     L.ref_seq_read.restype = C.c_void_p
     L.ref_seq_read.argtypes = [C.c_char_p]
     L.ref_seq_len.argtypes = [C.c_void_p]
@@ -99,6 +102,14 @@ JOBS = {
     "prot_ragged": lambda: run("prot_ragged", 1, 0, 0, None, [s[: 40 + 23 * k] for k, s in enumerate(synth(8, 260, 12, indel=0.03))]),
     "prot_unbanded": lambda: run("prot8_sh100", 1, 0, -100, None, synth(8, 150, 13, indel=0.06, max_indel=25)),
     "prot_tgapf": lambda: run("prot8_tgapf1", 1, 0, 0, 1.0, synth(8, 140, 14, indel=0.05)),
+    # terminal gaps at half price / free: Fwd2d::lastD's walks (fwd2d1.cc:100-134) and the scaled ramps; ragged lengths so that
+    # the optimal path ends in long terminal gaps
+    "prot_tgapf05": lambda: run("prot8_tgapf05", 1, 0, 0, 0.5, [s[: 50 + 17 * k] for k, s in enumerate(synth(8, 200, 17, indel=0.05))]),
+    "prot_tgapf0": lambda: run("prot8_tgapf0", 1, 0, 0, 0.0, [s[(5 * k) % 30: 60 + 19 * k] for k, s in enumerate(synth(8, 220, 18, indel=0.05))]),
+    "dna_tgapf05_ls3": lambda: run("dna8_tgapf05_ls3", 2, 3, 0, 0.5, [s[: 70 + 21 * k] for k, s in enumerate(synth(8, 240, 19, alphabet="dna", indel=0.04))]),
+    # penalties that are not dyadic rationals: the ramps' partial sums round, the closed form no longer applies
+    "prot_uv": lambda: run("prot8_u21_v93", 1, 0, 0, None, synth(8, 160, 20, indel=0.05), uv=(2.1, 9.3)),
+    "prot_uv_tgapf": lambda: run("prot8_u21_v93_tgapf03", 1, 0, 0, 0.3, [s[: 45 + 16 * k] for k, s in enumerate(synth(8, 180, 21, indel=0.05))], uv=(2.1, 9.3)),
     "prot_ls3": lambda: run("prot8_ls3", 1, 3, 0, None, synth(8, 200, 15, indel=0.05, max_indel=40)),
     "dna": lambda: run("dna10_sh60", 2, 0, 0, None, synth(10, 240, 16, alphabet="dna", indel=0.03)),
     "pas": lambda: run("pas_native", 1, 0, 0, None, fasta_members("/root/reference/sample/pas/native_A") + fasta_members("/root/reference/sample/pas/native_B")),
