@@ -204,7 +204,7 @@ def refinement_readout(ctx, args):
     refine_native(ctx, start, tree, ralp, seed=1, maxitr=1, window=2) if not use_big else None      # (warm: first use of the small-batch paths)
     c0 = ctx.counters()
     t1 = time.perf_counter()
-    # (g2g_refine starts every window of the big family at 8 speculative divisions, of the small one at 2: g2g_refine.cpp)
+    # (g2g_refine starts every window of the big family at 16 speculative divisions, of the small one at 4: g2g_refine.cpp)
     final, rsteps, rstats = refine_native(ctx, start, tree, ralp, seed=1, maxitr=10, window=16)
     rt = time.perf_counter() - t1
     c1 = ctx.counters()

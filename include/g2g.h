@@ -339,7 +339,7 @@ typedef struct g2g_refine_opts {
     void   *scorer_user;
     g2g_accept_fn on_accept;        /* optional: told about every accepted move, in order (what synthgap applies, src/prrn5.cc:536-541) */
     void   *on_accept_user;
-    int32_t window_min, reserved;   /* window after an accepted move (default: 8 for MSAs of 2048 columns or more, else 2); it doubles up
+    int32_t window_min, reserved;   /* window after an accepted move (default: 16 when len x len >= 2^22 -- MSAs of 2048 columns or more --, else 4); it doubles up
                                        to `window` while nothing is accepted */
 } g2g_refine_opts;
 typedef struct g2g_refine_step {

@@ -122,7 +122,10 @@ extern "C" g2g_ctx *g2g_create(int device)
     RandStateGuard keep_host_rand;
     // one hardware queue per concurrent persistent launch: HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES queues (4 by
     // default) and reads the variable when it initialises -- which this call does if nothing in the process did before
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // (setenv is not safe against a concurrent getenv in another thread: a multithreaded host either sets GPU_MAX_HW_QUEUES
+    //  itself before it starts its threads -- the Python loader does -- or calls g2g_create before it starts them; the variable
+    //  is only written here when it is unset)
+    if (!getenv("GPU_MAX_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         g2g_set_error("%s", "no HIP device visible");
@@ -1469,7 +1472,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             if (b->injected) { g_tot[5] += rep[G2G_HDR]; g_tot[6] += (long long) lost.size(); }
             {   // the report of the event: kept in the context (g2g_ctx_last_timeout: every ordinary run that meets one carries the
                 // evidence), printed under WARN / DEBUG
-                char buf[2048];
+                char buf[3072];
                 int o = 0;
                 auto add = [&](const char *fmt, ...) { va_list ap; va_start(ap, fmt); if (o < (int) sizeof buf - 1) { const int w = vsnprintf(buf + o, sizeof buf - o, fmt, ap); if (w > 0) o += w; } va_end(ap); if (o > (int) sizeof buf - 1) o = (int) sizeof buf - 1; };
                 int kinds[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1490,6 +1493,14 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                 for (int k = 0; k < 8; ++k) add(" %d", x[32 + k] / 64);
                 add("; by RMW %d:%d, loaded again %d:%d", (x[46] >> 20) & 0x7FF, x[46] & 0xFFFFF, (x[47] >> 20) & 0x7FF, x[47] & 0xFFFFF);
                 add("; columns the producer's waves left at their last publish (v2 / v3 strips): %d %d %d %d", x[42], x[43], x[44], x[45]);
+                {   // -DG2G_HEARTBEAT builds: (step, place) of up to four waves of a v2 / v3 producer, twice, 50 us apart (all zero otherwise)
+                    bool any = false;
+                    for (int k = 48; k < 64; ++k) if (x[k]) any = true;
+                    if (any) {
+                        add("; producer's waves (step:place, then 50 us later):");
+                        for (int w = 0; w < 4; ++w) add(" w%d %d:%d -> %d:%d", w, x[48 + 2 * w], x[49 + 2 * w], x[56 + 2 * w], x[57 + 2 * w]);
+                    }
+                }
                 add("; waiting waves off the machine for > 4 ms at a stretch in this run: %d (longest %.1f ms)", x[40], x[41] * 1024. / ctx->rt_ticks_per_ms);
                 buf[o] = 0;
                 if (!b->is_retry || ctx->last_timeout.empty()) ctx->last_timeout = buf;

@@ -610,10 +610,18 @@ extern "C" g2g_pwdm *g2g_pwdm_create(g2g_ctx *, const g2g_params *prm, g2g_group
     const int active = builders_active.fetch_add(1) + 1;
     const unsigned cores = std::thread::hardware_concurrency();
     const bool split = !getenv("G2G_NO_BUILD_SPLIT") && (size_t) a.many * a.len + (size_t) b.many * b.len >= 100000 && cores >= 4 && (unsigned) active * 3 <= cores;
+    // (std::thread's constructor throws std::system_error when the process is out of threads; nothing may cross the C ABI: a
+    //  task whose helper could not be started runs in line)
+    bool ran_a = false, ran_b = false;
     if (split) {
-        std::thread t1(task_vec_a), t2(task_b);
+        std::thread t1, t2;
+        try { t1 = std::thread(task_vec_a); ran_a = true; } catch (...) {}
+        try { t2 = std::thread(task_b); ran_b = true; } catch (...) {}
         task_gfq_a();
-        t1.join(); t2.join();
+        if (!ran_a) task_vec_a();
+        if (!ran_b) task_b();
+        if (t1.joinable()) t1.join();
+        if (t2.joinable()) t2.join();
     } else { task_gfq_a(); task_vec_a(); task_b(); }
     builders_active.fetch_sub(1);
     if (host_times) fprintf(stderr, "[g2g_pwdm_create] a %d x %d, b %d x %d: %.2f ms (%s: gap profile of a %.2f, vectors of a %.2f, b %.2f)\n", a.many, a.len, b.many, b.len, tnow() - tb0, split ? "three tasks" : "in line", tt[0], tt[1], tt[2]);

@@ -43,7 +43,7 @@ static __device__ unsigned long long g2g_stamp_acc[16];      // (one copy per tr
 #define G2G_FSTRIDE 32               // ints between two tile flags / progress words: one 128-byte line each, so that no two workgroups (in
                                      // different XCDs, behind different L2s) ever store into the same line
 #define G2G_GAP_TICKS 400000ull       // 4 ms of s_memrealtime: more than ten times what 64 polls take
-#define G2G_HDRN 48                  // header words: 4 + the snapshot (want, seen, offset of the polled word, the 40 words at and below it)
+#define G2G_HDRN 72                  // header words: 4 + the snapshot (want, seen, offset of the polled word, the words at and below it; [48, 64): per-wave heartbeats); G2G_HDR + G2G_HDRN is a multiple of G2G_FSTRIDE, so every progress line IS one 128-byte line
 __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hdr, int *failp, const int slot)
 {
     int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -92,10 +92,15 @@ __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hd
                     // progress word), read twice 50 us apart: is the producer running, and where?
                     hdr[16] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     hdr[17] = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int w = 0; w < 8; ++w) hdr[56 + w] = __hip_atomic_load(p + 12 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     for (int k = 0; k < 256; ++k) __builtin_amdgcn_s_sleep(8);
                     hdr[18] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     hdr[19] = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     for (int w = 0; w < 4; ++w) hdr[42 + w] = __hip_atomic_load(p + 8 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the producer's waves at their last publish (v2 / v3 strips)
+                    // per-wave heartbeats of a v2 / v3 producer (builds with -DG2G_HEARTBEAT: (step, place) of each of its waves,
+                    // G2G_HB below), read now and once more behind the 50 us above: which wave stands still, and where
+                    for (int w = 0; w < 8; ++w) hdr[48 + w] = hdr[56 + w];
+                    for (int w = 0; w < 8; ++w) hdr[56 + w] = __hip_atomic_load(p + 12 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     hdr[8 + 38] = atomicAdd((int *) p, 0);          // the same word through a read-modify-write (executes at the coherent point)
                     hdr[8 + 39] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -125,6 +130,19 @@ __device__ __forceinline__ bool g2g_dp_failed(const int *failp) { return __hip_a
 #define G2G_XST(p, v) (*(p) = (v))
 #define G2G_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #define G2G_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#endif
+// Passive producer-side heartbeat of the v2 / v3 strips (build with G2G_EXTRA_FLAGS=-DG2G_HEARTBEAT, which also turns on the v6
+// strips' G2G_V6_HEARTBEAT): every wave of a strip keeps (step, place in the step) in words 12 + 2 w / 13 + 2 w of the strip's
+// progress line; whoever times out waiting for the strip copies them into its report twice, 50 us apart (g2g_wait_ge,
+// hdr[48..63]) -- the report then names the wave that stands still and the place it stands at.  Off by default: a handful of
+// write-through stores per step and wave.  Places (v2): 1 top of the step, 2 publish entered, 3 behind the publish barrier,
+// 4 waiting for the strip above, 5 behind the column-score block, 6 sources staged, 7 cell done, 8 at the step's barrier.
+#ifdef G2G_HEARTBEAT
+#define G2G_HB_STEP(pself, w, s) { if (pself) __hip_atomic_store((pself) + 12 + 2 * (w), (int) (s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define G2G_HB(pself, w, k) { if (pself) __hip_atomic_store((pself) + 13 + 2 * (w), (int) (k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+#define G2G_HB_STEP(pself, w, s)
+#define G2G_HB(pself, w, k)
 #endif
 #define DL_GUARD 128                         // no list is this long: a corrupted one must not hang the wave
 
@@ -991,7 +1009,9 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         // every wave leaves the column it publishes at before it enters the barrier (all lanes, same word, same value): if this
         // workgroup ever stops here, the report of whoever waits for it shows which wave did not arrive (g2g_wait_ge, hdr[42..45])
         __hip_atomic_store(prog_self + 8 + (tid >> 6), col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        G2G_HB(prog_self, tid >> 6, 2)
         __syncthreads();
+        G2G_HB(prog_self, tid >> 6, 3)
         __hip_atomic_store(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     need(cbase + 2);
@@ -1008,12 +1028,16 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         STAMP(7)
         const int n = cbase + s - team;
         const bool active = row_ok && n >= lo && n < hi;
+        G2G_HB_STEP(prog_self, tid >> 6, s)
+        G2G_HB(prog_self, tid >> 6, 1)
         if (prog_self && s > 0 && (s & (pint - 1)) == 0) publish(cbase + s - tl);
+        G2G_HB(prog_self, tid >> 6, 4)
         need(cbase + s + 2);
         if (own_sim && (s & 63) == 0) {                    // the block the first row enters 64 steps from now; visible to the
             simblk_fill(P, SB, (s >> 6) + 1, m0, tid, blockDim.x, R);      // whole workgroup long before (a barrier every step)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        G2G_HB(prog_self, tid >> 6, 5)
         double sim_nx = 0, bc_nx = 0;
         if (active) {
             if (!have) { sim_cur = own_sim ? (double) *simblk_at(SB, team, n) : simrow[n]; bc_cur = thk_at(b, n)[0]; }
@@ -1105,6 +1129,7 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
             diag_rows(d, a.left, a.right, b.left, b.right, P.lw, P.up, &mlo, &mhi);
             uint8_t *tr = P.trace + (size_t) (d - P.d0) * P.tstride + (m - mlo);
             STAMP(1)
+            G2G_HB(prog_self, tid >> 6, 6)
             const double pua = a.nils ? unpa(P, m, n) : pua_row;
             const double pub = bc_cur * a_efq * -P.u;                       // unp1(bsi, asi), maln.h:185-187
             v2_cell<KIND, NOLL3>(P, G, L, m, n, lane, S, D, do_vert, do_hori, tr, sim_cur, pua, pub
@@ -1113,6 +1138,7 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
 #endif
                                  );
             STAMP(5)
+            G2G_HB(prog_self, tid >> 6, 7)
             sim_cur = sim_nx; bc_cur = bc_nx; have = (n + 1 < hi);
             // the row below starts at b.left with the left-boundary corner (m+1, b.left) as its
             // diagonal source: park it in this row's H ring where that row will look for it
@@ -1153,6 +1179,7 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         if (++rslot == RC) rslot = 0;
         if (++wslot == RC) wslot = 0;
         STAMP(6)
+        G2G_HB(prog_self, tid >> 6, 8)
         __syncthreads();
     }
     if (prog_self) publish(0xFFFFF);

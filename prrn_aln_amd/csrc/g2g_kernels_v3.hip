@@ -771,8 +771,11 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
         if (st_prev) stage_store(n0 + 1, vert0, st_h, st_g, st_g2);
         if (p_act) P.trace[p_tri] = (uint8_t) p_trb;
         if (wr_rows && s > 0) flush_rows(n0 - 1 - llast);
+        G2G_HB_STEP(prog_self, 0, s)                       // (places, v3: 1 top of the step, 5 behind publish / score block, 6 loads issued, 7 cell done)
+        G2G_HB(prog_self, 0, 1)
         if (prog_self && s > 0 && (s & (pint - 1)) == 0) publish(n0 - llast);
         if (own_sim && !sim_direct && (s & 63) == 0) { simblk_fill(P, SB, (s >> 6) + 1, m0, lane); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        G2G_HB(prog_self, 0, 5)
         // -- hand-over from the row above: what lane t-1 produced one step ago is my upper neighbour, what it
         // produced two steps ago (= my previous upper neighbour) is my diagonal neighbour
         hd = hu;

@@ -643,7 +643,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
 // diagnostic heartbeat (build with -DG2G_V6_HEARTBEAT): step counter and a marker of the place in the step, stored next to the
 // strip's progress word; the report of a time-out reads them (g2g_wait_ge).  Off by default: ten 4-byte write-through stores
 // per step are ~30 GB/s of fabric traffic for nothing.
-#ifdef G2G_V6_HEARTBEAT
+#if defined(G2G_V6_HEARTBEAT) || defined(G2G_HEARTBEAT)
 #define V6_MARK(k) { if (prog_self) __hip_atomic_store(prog_self + 2, (k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #define V6_BEAT(s) { if (prog_self) __hip_atomic_store(prog_self + 1, (s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #else
