@@ -290,9 +290,19 @@ def main():
     else:
         fam = make_family(args.nseq, args.length, args.seed)
         alp = op.AlnParam()
-    sw = sweep.Sweep(fam, alp, weighted=True, limit=args.limit or None)
-    mine = sweep.shard(sw.order, args.shard_of, 0) if args.shard_of > 1 and world == 1 else sweep.shard(sw.order, world, rank)
     ctx = engine.Context(local_rank)
+    # the divisions' inputs: groups split out of the MSA on host threads, then thickness / vectors / gap profiles of all 1018 groups
+    # built on the DEVICE in one batch (g2g_pwdm_create_batch, csrc/g2g_build.hip: SURVEY section 8 rows a8 / a9).  Outside the timed
+    # region; reported as config.builders (with the host builders timed beside them at N = 1).
+    sw = sweep.Sweep(fam, alp, weighted=True, limit=args.limit or None, ctx=ctx)
+    builders = {"groups_split_ms": 1e3 * sw.t_split, "device_batch_ms": 1e3 * sw.t_batch, "groups": 2 * len(sw)}
+    if world == 1 and not args.shard_of and not args.no_cpu:
+        t1 = time.perf_counter()
+        sw_host = sweep.Sweep(fam, alp, weighted=True, limit=args.limit or None)
+        builders["host_threads_ms_incl_split"] = 1e3 * (time.perf_counter() - t1)
+        builders["host_threads"] = min(16, os.cpu_count() or 1)
+        del sw_host
+    mine = sweep.shard(sw.order, args.shard_of, 0) if args.shard_of > 1 and world == 1 else sweep.shard(sw.order, world, rank)
     holders = [sw.pwds[k] for k in mine]
 
     # inputs resident in HBM before the timed region
@@ -469,7 +479,7 @@ def main():
                                       sum(1 for p in sw.pwds if p.alnmode in (7, 8)),
                                       sum(1 for p in sw.pwds if p.alnmode == 9), total_cells),
                        "divisions": len(sw), "cells_per_step": total_cells, "parallelism": "divisions round-robin by size over %d GPU(s)" % world,
-                       "failed_items": bad, "align2_batch_from_host_ms": e2e_ms,
+                       "failed_items": bad, "align2_batch_from_host_ms": e2e_ms, "builders": builders,
                        # every run is evidence about the scheduler's waits: per timed step, the waits that ran into
                        # their wall-clock limit and the DPs re-run because of it (rank 0's share); an ordinary run shows zeros
                        "wait_timeouts": wait_timeouts, "recovered_dps": recovered_dps,

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define G2G_ABI_VERSION 4
+#define G2G_ABI_VERSION 5
 
 /* error codes (negative) */
 enum {
@@ -101,7 +101,19 @@ typedef struct g2g_side {
     const double  *pfq_dns;
     double         sumwt;           /* Seq::sumwt: sum of the members' weights (the member count when unweighted); read by the
                                        PwdM::stt?? statistics (van / vbn and the thickness of the zero iterators)          */
+    /* ABI 5: device-resident twins of the arrays above (same contents, in the HBM of the context that built them:
+       g2g_pwdm_create_batch builds a group's derived arrays on the device and leaves them there).  NULL for a side that lives on
+       the host only.  A batch prepared from such a side reads the twins where they lie -- nothing is packed or uploaded for them --
+       so the objects that own them (the g2g_group behind the g2g_pwdm) must outlive the batch, like the host arrays. */
+    const struct g2g_side_dev *dev;
 } g2g_side;
+typedef struct g2g_side_dev {
+    const struct g2g_ctx *ctx;      /* the twins are addresses in THIS context's device                                      */
+    const uint8_t *seq;
+    const double  *weight, *pseq, *thk;
+    const int32_t *off[3], *glen[3];
+    const double  *freq[3];
+} g2g_side_dev;
 
 typedef struct g2g_problem {
     int32_t  alnmode;               /* G2G_*_ALB / _ALN                                            */
@@ -238,6 +250,12 @@ void       g2g_group_free(g2g_group *g);
 /* <-> PwdM::PwdM(mSeq** seqs, const ALPRM*) (src/maln2.cc:254): selects alnmode, swaps so the
    profile side is `a`, builds thickness / vectors / gap profiles.  *swapped receives PwdM::swp. */
 g2g_pwdm  *g2g_pwdm_create(g2g_ctx *ctx, const g2g_params *prm, g2g_group *a, g2g_group *b, int *swapped);
+/* n PwdMs at once with the derived arrays of all their groups -- column thickness (mSeq::mkthick, src/mseq.cc:149-354), frequency /
+   profile vectors (mSeq::convseq, src/mseq.cc:392-587) and static gap profiles (Gfq::Gfq / seq2gfq, src/gfreq.cc:134-312) -- built
+   ON THE DEVICE in one go (csrc/g2g_build.hip): what a sweep over hundreds of divisions wants.  Same objects and, bit for bit, the
+   same arrays as n calls of g2g_pwdm_create (tests/test_gpu_builders.py).  Groups with nil codes (tgapf < 1) are built on the
+   host inside the same call.  swapped (n ints) may be NULL.  On failure nothing is handed out. */
+int        g2g_pwdm_create_batch(g2g_ctx *ctx, const g2g_params *prm, int n, g2g_group *const *a, g2g_group *const *b, int *swapped, g2g_pwdm **out);
 void       g2g_pwdm_free(g2g_pwdm *p);
 const g2g_problem *g2g_pwdm_problem(const g2g_pwdm *p);
 

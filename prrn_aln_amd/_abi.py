@@ -29,7 +29,8 @@ class Side(C.Structure):
                 ("has_gfq", C.c_int32), ("gfq", GapProf),
                 ("gapdens", c_f64p), ("postgapdens", c_f64p),
                 ("npfq", C.c_int32), ("pfq_step", C.c_int32), ("pfq_pos", C.POINTER(C.c_int32)), ("pfq_dns", c_f64p),
-                ("sumwt", C.c_double)]
+                ("sumwt", C.c_double),
+                ("dev", C.c_void_p)]                # ABI 5: device-resident twins (g2g_side_dev), NULL for host-only sides
 
 
 class Problem(C.Structure):

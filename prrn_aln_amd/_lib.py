@@ -93,6 +93,7 @@ def bind_level1(L):
     L.g2g_group_free.argtypes = [C.c_void_p]
     L.g2g_pwdm_create.restype = C.c_void_p
     L.g2g_pwdm_create.argtypes = [C.c_void_p, C.POINTER(_abi.Params), C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    L.g2g_pwdm_create_batch.argtypes = [C.c_void_p, C.POINTER(_abi.Params), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
     L.g2g_pwdm_free.argtypes = [C.c_void_p]
     L.g2g_pwdm_problem.restype = C.POINTER(_abi.Problem)
     L.g2g_pwdm_problem.argtypes = [C.c_void_p]

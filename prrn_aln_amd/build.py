@@ -19,12 +19,12 @@ HDR = [os.path.join(os.path.dirname(HERE), "include", "g2g.h"), os.path.join(CSR
 _K1, _K2, _K3 = "g2g_kernels.hip", "g2g_kernels_v2.hip", "g2g_kernels_v3.hip"
 # unit -> (source, files it includes besides the headers)
 UNITS = {
-    "engine": ("g2g_engine.hip", [_K1, _K2, _K3, "g2g_kernels_v6.hip", "g2g_kernels_v7.hip", "g2g_kernels_v8.hip", "g2g_dist.hip", "g2g_pairaln.hip", "g2g_pairsum.hip"]),
+    "engine": ("g2g_engine.hip", [_K1, _K2, _K3, "g2g_kernels_v6.hip", "g2g_kernels_v7.hip", "g2g_kernels_v8.hip", "g2g_dist.hip", "g2g_pairaln.hip", "g2g_pairsum.hip", "g2g_build.hip", "g2g_group.h"]),
     "v2": ("g2g_tu_v2.hip", [_K1, _K2]),
     "v3": ("g2g_tu_v3.hip", [_K1, _K2, _K3]),
     "v6": ("g2g_tu_v6.hip", [_K1, _K2, _K3, "g2g_kernels_v6.hip"]),
     "v78": ("g2g_tu_v78.hip", [_K1, _K2, _K3, "g2g_kernels_v6.hip", "g2g_kernels_v7.hip", "g2g_kernels_v8.hip"]),
-    "host": ("g2g_host.cpp", []),
+    "host": ("g2g_host.cpp", ["g2g_group.h"]),
     "refine": ("g2g_refine.cpp", []),
 }
 

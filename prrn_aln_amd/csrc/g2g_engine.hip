@@ -12,6 +12,7 @@
 #include <thread>
 #include <atomic>
 #include <mutex>
+#include <memory>
 #include <algorithm>
 #include <chrono>
 #ifndef G2G_TU_ALL
@@ -69,6 +70,7 @@ struct g2g_ctx {
     std::vector<DevBlock> pool;     // free blocks
     long long n_dev_malloc, n_dev_free, n_pool_hits;   // hipMalloc / hipFree calls made for the pool, requests served from it
     int ncu;                        // compute units of the device
+    std::shared_ptr<int> alive;     // 1 while the context exists: device slabs that outlive it (twins held by g2g_group objects) free themselves
     long long n_runs, n_timeouts, n_recovered, n_v1;   // g2g_ctx_counters: batch runs, waits that ran into the limit, DPs re-run, of those on v1
     struct MStream { int lo, n; hipStream_t s; unsigned long long used; };
     std::vector<MStream> mstream;   // streams confined to a share of the CUs (units lo .. lo + n - 1 of 32; see cu_share_stream)
@@ -139,6 +141,7 @@ extern "C" g2g_ctx *g2g_create(int device)
     c->ok = 0;
     c->stage = 0; c->stage_cap = 0;
     c->n_dev_malloc = c->n_dev_free = c->n_pool_hits = 0; c->ncu = 256;
+    c->alive = std::make_shared<int>(1);
     c->n_runs = c->n_timeouts = c->n_recovered = c->n_v1 = 0;
     c->n_gaps = 0; c->max_gap_ms = 0; c->n_mstreams = 0;
     c->sp_slots = 0; c->sp_slots_cap = 0;
@@ -189,15 +192,39 @@ extern "C" g2g_ctx *g2g_create(int device)
 extern "C" void g2g_destroy(g2g_ctx *c)
 {
     if (!c) return;
+    // G2G_LOG_FILE (plain environment): the phases of the tear-down with their times, appended to that file (a test runner captures
+    // stderr; a tear-down that does not come back must still say where it stands)
+    FILE *lf = getenv("G2G_LOG_FILE") ? fopen(getenv("G2G_LOG_FILE"), "a") : 0;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!lf) return;
+        fprintf(lf, "[g2g destroy %p] %-22s %8.1f ms\n", (void *) c, what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        fflush(lf);
+    };
     hipSetDevice(c->device);
+    lap("begin");
+    // Order: everything idle first; then the MEMORY goes while every stream it was ever used on still exists (hipFree waits for the
+    // device: round 4 saw tear-downs that never came back when some fifty pool blocks were freed behind destroyed CU-mask streams);
+    // the streams and events last.
+    hipDeviceSynchronize();
+    lap("device idle");
+    *c->alive = 0;
+    for (auto &bk : c->pool) hipFree(bk.p);
+    c->pool.clear();
+    if (c->sp_slots) hipFree(c->sp_slots);
+    lap("device pool");
+    if (c->stage) hipHostFree(c->stage);
+    lap("pinned staging");
     for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
     for (int i = 0; i < G2G_NVS + 1; ++i) hipEventDestroy(c->vev[i]);
-    for (int i = 0; i < G2G_NVS; ++i) hipStreamDestroy(c->vstream[i]);
+    lap("events");
     for (auto &m : c->mstream) hipStreamDestroy(m.s);
+    lap("CU-share streams");
+    for (int i = 0; i < G2G_NVS; ++i) hipStreamDestroy(c->vstream[i]);
+    lap("launch streams");
     hipStreamDestroy(c->stream);
-    if (c->stage) hipHostFree(c->stage);
-    for (auto &bk : c->pool) hipFree(bk.p);
-    if (c->sp_slots) hipFree(c->sp_slots);
+    lap("main stream");
+    if (lf) fclose(lf);
     delete c;
 }
 
@@ -548,16 +575,28 @@ static int check_problem(const g2g_problem *p)
 template <class T> static inline T *OFF(size_t off) { return (T *) (uintptr_t) (off + 1); }   // +1: 0 stays NULL
 template <class T> static inline void rebase(T *&p, char *base) { if (p) p = (T *) (base + ((uintptr_t) p - 1)); }
 
-static void pack_side(Blob &bl, const g2g_side &s, DevSide &d, int kind, bool need_gfq)
+// An array that already lives in this context's HBM (g2g_side::dev, left there by g2g_device_derive) is not packed: the
+// descriptor field gets the twin's address once the arena's offsets have been rebased (Patch list).
+struct DevPatch { const void **field; const void *value; };
+template <class T> static inline bool use_twin(std::vector<DevPatch> &patches, const T *&field, const T *twin)
+{
+    if (!twin) return false;
+    field = 0;
+    DevPatch p = {(const void **) &field, (const void *) twin};
+    patches.push_back(p);
+    return true;
+}
+static void pack_side(Blob &bl, const g2g_side &s, DevSide &d, int kind, bool need_gfq, std::vector<DevPatch> &patches)
 {
     memset(&d, 0, sizeof d);
+    const g2g_side_dev *tw = (s.dev && s.dev->ctx == bl.owner && !g2g_opt(bl.owner, "NO_RESIDENT_INPUTS")) ? s.dev : 0;
     d.many = s.many; d.len = s.len; d.left = s.left; d.right = s.right; d.nils = s.nils;
     d.nelm = s.nelm; d.felm = s.felm; d.sumwt = s.sumwt > 0 ? s.sumwt : (double) s.many;
     const size_t cols = (size_t) s.len + 2;
-    d.seq = OFF<const uint8_t>(bl.put(s.seq, cols * s.many));
-    if (s.weight) d.weight = OFF<const double>(bl.put(s.weight, sizeof(double) * s.many));
-    if (s.pseq && s.nelm > 0) d.pseq = OFF<const double>(bl.put(s.pseq, sizeof(double) * cols * s.nelm));
-    d.thk = OFF<const double>(bl.put(s.thk, sizeof(double) * cols * 3));
+    if (!use_twin(patches, d.seq, tw ? tw->seq : 0)) d.seq = OFF<const uint8_t>(bl.put(s.seq, cols * s.many));
+    if (s.weight && !use_twin(patches, d.weight, tw ? tw->weight : 0)) d.weight = OFF<const double>(bl.put(s.weight, sizeof(double) * s.many));
+    if (s.pseq && s.nelm > 0 && !use_twin(patches, d.pseq, tw ? tw->pseq : 0)) d.pseq = OFF<const double>(bl.put(s.pseq, sizeof(double) * cols * s.nelm));
+    if (!use_twin(patches, d.thk, tw ? tw->thk : 0)) d.thk = OFF<const double>(bl.put(s.thk, sizeof(double) * cols * 3));
     if (need_gfq) {
         d.hetero = s.gfq.hetero;
         {   // r = [head?] + (t with glen + 1): the structure Gfq::seq2gfq gives the r view (reference src/gfreq.cc:218-226)
@@ -578,9 +617,9 @@ static void pack_side(Blob &bl, const g2g_side &s, DevSide &d, int kind, bool ne
             const int nlist = s.len + 2;                       // offsets for positions -1..len-1 + end
             const int pool = s.gfq.off[v][s.len + 1];
             for (int i = 0; i + 1 < nlist; ++i) d.maxlist = std::max(d.maxlist, s.gfq.off[v][i + 1] - s.gfq.off[v][i]);
-            d.off[v] = OFF<const int>(bl.put(s.gfq.off[v], sizeof(int) * nlist));
-            d.glen[v] = OFF<const int>(bl.put(s.gfq.glen[v], sizeof(int) * pool));
-            d.freq[v] = OFF<const double>(bl.put(s.gfq.freq[v], sizeof(double) * pool));
+            if (!use_twin(patches, d.off[v], tw ? (const int *) tw->off[v] : 0)) d.off[v] = OFF<const int>(bl.put(s.gfq.off[v], sizeof(int) * nlist));
+            if (!use_twin(patches, d.glen[v], tw ? (const int *) tw->glen[v] : 0)) d.glen[v] = OFF<const int>(bl.put(s.gfq.glen[v], sizeof(int) * pool));
+            if (!use_twin(patches, d.freq[v], tw ? tw->freq[v] : 0)) d.freq[v] = OFF<const double>(bl.put(s.gfq.freq[v], sizeof(double) * pool));
         }
     }
     if (kind == 3) {
@@ -680,11 +719,13 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
     Blob bl(ctx);
     if (const char *e = g2g_opt(ctx, "PACK_THREADS")) bl.pack_threads = atoi(e);
     {   // size the staging buffer once (growing a pinned buffer means allocating and copying it again)
-        auto side_bytes = [](const g2g_side &s) {
+        auto side_bytes = [&](const g2g_side &s) {
             const size_t cols = (size_t) s.len + 2;
-            size_t t = cols * s.many + 8 * (size_t) s.many + 24 * cols + 256;
-            if (s.pseq && s.nelm > 0) t += 8 * cols * s.nelm;
-            if (s.has_gfq) for (int v = 0; v < 3; ++v) if (s.gfq.off[v]) t += 4 * cols + 12 * (size_t) s.gfq.off[v][s.len + 1] + 64;
+            const g2g_side_dev *tw = (s.dev && s.dev->ctx == ctx) ? s.dev : 0;
+            size_t t = 8 * (size_t) s.many + 24 * cols + 256;
+            if (!(tw && tw->seq)) t += cols * s.many;
+            if (s.pseq && s.nelm > 0 && !(tw && tw->pseq)) t += 8 * cols * s.nelm;
+            if (s.has_gfq) for (int v = 0; v < 3; ++v) if (s.gfq.off[v] && !(tw && tw->freq[v])) t += 4 * cols + 12 * (size_t) s.gfq.off[v][s.len + 1] + 64;
             if (s.gapdens) t += 16 * cols * s.many;
             return t;
         };
@@ -698,6 +739,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
     }
     size_t probs_off = bl.put(0, 0);
     bl.extend(probs_off + sizeof(DevProb) * (size_t) (n > 0 ? n : 1));
+    std::vector<DevPatch> patches;            // descriptor fields that point at device-resident inputs (b->dp is never resized)
     // 1. inputs
     for (int i = 0; i < n; ++i) {
         DevProb &d = b->dp[i];
@@ -713,8 +755,8 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         d.u2divu1 = p->u2divu1; d.v2divv1 = p->v2divv1;
         d.simdim = p->simdim;
         if (p->simmtx) d.simmtx = OFF<const double>(bl.put(p->simmtx, sizeof(double) * (size_t) p->simdim * p->simrows));
-        pack_side(bl, p->a, d.a, d.kind, d.kind == 1 || d.kind == 2);
-        pack_side(bl, p->b, d.b, d.kind, d.kind == 2);
+        pack_side(bl, p->a, d.a, d.kind, d.kind == 1 || d.kind == 2, patches);
+        pack_side(bl, p->b, d.b, d.kind, d.kind == 2, patches);
         d.spb_fact = p->spb_fact; d.dvsp = p->dvsp;
         {
             std::vector<BonusCell> bc;
@@ -908,6 +950,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         rebase(d.v2_rowoff, b->d_arena); rebase(d.v2_sim, b->d_arena);
         rebase(d.trace, b->d_arena); rebase(d.score, b->d_arena); rebase(d.ntrace, b->d_arena); rebase(d.otrace, b->d_arena);
     }
+    for (const DevPatch &pt : patches) *pt.field = pt.value;
     {
         int *i1 = (int *) (bl.data() + idx_off), *i2 = i1 + (n > 0 ? n : 1);
         b->n1 = b->n2 = 0; b->lds2 = 0;
@@ -1833,3 +1876,4 @@ extern "C" int g2g_forward_batch(g2g_ctx *ctx, int n, const g2g_problem *const *
 #include "g2g_dist.hip"                // f3: the guide-tree DPs (own kernels, own entry point; shares the context)
 #include "g2g_pairaln.hip"             // f3: alignB_ng (pairwise alignment of single sequences with the path)
 #include "g2g_pairsum.hip"             // f1: Ssrel::pairsum_ss (naive nodes on the GPU, joins through calcSpScore)
+#include "g2g_build.hip"               // a8 / a9: thickness, vectors and gap profiles of a batch of groups on the device

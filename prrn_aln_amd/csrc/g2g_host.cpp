@@ -18,6 +18,7 @@
 #include <vector>
 #include "../../include/g2g.h"
 #include "g2g_internal.h"
+#include "g2g_group.h"
 
 namespace {
 
@@ -35,42 +36,7 @@ struct Gfreq { int glen; double freq; int nres; };           // src/gfreq.h:25
 const Gfreq zerogfq = {0, 0, 0}, delmgfq = {-1, 0, 0};
 inline bool neogfq(const Gfreq &g) { return g.glen >= 0; }
 
-struct GapProfile {                                          // <-> class Gfq, src/gfreq.h:44-64
-    int hetero;
-    std::vector<int32_t> off[3], glen[3];
-    std::vector<double> freq[3];
-};
-
 }   // namespace
-
-// <-> mSeq (src/mseq.h:86-200) reduced to what the group-to-group DP reads
-struct g2g_group {
-    int many, len, left, right;
-    int molc, max_code;
-    int dels, nils, exgl, exgr;
-    bool has_weight;
-    double tgapf;
-    std::vector<uint8_t> seq;            // (len + 2) * many, position -1 first
-    std::vector<double> weight;
-    // derived lazily, like the reference (mkthick / convseq / Gfq on first use)
-    bool thk_done;
-    double sumwt;
-    int thk_len;
-    bool has_internalres;
-    std::vector<int> internal_pos;       // position of mSeq::internalres[i]
-    std::vector<double> thk;             // (thk_len + 2) * 3, index -1 first
-    int vect, nelm, felm, simdim_used;
-    std::vector<double> pseq;            // (len + 2) * nelm
-    GapProfile *gfq;
-    // flattened views handed to the engine
-    std::vector<double> thk_pos;         // (len + 2) * 3
-    std::vector<double> gapdens, postgapdens;
-
-    uint8_t at(int pos, int i) const { return seq[(size_t) (pos + 1) * many + i]; }
-    uint8_t &at(int pos, int i) { return seq[(size_t) (pos + 1) * many + i]; }
-    double *T(int j) { return &thk[(size_t) (j + 1) * 3]; }
-    ~g2g_group() { delete gfq; }
-};
 
 namespace {
 
@@ -373,6 +339,8 @@ struct Matrix { const double *m; int dim, rows; double at(int i, int j) const { 
 
 void convseq(g2g_group &g, int vect, const Matrix &sm)
 {
+    // (vectors rebuilt on the host below make a device twin of the old ones void)
+    if ((g.vect == RAWSEQ && vect != RAWSEQ) || (g.vect != vect && vect == VECPRO && sm.m)) g.dev.pseq = 0;
     // (mkthick and the gap profile are made by the caller in the reference's order)
     const int many = g.many, len = g.len;
     if (g.vect == RAWSEQ) {
@@ -490,6 +458,10 @@ void fill_side(g2g_group &g, g2g_side &s, bool ntv)
             s.gfq.freq[v] = g.gfq->freq[v].data();
         }
     }
+    if (g.dev.ctx && g.dev.seq) {            // device-resident twins (g2g_device_derive): only of what the host side hands out too
+        static_assert(sizeof(int) == sizeof(int32_t), "int32");
+        s.dev = &g.dev;
+    }
     if (ntv) {
         const size_t n = (size_t) (g.len + 2) * g.many;
         g.gapdens.assign(n, 0.); g.postgapdens.assign(n, 0.);
@@ -536,30 +508,40 @@ extern "C" g2g_group *g2g_group_create(g2g_ctx *, const g2g_params *prm, int man
     for (size_t k = 0; k < (size_t) len * many; ++k) if (IsGap(seq[k])) { g->dels = 1; break; }
     g->thk_done = false; g->sumwt = 0; g->thk_len = 0; g->has_internalres = false;
     g->vect = RAWSEQ; g->nelm = g->felm = 0; g->gfq = 0; g->nils = 0; g->exgl = g->exgr = 0;
+    memset(&g->dev, 0, sizeof g->dev);
     exg_seq(*g, 0, 0);                                       // Prrn::gather / aln_main: global, both ends
     return g;
 }
 
 extern "C" void g2g_group_free(g2g_group *g) { delete g; }
 
-extern "C" g2g_pwdm *g2g_pwdm_create(g2g_ctx *, const g2g_params *prm, g2g_group *ga, g2g_group *gb, int *swapped)
+// The PwdM constructor in three stages, so that the middle one -- the derived arrays of the two groups -- can run for one pair on
+// host threads (g2g_pwdm_create) or for a whole batch of pairs on the device (g2g_pwdm_create_batch, g2g_build.hip).
+namespace {
+struct PwdmPlan {
+    g2g_pwdm *P;
+    g2g_group *a, *b;                 // after the swap
+    int aprof, bprof, swp, alnmode, DvsP, Noll, codonk1;
+    float f_scale, f_u, f_v, f_u1;
+    double BasicGOP, BasicGEP, LongGOP, LongGEP, diffu;
+};
+
+// stage 1: PwdB, selAlnMode, the swap
+bool pwdm_plan(const g2g_params *prm, g2g_group *ga, g2g_group *gb, PwdmPlan &L)
 {
-    if (!prm || !ga || !gb) { g2g_set_error("%s", "g2g_pwdm_create: bad argument"); return NULL; }
-    if (prm->u0 > 0) { g2g_set_error("%s", "ether scorers (u0 > 0) are not on this path"); return NULL; }
-    g2g_pwdm *P = new g2g_pwdm();
-    P->prm = *prm;
+    if (!prm || !ga || !gb) { g2g_set_error("%s", "g2g_pwdm_create: bad argument"); return false; }
+    if (prm->u0 > 0) { g2g_set_error("%s", "ether scorers (u0 > 0) are not on this path"); return false; }
     g2g_group *sq[2] = {ga, gb};
-    const Matrix sm = {prm->simmtx, prm->simdim, prm->simrows};
     // --- PwdB (before any swap) ---
-    const float f_scale = (float) prm->scale, f_u = (float) prm->u, f_v = (float) prm->v, f_u1 = (float) prm->u1;
-    const int DvsP = (ga->molc == MOLC_PROTEIN) + 2 * (gb->molc == MOLC_PROTEIN);
-    const int Noll = std::max(2, std::min(NOL, (int) prm->ls));
-    const double VabB = (double) (f_scale * ga->many * gb->many);          // axbscale, src/seq.h:1468 (float arithmetic)
-    const double BasicGOP = (double) (-f_v * VabB), BasicGEP = (double) (-f_u * VabB), LongGEP = (double) (-f_u1 * VabB);
-    const double diffu = LongGEP - BasicGEP;
-    const double LongGOP = BasicGOP - diffu * prm->k1;
-    const int step = (DvsP == 3) ? 1 : 3;
-    const int codonk1 = prm->ls == 3 ? step * prm->k1 : LARGEN;
+    L.f_scale = (float) prm->scale; L.f_u = (float) prm->u; L.f_v = (float) prm->v; L.f_u1 = (float) prm->u1;
+    L.DvsP = (ga->molc == MOLC_PROTEIN) + 2 * (gb->molc == MOLC_PROTEIN);
+    L.Noll = std::max(2, std::min(NOL, (int) prm->ls));
+    const double VabB = (double) (L.f_scale * ga->many * gb->many);          // axbscale, src/seq.h:1468 (float arithmetic)
+    L.BasicGOP = (double) (-L.f_v * VabB); L.BasicGEP = (double) (-L.f_u * VabB); L.LongGEP = (double) (-L.f_u1 * VabB);
+    L.diffu = L.LongGEP - L.BasicGEP;
+    L.LongGOP = L.BasicGOP - L.diffu * prm->k1;
+    const int step = (L.DvsP == 3) ? 1 : 3;
+    L.codonk1 = prm->ls == 3 ? step * prm->k1 : LARGEN;
     // --- PwdM::selAlnMode, src/maln2.cc:81-154 ---
     int aprof = 0, bprof = 0, abgfq = 0;
     {   // advised_sim2 :43-60
@@ -590,9 +572,27 @@ extern "C" g2g_pwdm *g2g_pwdm_create(g2g_ctx *, const g2g_params *prm, g2g_group
     default: swp = 0; break;                                 // a->inex.intr: no spliced input here
     }
     if (swp) { std::swap(sq[0], sq[1]); std::swap(aprof, bprof); }
-    g2g_group &a = *sq[0], &b = *sq[1];
+    L.a = sq[0]; L.b = sq[1]; L.aprof = aprof; L.bprof = bprof; L.swp = swp; L.alnmode = alnmode;
+    L.P = new g2g_pwdm();
+    L.P->prm = *prm;
+    return true;
+}
+
+// what stage 2 has to provide for each side (bits of G2G_NEED_*): mSeq::convseq begins with mkthick + the gap profile
+// (src/mseq.cc:506-507); a profile side gets its frequency vectors, side a (or b when a is none) the profile vectors on top
+void pwdm_needs(const PwdmPlan &L, int *need_a, int *need_b)
+{
+    *need_a = (L.a->dels ? G2G_NEED_GFQ : 0) | (L.aprof ? (G2G_NEED_VECTOR | G2G_NEED_VECPRO) : 0);
+    *need_b = (L.b->dels ? G2G_NEED_GFQ : 0) | (L.bprof ? (G2G_NEED_VECTOR | (L.aprof ? 0 : G2G_NEED_VECPRO)) : 0);
+}
+
+// stage 2 on the host
+void pwdm_derive_host(const g2g_params *prm, PwdmPlan &L)
+{
+    const Matrix sm = {prm->simmtx, prm->simdim, prm->simrows};
+    g2g_group &a = *L.a, &b = *L.b;
+    const int aprof = L.aprof, bprof = L.bprof;
     // exg_seq(lcl & 1, lcl & 2): algmode.lcl == 0 (global) -> already done at creation
-    // mSeq::convseq begins with mkthick + gap profile (src/mseq.cc:506-507)
     // The builders of one pair: thickness first (the gap profile reads its weight sum), then the gap profile of a, the vectors of
     // a and everything of b are independent of one another (they read the residues and write their own members): three tasks,
     // on helper threads while the machine has idle cores (a window of g2g_refine builds 2-16 pairs on 16+ cores; the big group's
@@ -625,6 +625,14 @@ extern "C" g2g_pwdm *g2g_pwdm_create(g2g_ctx *, const g2g_params *prm, g2g_group
     } else { task_gfq_a(); task_vec_a(); task_b(); }
     builders_active.fetch_sub(1);
     if (host_times) fprintf(stderr, "[g2g_pwdm_create] a %d x %d, b %d x %d: %.2f ms (%s: gap profile of a %.2f, vectors of a %.2f, b %.2f)\n", a.many, a.len, b.many, b.len, tnow() - tb0, split ? "three tasks" : "in line", tt[0], tt[1], tt[2]);
+}
+
+// stage 3: scorer selection, the flattened problem, the band
+void pwdm_finish(const g2g_params *prm, PwdmPlan &L)
+{
+    g2g_pwdm *P = L.P;
+    g2g_group &a = *L.a, &b = *L.b;
+    const int aprof = L.aprof, bprof = L.bprof, swp = L.swp, alnmode = L.alnmode, DvsP = L.DvsP;
     // --- rest of the PwdM ctor :266-285 ---
     const double *wta = a.has_weight ? a.weight.data() : 0, *wtb = b.has_weight ? b.weight.data() : 0;
     if (wta && !wtb && !bprof) { b.weight.assign(b.many, 1.); b.has_weight = true; wtb = b.weight.data(); }
@@ -652,12 +660,12 @@ extern "C" g2g_pwdm *g2g_pwdm_create(g2g_ctx *, const g2g_params *prm, g2g_group
     const bool ntv = alnmode == G2G_NTV_ALB || alnmode == G2G_NTV_ALN;
     q.crg2_kind = ntv ? crg2 : 0;
     q.dvsp = DvsP;
-    q.noll = Noll; q.codonk1 = codonk1;
-    q.basic_gop = (double) (-f_scale * f_v);                 // resetuab, src/maln2.cc:227-243 (float arithmetic)
-    q.weighted_gop = (double) -f_v;
-    q.u = (double) f_u;
-    q.u2divu1 = BasicGEP < 0 ? LongGEP / BasicGEP : 0;       // Fwd2c ctor, src/fwd2c.h:85-86
-    q.v2divv1 = BasicGOP < 0 ? LongGOP / BasicGOP : 0;
+    q.noll = L.Noll; q.codonk1 = L.codonk1;
+    q.basic_gop = (double) (-L.f_scale * L.f_v);             // resetuab, src/maln2.cc:227-243 (float arithmetic)
+    q.weighted_gop = (double) -L.f_v;
+    q.u = (double) L.f_u;
+    q.u2divu1 = L.BasicGEP < 0 ? L.LongGEP / L.BasicGEP : 0; // Fwd2c ctor, src/fwd2c.h:85-86
+    q.v2divv1 = L.BasicGOP < 0 ? L.LongGOP / L.BasicGOP : 0;
     q.simmtx = prm->simmtx; q.simdim = prm->simdim; q.simrows = prm->simrows;
     fill_side(a, q.a, ntv);
     fill_side(b, q.b, ntv);
@@ -666,11 +674,76 @@ extern "C" g2g_pwdm *g2g_pwdm_create(g2g_ctx *, const g2g_params *prm, g2g_group
     {   // resetuab, src/maln2.cc:227-234: Vab = scale * wa * wb with the weight sums of the profile-mode sides
         const double wa = a_mode ? a.sumwt : 1, wb = b_mode ? b.sumwt : 1;
         P->sp.vab = (double) (prm->scale * wa * wb);
-        P->sp.basic_gep = BasicGEP; P->sp.diffu = diffu;
-        P->sp.diff_u = (double) (f_scale * (f_u - f_u1));      // resetuab, src/maln2.cc:233 (float arithmetic)
+        P->sp.basic_gep = L.BasicGEP; P->sp.diffu = L.diffu;
+        P->sp.diff_u = (double) (L.f_scale * (L.f_u - L.f_u1));  // resetuab, src/maln2.cc:233 (float arithmetic)
     }
-    if (swapped) *swapped = swp;
-    return P;
+}
+}   // namespace
+
+extern "C" g2g_pwdm *g2g_pwdm_create(g2g_ctx *, const g2g_params *prm, g2g_group *ga, g2g_group *gb, int *swapped)
+{
+    PwdmPlan L;
+    if (!pwdm_plan(prm, ga, gb, L)) return NULL;
+    pwdm_derive_host(prm, L);
+    pwdm_finish(prm, L);
+    if (swapped) *swapped = L.swp;
+    return L.P;
+}
+
+// n PwdMs at once, the derived arrays of all their groups built ON THE DEVICE in one go (g2g_build.hip: thickness, frequency /
+// profile vectors, gap profiles -- SURVEY.md section 8 rows a8 / a9); same objects, same arrays as n calls of g2g_pwdm_create.
+// Groups the device builders do not take (nil codes: tgapf < 1; a group already vectorised half-way) are built on the host.
+extern "C" int g2g_pwdm_create_batch(g2g_ctx *ctx, const g2g_params *prm, int n, g2g_group *const *ga, g2g_group *const *gb, int *swapped, g2g_pwdm **out)
+{
+    if (!ctx || !prm || n < 0 || (n && (!ga || !gb || !out))) { g2g_set_error("%s", "g2g_pwdm_create_batch: bad argument"); return G2G_ERR_ARG; }
+    std::vector<PwdmPlan> L((size_t) n);
+    for (int k = 0; k < n; ++k) out[k] = 0;
+    for (int k = 0; k < n; ++k)
+        if (!pwdm_plan(prm, ga[k], gb[k], L[(size_t) k])) { for (int j = 0; j < k; ++j) delete L[(size_t) j].P; return G2G_ERR_ARG; }
+    // the groups and what each needs (a group may serve several pairs)
+    std::vector<g2g_group *> groups;
+    std::vector<int> need;
+    auto want = [&](g2g_group *g, int bits) {
+        for (size_t q = 0; q < groups.size(); ++q) if (groups[q] == g) { need[q] |= bits; return; }
+        groups.push_back(g); need.push_back(bits);
+    };
+    for (int k = 0; k < n; ++k) { int na, nb; pwdm_needs(L[(size_t) k], &na, &nb); want(L[(size_t) k].a, na); want(L[(size_t) k].b, nb); }
+    std::vector<g2g_group *> dev;
+    std::vector<int> dneed;
+    const bool use_dev = !g2g_get_option(ctx, "NO_DEVICE_BUILD");
+    for (size_t q = 0; q < groups.size(); ++q) {
+        g2g_group &g = *groups[q];
+        int bits = need[q];
+        if (g.gfq) bits &= ~G2G_NEED_GFQ;
+        if (g.vect == VECPRO || (g.vect == VECTOR && !(bits & G2G_NEED_VECPRO))) bits &= ~(G2G_NEED_VECTOR | G2G_NEED_VECPRO);
+        const bool halfway = g.vect == VECTOR && (bits & G2G_NEED_VECPRO);
+        const bool work = (g.dels && !g.thk_done) || bits;
+        if (use_dev && work && !halfway && !g.nils && !g.exgl && !g.exgr) { dev.push_back(&g); dneed.push_back(bits); }
+    }
+    if (!dev.empty()) {
+        const int rc = g2g_device_derive(ctx, prm, (int) dev.size(), dev.data(), dneed.data());
+        if (rc != G2G_OK && rc != G2G_ERR_MODE) { for (auto &l : L) delete l.P; return rc; }      // (G2G_ERR_MODE: not taken -- the host builds them below)
+    }
+    // whatever is still missing (gap-free groups' constant thickness rows; groups the device did not take): host, pairs in parallel
+    {
+        std::atomic<int> next(0);
+        auto work = [&]() { for (int k; (k = next.fetch_add(1)) < n; ) pwdm_derive_host(prm, L[(size_t) k]); };
+        unsigned nthr = std::thread::hardware_concurrency();
+        if (nthr > 16) nthr = 16;
+        if (nthr < 1) nthr = 1;
+        // (a group shared by two pairs must not be derived by two threads at once: shared groups make the loop serial)
+        if (groups.size() < 2 * (size_t) n) nthr = 1;
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nthr && (int) t < n; ++t) { try { th.emplace_back(work); } catch (...) { break; } }
+        work();
+        for (auto &t : th) t.join();
+    }
+    for (int k = 0; k < n; ++k) {
+        pwdm_finish(prm, L[(size_t) k]);
+        out[k] = L[(size_t) k].P;
+        if (swapped) swapped[k] = L[(size_t) k].swp;
+    }
+    return G2G_OK;
 }
 
 extern "C" void g2g_pwdm_free(g2g_pwdm *p) { delete p; }

@@ -115,6 +115,32 @@ class PwdM:
         self.problem = L.g2g_pwdm_problem(self._h).contents
         self.alnmode = self.problem.alnmode
 
+    @classmethod
+    def batch(cls, ctx, pairs: Sequence[Sequence[mSeq]], alp: AlnParam) -> List["PwdM"]:
+        """g2g_pwdm_create_batch: the PwdMs of many pairs at once, thickness / vectors / gap profiles of all their groups built
+        on the DEVICE (csrc/g2g_build.hip); the same objects as [PwdM(p, alp) for p in pairs]."""
+        L = lib()
+        n = len(pairs)
+        prm, sm = alp.to_c()
+        ha = (C.c_void_p * max(1, n))(*[p[0]._h for p in pairs])
+        hb = (C.c_void_p * max(1, n))(*[p[1]._h for p in pairs])
+        swp = (C.c_int * max(1, n))()
+        out = (C.c_void_p * max(1, n))()
+        rc = L.g2g_pwdm_create_batch(ctx._h, C.byref(prm), n, ha, hb, swp, out)
+        if rc:
+            raise G2GError("g2g_pwdm_create_batch rc=%d: %s" % (rc, last_error()))
+        res = []
+        for k in range(n):
+            o = cls.__new__(cls)
+            o.seqs = list(pairs[k])
+            o._prm, o._sm = prm, sm
+            o._h = out[k]
+            o.swp = bool(swp[k])
+            o.problem = L.g2g_pwdm_problem(o._h).contents
+            o.alnmode = o.problem.alnmode
+            res.append(o)
+        return res
+
     def __del__(self):
         try:
             if self._h:

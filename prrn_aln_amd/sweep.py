@@ -37,8 +37,10 @@ class Sweep:
     libg2g.so).  `order` lists division ids by decreasing DP size (longest-processing-time first)."""
 
     def __init__(self, fam: Family, alp: op.AlnParam, weighted: bool = True, limit: Optional[int] = None,
-                 workers: Optional[int] = None, codes: Optional[np.ndarray] = None):
-        """`codes`: start from this MSA ((columns, members) residue codes of the family's members) instead of fam.msa."""
+                 workers: Optional[int] = None, codes: Optional[np.ndarray] = None, ctx=None):
+        """`codes`: start from this MSA ((columns, members) residue codes of the family's members) instead of fam.msa.
+        `ctx`: an engine.Context -- the derived arrays of all divisions' groups (thickness, vectors, gap profiles) are then built on
+        the device in one batch (g2g_pwdm_create_batch) instead of on host threads; same objects either way."""
         self.fam, self.alp = fam, alp
         self.codes = op.encode(fam.msa, alp.molc) if codes is None else np.ascontiguousarray(codes, np.uint8)
         n = len(fam.msa)
@@ -54,8 +56,10 @@ class Sweep:
             wa = None if self.weights is None else self.weights[ia]
             wb = None if self.weights is None else self.weights[ib]
             ga, gb = op.mSeq(a, alp, wa), op.mSeq(b, alp, wb)
-            return (ga, gb), op.PwdM([ga, gb], alp)
+            return (ga, gb), (op.PwdM([ga, gb], alp) if ctx is None else None)
 
+        import time
+        t0 = time.perf_counter()
         nthr = workers if workers is not None else min(16, os.cpu_count() or 1)
         if nthr > 1 and len(self.branches) > 1:
             with ThreadPoolExecutor(max_workers=nthr) as pool:
@@ -63,7 +67,10 @@ class Sweep:
         else:
             built = [build(side) for side in self.branches]
         self.groups = [g for g, _ in built]
-        self.pwds: List[op.PwdM] = [p for _, p in built]
+        t1 = time.perf_counter()
+        self.pwds: List[op.PwdM] = [p for _, p in built] if ctx is None else op.PwdM.batch(ctx, self.groups, alp)
+        # seconds: splitting the MSA into groups (+ the PwdMs when they are built on the host threads, ctx None); the device batch
+        self.t_split, self.t_batch = t1 - t0, time.perf_counter() - t1
         self.cells = np.array([band_cells(p.problem) for p in self.pwds], np.int64)
         self.order = np.argsort(-self.cells, kind="stable")
 

@@ -27,7 +27,7 @@ def test_exports_every_declared_symbol(built):
 
 def test_abi_version(built):
     L = C.CDLL(built)
-    assert L.g2g_abi_version() == 4
+    assert L.g2g_abi_version() == 5
 
 
 def test_struct_sizes_match_header(built):
