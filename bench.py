@@ -212,21 +212,36 @@ def refinement_readout(ctx, args):
     same = bool(np.array_equal(final, want))
     dps = [x for x in rsteps if not x["skipped"]]
     scr_same = len(dps) == len(f["align2"]) and all(x["scr"] == r["scr"] and x["val_new"] == r["val"] for x, r in zip(dps, f["align2"]))
-    sp_gpu, sp_ref = pairsum(ctx, final, tree, ralp), pairsum(ctx, want, tree, ralp)
+    sp_gpu = pairsum(ctx, final, tree, ralp)
+    # the REFERENCE's own Ssrel::pairsum_ss values of this run (fixture key pairsum_ss, tools/make_refine_pairsum.py: traced out of
+    # `prrn5 -YH0 -R1 -O4` itself): start and refined MSA on the refinement's tree, and the -O4 read-outs on the tree it rebuilt
+    ref_ps = {(c["msa"], c["use_pw"], c["tree"] is None): c for c in f.get("pairsum_ss", [])}
+    sp_ref = ref_ps[("final", 1, True)]["value"] if ("final", 1, True) in ref_ps else None
+    o4 = []
+    for c in f.get("pairsum_ss", []):
+        if c["tree"] is None:
+            continue
+        t2 = c["tree"]
+        ours = pairsum(ctx, final, KTree(t2["left"], t2["right"], t2["parent"], t2["vol"], t2["cur"]), ralp, use_pw=bool(c["use_pw"]))
+        o4.append({"use_pw": c["use_pw"], "ours_on_our_refined_msa": ours, "reference": c["value"], "abs_delta": abs(ours - c["value"])})
     out = {"family": "%d %s x %s, start MSA %d columns (%s: trace of the reference's own Prrn::rir, serial, -YH0 -R1)"
                      % (len(f["rows"]), "proteins" if f["molc"] == 1 else "DNA sequences", "1024 aa" if use_big else "300 aa", len(f["rows"][0]), os.path.basename(big if use_big else small)),
            "engine": "g2g_refine (C++ behind the C ABI): windows of speculative divisions batched on the GPU, in-order acceptance",
            "wall_s": rt, "divisions_evaluated": rstats["divisions"], "align2_calls": len(dps), "accepted_moves": rstats["accepted"],
            "gpu_batches": rstats["batches"], "divisions_recomputed": rstats["divisions_wasted"],
            "wait_timeouts": int(c1["wait_timeouts"] - c0["wait_timeouts"]), "recovered_dps": int(c1["recovered_dps"] - c0["recovered_dps"]),
-           "last_timeout_report": (ctx.last_timeout()[:1500] if c1["recovered_dps"] > c0["recovered_dps"] else None),
+           "last_timeout_report": (ctx.last_timeout()[:4000] if c1["recovered_dps"] > c0["recovered_dps"] else None),
            "wait_gaps": list(ctx.wait_gaps()),
            "same_branch_sequence_as_reference": [x["branch"] for x in rsteps] == f["branches"],
            "every_dp_score_and_fstat_val_equal_to_reference": bool(scr_same),
            "final_msa_identical_to_reference": same,
            # Ssrel::pairsum_ss (g2g_pairsum, on the trace's tree) of the start MSA, of OUR refined MSA and of the REFERENCE's refined MSA
-           "pairsum_ss_start": pairsum(ctx, start, tree, ralp), "pairsum_ss_refined": sp_gpu, "pairsum_ss_reference_refined": sp_ref,
-           "sp_delta_vs_reference": abs(sp_gpu - sp_ref)}
+           "pairsum_ss_start": pairsum(ctx, start, tree, ralp), "pairsum_ss_refined": sp_gpu,
+           # what the reference itself printed / computed for ITS refined MSA (not our kernel on its MSA): Ssrel::pairsum_ss, src/fspscore.cc:896
+           "pairsum_ss_reference_start": ref_ps[("start", 1, True)]["value"] if ("start", 1, True) in ref_ps else None,
+           "pairsum_ss_reference_refined": sp_ref,
+           "sp_delta_vs_reference": (abs(sp_gpu - sp_ref) if sp_ref is not None else None),
+           "sp_readout_O4_on_the_reference_s_rebuilt_tree": o4}
     ref = {"whole_run_s_one_core_build_container": f.get("reference_seconds")}
     if not args.no_cpu:
         names = [("s%03d" if len(f["rows"]) > 99 else "s%02d") % i for i in range(len(f["rows"]))]
@@ -333,7 +348,15 @@ def main():
                 slots = slots.cuda()
             gathered = [torch.empty_like(slots) for _ in range(world)]
             dist.all_gather(gathered, slots)
-            return out, gathered
+            # the consumer of the exchange, inside the timed step: every rank unpacks ALL ranks' slots into the complete table of the
+            # sweep's results -- what Prrn::best_of_n looks at (reference src/prrn5.cc:594-631) -- and takes the same decision on it
+            # (here: the division with the best DP score; ties to the lower id).  No rank acts on numbers another rank does not hold.
+            table = sweep.unpack_slots(torch.stack(gathered).cpu().numpy())
+            if len(table) != len(sw) or any(v[2] != 0 for v in table.values()):
+                raise RuntimeError("exchange: %d of %d divisions arrived, %d failed" % (len(table), len(sw), sum(1 for v in table.values() if v[2] != 0)))
+            best = min(table, key=lambda k: (-table[k][0], k))
+            return out, {"divisions_on_every_rank": len(table), "best_division": int(best), "best_score": float(table[best][0]),
+                         "bytes_gathered_per_rank": int(slots.numel() * slots.element_size() * world)}
         return out, None
 
     for _ in range(args.warmup):
@@ -479,6 +502,7 @@ def main():
                                       sum(1 for p in sw.pwds if p.alnmode in (7, 8)),
                                       sum(1 for p in sw.pwds if p.alnmode == 9), total_cells),
                        "divisions": len(sw), "cells_per_step": total_cells, "parallelism": "divisions round-robin by size over %d GPU(s)" % world,
+                       "exchange": gathered,
                        "failed_items": bad, "align2_batch_from_host_ms": e2e_ms, "builders": builders,
                        # every run is evidence about the scheduler's waits: per timed step, the waits that ran into
                        # their wall-clock limit and the DPs re-run because of it (rank 0's share); an ordinary run shows zeros

@@ -1515,7 +1515,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             if (b->injected) { g_tot[5] += rep[G2G_HDR]; g_tot[6] += (long long) lost.size(); }
             {   // the report of the event: kept in the context (g2g_ctx_last_timeout: every ordinary run that meets one carries the
                 // evidence), printed under WARN / DEBUG
-                char buf[3072];
+                char buf[4096];
                 int o = 0;
                 auto add = [&](const char *fmt, ...) { va_list ap; va_start(ap, fmt); if (o < (int) sizeof buf - 1) { const int w = vsnprintf(buf + o, sizeof buf - o, fmt, ap); if (w > 0) o += w; } va_end(ap); if (o > (int) sizeof buf - 1) o = (int) sizeof buf - 1; };
                 int kinds[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1544,6 +1544,11 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                         for (int w = 0; w < 4; ++w) add(" w%d %d:%d -> %d:%d", w, x[48 + 2 * w], x[49 + 2 * w], x[56 + 2 * w], x[57 + 2 * w]);
                     }
                 }
+                add("; the blocker (lowest strip of this DP without a publish in this generation, %d below the polled one): word %d:%d, HW_ID %08x XCC %08x, taken-by marker %08x (gen %d, workgroup %d), past the left chain %08x, past its first look at the strip above %08x, first wave's last publish %d (markers carry the generation; 7fffffff: never written)",
+                    x[64], (x[65] >> 20) & 0x7FF, x[65] & 0xFFFFF, x[66], x[67], x[68], (x[68] >> 20) & 0x7FF, x[68] & 0xFFFF, x[69], x[70], x[71]);
+                add("; chain words of this DP as the first waiter saw them (valid when the polled word is a strip's): left %d:%d, top %d:%d", (x[80] >> 20) & 0x7FF, x[80] & 0xFFFFF, (x[81] >> 20) & 0x7FF, x[81] & 0xFFFFF);
+                if (x[72]) add("; of the waves released when their DP was given up, the one with the lowest strip index (%d) was waiting on word %d for %d:%d and had last seen %d:%d (read-modify-write on release: %d:%d) after %d polls, %.0f ms of its own running time",
+                               0x7fffffff - x[72], x[75], (x[73] >> 20) & 0x7FF, x[73] & 0xFFFFF, (x[74] >> 20) & 0x7FF, x[74] & 0xFFFFF, (x[78] >> 20) & 0x7FF, x[78] & 0xFFFFF, x[76], x[77] * 65536. / ctx->rt_ticks_per_ms);
                 add("; waiting waves off the machine for > 4 ms at a stretch in this run: %d (longest %.1f ms)", x[40], x[41] * 1024. / ctx->rt_ticks_per_ms);
                 buf[o] = 0;
                 if (!b->is_retry || ctx->last_timeout.empty()) ctx->last_timeout = buf;

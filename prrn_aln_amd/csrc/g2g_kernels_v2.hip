@@ -40,13 +40,30 @@ static __device__ unsigned long long g2g_stamp_acc[16];      // (one copy per tr
 // hdr = done + G2G_HDR: [0] time-outs, [1] strip index of the first, [2] offset of the fail array from `done`, [3] the limit,
 // [4..47] what the first wave to give up saw (the host prints it under G2G_WARN; DESIGN.md 4.2 reads such reports).
 #define G2G_HDR 24                   // d_flags: [0, 24) queue heads of the kernel variants, [24, 28) this header, [28, 72) snapshot of the first time-out, tile flags behind
-#define G2G_FSTRIDE 32               // ints between two tile flags / progress words: one 128-byte line each, so that no two workgroups (in
-                                     // different XCDs, behind different L2s) ever store into the same line
+// Two 128-byte lines per strip.  The FIRST holds the progress word and nothing else: it is the line other workgroups poll, and the
+// only store that ever goes into it is the publish itself.  Everything the strip leaves for a time-out report (HW_ID, markers,
+// per-wave columns, heartbeats) lives in the SECOND line, G2G_DIAG ints on, which nobody polls.  Round 4's reports showed what the
+// stopped workgroups of DESIGN.md 4.2 were doing: the head strip of every pipeline of one launch sat at an s_waitcnt vmcnt(0)
+// behind a write-through store INTO THE LINE ITS SUCCESSOR WAS POLLING (its queue marker, its per-wave column, the progress
+// word itself), for as long as the polling went on -- a store starved by a stream of coherent loads from another XCD.  Hence
+// also G2G_POLL / G2G_POST: with -DG2G_POLL_RMW the progress word is read and written with read-modify-write atomics, which
+// execute at the memory side and leave no copy of the line in anybody's L2.  MEASURED (three whole refinements each way, round
+// 4): the events went on with both remedies in place (1, 1 and 3 per run), and the RMW polls cost 4 % -- the hypothesis is refuted,
+// the split lines stay (they cost nothing), the polls and publishes are plain agent-scope loads and stores again.
+#define G2G_FSTRIDE 64               // ints between two tile flags / progress words
+#define G2G_DIAG 32                  // offset of a strip's diagnostics line from its progress word
+#ifdef G2G_POLL_RMW
+#define G2G_POLL(p) __hip_atomic_fetch_or((int *) (p), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define G2G_POST(p, v) ((void) __hip_atomic_exchange((int *) (p), (int) (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+#else
+#define G2G_POLL(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define G2G_POST(p, v) __hip_atomic_store((int *) (p), (int) (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
 #define G2G_GAP_TICKS 400000ull       // 4 ms of s_memrealtime: more than ten times what 64 polls take
-#define G2G_HDRN 72                  // header words: 4 + the snapshot (want, seen, offset of the polled word, the words at and below it; [48, 64): per-wave heartbeats); G2G_HDR + G2G_HDRN is a multiple of G2G_FSTRIDE, so every progress line IS one 128-byte line
+#define G2G_HDRN 104                  // header words: 4 + the snapshot (want, seen, offset of the polled word, the words at and below it; [48, 64): per-wave heartbeats); G2G_HDR + G2G_HDRN is a multiple of G2G_FSTRIDE, so every progress line IS one 128-byte line
 __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hdr, int *failp, const int slot)
 {
-    int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int v = G2G_POLL(p);
     if (v >= want) return v;
     // The limit counts the time THIS wave was running: a gap of more than G2G_GAP_TICKS between two looks at the clock (64 polls:
     // 0.3 ms when the wave runs) means the wave itself was off the machine -- and with it, as a rule, the rest of its kernel, the
@@ -58,10 +75,19 @@ __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hd
         // waits per sweep last tens of ms -- strips pulled long before their producers get going: no point in hammering the fabric)
         const unsigned nap = it < 16 ? 1 : it < 64 ? 2 + (it & 1) : 8 + ((it * 5 + (unsigned) slot) & 7);
         for (unsigned j = 0; j < nap; ++j) __builtin_amdgcn_s_sleep(8);
-        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = G2G_POLL(p);
         if (v >= want) return v;
         if ((it & 63) == 0) {
-            if (__hip_atomic_load(failp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 0x7fffffff;      // this DP is lost already
+            if (__hip_atomic_load(failp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {                       // this DP is lost already
+                // ... and this wave was waiting too: of all the waves released this way the one with the LOWEST strip index leaves what
+                // it was waiting for and what it last saw (the blocker of its DP, if the blocker itself sat in a wait)
+                const int key = 0x7fffffff - slot;
+                if (key > atomicMax(hdr + 72, key)) {
+                    hdr[73] = want; hdr[74] = v; hdr[75] = (int) (p - (hdr - G2G_HDR)); hdr[76] = (int) it; hdr[77] = (int) (run >> 16);
+                    hdr[78] = atomicAdd((int *) p, 0);
+                }
+                return 0x7fffffff;
+            }
             const unsigned long long tn = __builtin_amdgcn_s_memrealtime();
             unsigned long long d = tn - tl;
             tl = tn;
@@ -75,13 +101,13 @@ __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hd
                 __hip_atomic_store(failp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 {   // where the waves that gave up sit, and where their producers sit (v6 strips leave HW_ID / XCC_ID next to their progress word)
                     const int my_xcc = (int) __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15;
-                    const int pr_xcc = __hip_atomic_load(p + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int pr_xcc = __hip_atomic_load(p + G2G_DIAG + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     atomicAdd(hdr + 24 + (my_xcc & 7), 1);
                     if ((pr_xcc & ~15) == 0x100) atomicAdd(hdr + 32 + (pr_xcc & 7), 1);
                 }
                 if (atomicAdd(hdr, 1) == 0) {
-                    hdr[20] = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hdr[21] = __hip_atomic_load(p + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hdr[20] = __hip_atomic_load(p + G2G_DIAG + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hdr[21] = __hip_atomic_load(p + G2G_DIAG + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     hdr[22] = (int) __builtin_amdgcn_s_getreg((31 << 11) | 4);
                     hdr[23] = (int) __builtin_amdgcn_s_getreg((31 << 11) | 20);             // the first one leaves a snapshot for the host's report
                     hdr[1] = slot; hdr[4] = want; hdr[5] = v;
@@ -90,17 +116,39 @@ __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hd
                     for (int k = 0; k < 8 && off - k * G2G_FSTRIDE >= G2G_HDR + G2G_HDRN; ++k) hdr[8 + k] = __hip_atomic_load(p - k * G2G_FSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // the producer's heartbeat (v6 strips: step counter and a marker of the place in the step, stored next to the
                     // progress word), read twice 50 us apart: is the producer running, and where?
-                    hdr[16] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hdr[17] = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    for (int w = 0; w < 8; ++w) hdr[56 + w] = __hip_atomic_load(p + 12 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hdr[16] = __hip_atomic_load(p + G2G_DIAG + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hdr[17] = __hip_atomic_load(p + G2G_DIAG + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int w = 0; w < 8; ++w) hdr[56 + w] = __hip_atomic_load(p + G2G_DIAG + 12 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     for (int k = 0; k < 256; ++k) __builtin_amdgcn_s_sleep(8);
-                    hdr[18] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hdr[19] = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    for (int w = 0; w < 4; ++w) hdr[42 + w] = __hip_atomic_load(p + 8 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the producer's waves at their last publish (v2 / v3 strips)
+                    hdr[18] = __hip_atomic_load(p + G2G_DIAG + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hdr[19] = __hip_atomic_load(p + G2G_DIAG + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int w = 0; w < 4; ++w) hdr[42 + w] = __hip_atomic_load(p + G2G_DIAG + 8 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the producer's waves at their last publish (v2 / v3 strips)
                     // per-wave heartbeats of a v2 / v3 producer (builds with -DG2G_HEARTBEAT: (step, place) of each of its waves,
                     // G2G_HB below), read now and once more behind the 50 us above: which wave stands still, and where
                     for (int w = 0; w < 8; ++w) hdr[48 + w] = hdr[56 + w];
-                    for (int w = 0; w < 8; ++w) hdr[56 + w] = __hip_atomic_load(p + 12 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int w = 0; w < 8; ++w) hdr[56 + w] = __hip_atomic_load(p + G2G_DIAG + 12 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    {   // the BLOCKER: walk down the strips of this DP from the polled word while they have not published anything in this
+                        // generation; the lowest such strip has a finished strip (or the top chain) above it -- it waits for nobody's
+                        // progress, so where IT stands is the question.  Its markers (v2 strips): +5 taken from the queue by workgroup
+                        // (0x20000 | id), +6 past the wait for the left chain, +7 past the first look at the strip above.
+                        int kb = 0;
+                        const int gen_now = want & ~0xFFFFF;
+                        for (int k = 1; k < 64 && off - k * G2G_FSTRIDE >= G2G_HDR + G2G_HDRN; ++k) {
+                            const int w = __hip_atomic_load(p - k * G2G_FSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (w >= (gen_now | 1)) break;            // published something in this generation
+                            kb = k;
+                        }
+                        const int *q = p - kb * G2G_FSTRIDE;
+                        hdr[64] = kb;
+                        hdr[65] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int w = 0; w < 5; ++w) hdr[66 + w] = __hip_atomic_load(q + G2G_DIAG + 3 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        hdr[71] = __hip_atomic_load(q + G2G_DIAG + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    // sweep mode with the chains in the queue: the two chain words of this DP sit right below its first strip's word
+                    if (off - (slot + 1) * G2G_FSTRIDE >= G2G_HDR + G2G_HDRN) {
+                        hdr[80] = __hip_atomic_load(p - slot * G2G_FSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // left chain
+                        hdr[81] = __hip_atomic_load(p - (slot + 1) * G2G_FSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // top chain
+                    }
                     hdr[8 + 38] = atomicAdd((int *) p, 0);          // the same word through a read-modify-write (executes at the coherent point)
                     hdr[8 + 39] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -138,8 +186,8 @@ __device__ __forceinline__ bool g2g_dp_failed(const int *failp) { return __hip_a
 // write-through stores per step and wave.  Places (v2): 1 top of the step, 2 publish entered, 3 behind the publish barrier,
 // 4 waiting for the strip above, 5 behind the column-score block, 6 sources staged, 7 cell done, 8 at the step's barrier.
 #ifdef G2G_HEARTBEAT
-#define G2G_HB_STEP(pself, w, s) { if (pself) __hip_atomic_store((pself) + 12 + 2 * (w), (int) (s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#define G2G_HB(pself, w, k) { if (pself) __hip_atomic_store((pself) + 13 + 2 * (w), (int) (k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define G2G_HB_STEP(pself, w, s) { if (pself) __hip_atomic_store((pself) + G2G_DIAG + 12 + 2 * (w), (int) (s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define G2G_HB(pself, w, k) { if (pself) __hip_atomic_store((pself) + G2G_DIAG + 13 + 2 * (w), (int) (k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #else
 #define G2G_HB_STEP(pself, w, s)
 #define G2G_HB(pself, w, k)
@@ -423,7 +471,7 @@ __device__ __forceinline__ void chain_publish(int *prog, int penc, int v)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(prog, penc | (v < 0xFFFFF ? v : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    G2G_POST(prog, penc | (v < 0xFFFFF ? v : 0xFFFFF));
 }
 // ---- prologue: the boundary chains of initB (fwd2c.h:138-176), one lane each, lists straight from HBM
 template <int KIND>
@@ -923,6 +971,8 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
     const int m_left_last = b.left - rrl;                  // last row whose corner (m, b.left) exists
     const LRec black = G.extra(EX_BLACK);
     const int m0 = a.left + ti * R, m = m0 + team;
+    // markers for the time-out report of whoever ends up waiting for this strip (g2g_wait_ge): taken from the queue, by which workgroup
+    if (prog_self) __hip_atomic_store(prog_self + G2G_DIAG + 5, ((pgen & 0x7FF) << 20) | 0x20000 | (int) (blockIdx.x & 0xFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prog_left) {                                       // sweep mode: the left boundary chain runs beside the strips (v2_chain_tile)
         const int rows_ = m0 + R - a.left;
         const int wantl = ((pgen & 0x7FF) << 20) | (rows_ < 0xFFFFF ? rows_ : 0xFFFFF);
@@ -930,6 +980,7 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    if (prog_self) __hip_atomic_store(prog_self + G2G_DIAG + 6, ((pgen & 0x7FF) << 20) | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ... past the left chain
     const int c0 = b.left + tj * C;
     int c1 = c0 + C; if (c1 > b.right) c1 = b.right;
     const bool row_ok = m < a.right;
@@ -1008,16 +1059,17 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // every wave leaves the column it publishes at before it enters the barrier (all lanes, same word, same value): if this
         // workgroup ever stops here, the report of whoever waits for it shows which wave did not arrive (g2g_wait_ge, hdr[42..45])
-        __hip_atomic_store(prog_self + 8 + (tid >> 6), col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(prog_self + G2G_DIAG + 8 + (tid >> 6), col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         G2G_HB(prog_self, tid >> 6, 2)
         __syncthreads();
         G2G_HB(prog_self, tid >> 6, 3)
-        __hip_atomic_store(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        G2G_POST(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF));
     };
     need(cbase + 2);
+    if (prog_self) __hip_atomic_store(prog_self + G2G_DIAG + 7, ((pgen & 0x7FF) << 20) | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ... past the first look at the strip above
     if (prog_self && tid < 64) {                           // (the whole first wave, same value: no one-lane branch) where this strip runs: for the time-out report of whoever waits for it (g2g_wait_ge)
-        __hip_atomic_store(prog_self + 3, (int) __builtin_amdgcn_s_getreg((31 << 11) | 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(prog_self + 4, 0x100 | ((int) __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(prog_self + G2G_DIAG + 3, (int) __builtin_amdgcn_s_getreg((31 << 11) | 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(prog_self + G2G_DIAG + 4, 0x100 | ((int) __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #ifdef G2G_V2_STAMP
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1430,7 +1482,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         const int dp_dead = s_vals[0];                                                              \
         __syncthreads();                                                                            \
         if (dp_dead) {                    /* this DP lost a wait: its strips are skipped, dependents released */ \
-            if (threadIdx.x == 0) __hip_atomic_store(done + T.self, sweep ? (((gen & 0x7FF) << 20) | 0xFFFFF) : gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            if (threadIdx.x == 0) G2G_POST(done + T.self, sweep ? (((gen & 0x7FF) << 20) | 0xFFFFF) : gen); \
             __syncthreads();                                                                        \
             continue;                                                                               \
         }                                                                                           \
@@ -1457,7 +1509,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         if (!sweep) {                                                                               \
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                                      \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
-            __hip_atomic_store(done + T.self, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     \
+            G2G_POST(done + T.self, gen);     \
         }                                                                                           \
     }                                                                                               \
 }

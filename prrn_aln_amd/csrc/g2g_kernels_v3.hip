@@ -692,16 +692,16 @@ __device__ __forceinline__ void v3_tile(const DevProb &Pmem, lchar *lds, const V
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             G2G_RELEASE();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(prog_self + 8, col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (as the v2 strips: the wave's last publish, for the time-out report)
-            __hip_atomic_store(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(prog_self + G2G_DIAG + 8, col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (as the v2 strips: the wave's last publish, for the time-out report)
+            G2G_POST(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF));
         }
     };
     if (lane < 28) stsc[lane] = 0;
     team_sync();
     need(cbase + 1 <= c1 ? cbase + 1 : cbase);
     if (prog_self) {                                       // where this strip runs: for the time-out report of whoever waits for it (g2g_wait_ge)
-        __hip_atomic_store(prog_self + 3, (int) __builtin_amdgcn_s_getreg((31 << 11) | 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(prog_self + 4, 0x100 | ((int) __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(prog_self + G2G_DIAG + 3, (int) __builtin_amdgcn_s_getreg((31 << 11) | 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(prog_self + G2G_DIAG + 4, 0x100 | ((int) __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     {
         unsigned rh = 0, rg = 0, rg2 = 0;
@@ -889,7 +889,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         const int dp_dead = s_vals[0];                                                              \
         __syncthreads();                                                                            \
         if (dp_dead) {                    /* this DP lost a wait: its strips are skipped, dependents released */ \
-            if (threadIdx.x == 0) __hip_atomic_store(done + T.self, sweep ? (((gen & 0x7FF) << 20) | 0xFFFFF) : gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            if (threadIdx.x == 0) G2G_POST(done + T.self, sweep ? (((gen & 0x7FF) << 20) | 0xFFFFF) : gen); \
             __syncthreads();                                                                        \
             continue;                                                                               \
         }                                                                                           \
@@ -914,7 +914,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         if (!sweep) {                                                                               \
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                                      \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
-            __hip_atomic_store(done + T.self, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     \
+            G2G_POST(done + T.self, gen);     \
         }                                                                                           \
     }                                                                                               \
 }

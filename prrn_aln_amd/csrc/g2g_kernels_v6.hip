@@ -644,8 +644,8 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
 // strip's progress word; the report of a time-out reads them (g2g_wait_ge).  Off by default: ten 4-byte write-through stores
 // per step are ~30 GB/s of fabric traffic for nothing.
 #if defined(G2G_V6_HEARTBEAT) || defined(G2G_HEARTBEAT)
-#define V6_MARK(k) { if (prog_self) __hip_atomic_store(prog_self + 2, (k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#define V6_BEAT(s) { if (prog_self) __hip_atomic_store(prog_self + 1, (s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define V6_MARK(k) { if (prog_self) __hip_atomic_store(prog_self + G2G_DIAG + 2, (k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define V6_BEAT(s) { if (prog_self) __hip_atomic_store(prog_self + G2G_DIAG + 1, (s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #else
 #define V6_MARK(k)
 #define V6_BEAT(s)
@@ -658,7 +658,7 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
             V6_RELEASE();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             V6_MARK(11)
-            __hip_atomic_store(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            G2G_POST(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF));
             V6_MARK(12)
         }
     };
@@ -724,8 +724,8 @@ __device__ __forceinline__ void v6_strip(const DevProb &Pmem, lchar *lds, const 
     unsigned long long st_t = __builtin_amdgcn_s_memtime();
 #endif
     if (prog_self) {                                       // where this strip runs (read by the report of a time-out, g2g_wait_ge)
-        __hip_atomic_store(prog_self + 3, (int) __builtin_amdgcn_s_getreg((31 << 11) | 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(prog_self + 4, 0x100 | ((int) __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(prog_self + G2G_DIAG + 3, (int) __builtin_amdgcn_s_getreg((31 << 11) | 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(prog_self + G2G_DIAG + 4, 0x100 | ((int) __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int s = 0; s < nsteps; ++s) {
         V6_STAMP(9)
@@ -864,7 +864,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         const int dp_dead = s_vals[0];                                                              \
         __syncthreads();                                                                            \
         if (dp_dead) {                    /* this DP lost a wait: its strips are skipped, dependents released */ \
-            if (threadIdx.x == 0) __hip_atomic_store(done + T.self, ((gen & 0x7FF) << 20) | 0xFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            if (threadIdx.x == 0) G2G_POST(done + T.self, ((gen & 0x7FF) << 20) | 0xFFFFF); \
             __syncthreads();                                                                        \
             continue;                                                                               \
         }                                                                                           \

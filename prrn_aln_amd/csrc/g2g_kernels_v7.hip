@@ -130,7 +130,7 @@ __device__ __forceinline__ void v7_strip(const DevProb &Pmem, lchar *lds, const 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            G2G_POST(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF));
         }
     };
     if (lane < 28) stsc[lane] = 0;
@@ -273,7 +273,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         const int dp_dead = s_vals[0];                                                              \
         __syncthreads();                                                                            \
         if (dp_dead) {                                                                              \
-            if (threadIdx.x == 0) __hip_atomic_store(done + T.self, ((gen & 0x7FF) << 20) | 0xFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            if (threadIdx.x == 0) G2G_POST(done + T.self, ((gen & 0x7FF) << 20) | 0xFFFFF); \
             __syncthreads();                                                                        \
             continue;                                                                               \
         }                                                                                           \

@@ -31,3 +31,20 @@ def test_pairsum_matches_reference(ctx, path):
         tree = KTree(t["left"], t["right"], t["parent"], t["vol"], t["cur"])
         got = pairsum(ctx, pairsumlib.case_codes(c), tree, alp, use_pw=bool(c["use_pw"]))
         assert got == c["value"], (f["name"], c["use_pw"], got, c["value"])
+
+
+def test_pairsum_of_the_256_member_bench_family_matches_the_reference(ctx):
+    """the headline fixture itself: every Ssrel::pairsum_ss value the reference computed in `prrn5 -YH0 -R1 -O4` on the 256 x 1024 aa
+    family (tools/make_refine_pairsum.py): the start MSA and the refined MSA on the refinement's tree, and the two -O4 read-outs
+    (unweighted, weighted) on the tree the reference rebuilt from the refined MSA -- 256 members, four levels of the tree recursion"""
+    import gzip
+    from prrn_aln_amd import operator as op
+    f = json.load(gzip.open(os.path.join(os.path.dirname(__file__), "golden", "refine_prot256x1024_prog.json.gz"), "rt"))
+    alp = op.AlnParam(ls=f["ls"], molc=f["molc"], max_code=25)
+    msa = {"start": op.encode(f["rows"], f["molc"]), "final": op.encode(f["final_rows"], f["molc"])}
+    assert len(f["pairsum_ss"]) == 4 and len(f["rows"]) == 256
+    for c in f["pairsum_ss"]:
+        t = c["tree"] or f["tree"]
+        tree = KTree(t["left"], t["right"], t["parent"], t["vol"], t["cur"])
+        got = pairsum(ctx, msa[c["msa"]], tree, alp, use_pw=bool(c["use_pw"]))
+        assert got == c["value"], (c["msa"], c["use_pw"], c["tree_is"], got, c["value"])
