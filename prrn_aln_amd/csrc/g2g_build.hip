@@ -205,22 +205,41 @@ __global__ __launch_bounds__(64) void g2g_build_gfq_kernel(const BGroup *G, cons
         so = 1; to = ro = lead ? 2 : 1;
         if (lead) longest = 2;
     }
-    for (int pos = 0; pos < len && !overflow; ++pos) {
+    // Everything a column needs from HBM -- its members' codes (up to 256 members: four registers per lane; larger groups read
+    // theirs in place) and its three sums -- is loaded FOUR COLUMNS AHEAD into a rotating set of registers: the walk is a chain of
+    // dependent steps of about half a microsecond, an HBM load takes two, and a load waited for inside the step that uses it made
+    // the walk take 5.7 us per column.
+    const bool pre = many <= 256;
+    int pf_code[4][4];
+    double pf_w[4][3];
+    int pf_n[4][3];
+#define BG_FETCH(U, POS) { \
+        const int pp_ = (POS); \
+        if (pp_ < len) { \
+            const uint8_t *q_ = g.seq + (size_t) (pp_ + 1) * many; \
+            if (pre) { _Pragma("unroll") for (int u = 0; u < 4; ++u) { const int i_ = u * 64 + lane; pf_code[U][u] = i_ < many ? (int) q_[i_] : 2; } } \
+            _Pragma("unroll") for (int u = 0; u < 3; ++u) { pf_w[U][u] = g.colsum[(size_t) pp_ * 3 + u]; pf_n[U][u] = g.coln[(size_t) pp_ * 3 + u]; } \
+        } }
+    auto column = [&](const int pos, const int c0_, const int c1_, const int c2_, const int c3_, const double plain_w, const double post_w, const double open_w,
+                      const int plain_n, const int post_n, const int open_n) __attribute__((always_inline)) {
+        const int cu_code[4] = {c0_, c1_, c2_, c3_};
         if (lane < ncls) { cl_len += 1; cl_sw = 0; cl_sn = 0; }
         // members that leave a gap run here: out of their class's running weight, into its s face -- one by one, in member order
         const uint8_t *cur = g.seq + (size_t) (pos + 1) * many;
         for (int c = 0; c < many; c += 64) {
             const int i = c + lane;
             const bool valid = i < many;
-            const int code = valid ? (int) cur[i] : 2;
+            const int u_ = c >> 6;
+            const int code = !valid ? 2 : pre ? (u_ == 0 ? cu_code[0] : u_ == 1 ? cu_code[1] : u_ == 2 ? cu_code[2] : cu_code[3]) : (int) cur[i];
             const int r = valid ? run[i] : 0;
+            const double wv = valid ? w[i] : 0.;                // (read with the chunk, handed out by readlane: no LDS latency per leaving member)
             const bool is_gap = code == B_GAP;
             unsigned long long leaving = __ballot(valid && !is_gap && r > 0);
             while (leaving) {
                 const int j = __builtin_ctzll(leaving);
                 leaving &= leaving - 1;
                 const int li = __builtin_amdgcn_readlane(r, j);
-                const double wi = w[c + j];
+                const double wi = bg_readlane(wv, j);
                 const unsigned long long hit = __ballot(lane < ncls && cl_len == li);
                 if (hit) {
                     const int k = __builtin_ctzll(hit);
@@ -229,8 +248,6 @@ __global__ __launch_bounds__(64) void g2g_build_gfq_kernel(const BGroup *G, cons
             }
             if (valid) run[i] = is_gap ? r + 1 : 0;
         }
-        const double plain_w = g.colsum[(size_t) pos * 3], post_w = g.colsum[(size_t) pos * 3 + 1], open_w = g.colsum[(size_t) pos * 3 + 2];
-        const int plain_n = g.coln[(size_t) pos * 3], post_n = g.coln[(size_t) pos * 3 + 1], open_n = g.coln[(size_t) pos * 3 + 2];
         // s view: [plain] + the classes somebody left at this column, suffix sums from the far end
         {
             const unsigned long long bs = __ballot(lane < ncls && cl_sn > 0);
@@ -260,7 +277,7 @@ __global__ __launch_bounds__(64) void g2g_build_gfq_kernel(const BGroup *G, cons
             const unsigned long long bt = __ballot(keep);
             const int ho = open_n ? 1 : 0, nt = ho + __builtin_popcountll(bt), hq = post_n ? 1 : 0, nr = hq + nt;
             const int nidx = ho + __builtin_popcountll(bt & ((1ull << lane) - 1));
-            if (nt > 64) { overflow = 1; break; }
+            if (nt > 64) { overflow = 1; return; }
             if (FILL) {
                 if (lane == 0) {
                     g.off[1][pos + 1] = to; g.off[2][pos + 1] = ro;
@@ -286,7 +303,24 @@ __global__ __launch_bounds__(64) void g2g_build_gfq_kernel(const BGroup *G, cons
             cl_sw = 0; cl_sn = 0;
             bg_sync();
         }
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { _Pragma("unroll") for (int k = 0; k < 4; ++k) pf_code[u][k] = 2; _Pragma("unroll") for (int k = 0; k < 3; ++k) { pf_w[u][k] = 0; pf_n[u][k] = 0; } }
+    BG_FETCH(0, 0) BG_FETCH(1, 1) BG_FETCH(2, 2) BG_FETCH(3, 3)
+    for (int pos0 = 0; pos0 < len && !overflow; pos0 += 4) {
+#define BG_STEP(U) { \
+            const int pos_ = pos0 + U; \
+            if (pos_ < len && !overflow) { \
+                const int a0_ = pf_code[U][0], a1_ = pf_code[U][1], a2_ = pf_code[U][2], a3_ = pf_code[U][3]; \
+                const double w0_ = pf_w[U][0], w1_ = pf_w[U][1], w2_ = pf_w[U][2]; \
+                const int n0_ = pf_n[U][0], n1_ = pf_n[U][1], n2_ = pf_n[U][2]; \
+                BG_FETCH(U, pos_ + 4) \
+                column(pos_, a0_, a1_, a2_, a3_, w0_, w1_, w2_, n0_, n1_, n2_); \
+            } }
+        BG_STEP(0) BG_STEP(1) BG_STEP(2) BG_STEP(3)
+#undef BG_STEP
     }
+#undef BG_FETCH
     if (lane == 0) {
         if (FILL) { g.off[0][len + 1] = so; g.off[1][len + 1] = to; g.off[2][len + 1] = ro; }
         else { g.counts[0] = so; g.counts[1] = to; g.counts[2] = ro; g.counts[3] = most; g.counts[4] = longest; g.counts[5] = overflow; }
@@ -349,9 +383,6 @@ int g2g_device_derive(g2g_ctx *ctx, const g2g_params *prm, int n, g2g_group *con
         if (g.has_weight) b.weight = OFF<const double>(bl.put(g.weight.data(), sizeof(double) * (size_t) g.many));
         if (g.dels) {
             o_thk[k] = out_take(sizeof(double) * 3 * (size_t) (g.len + 2));
-            o_cs[k] = out_take(sizeof(double) * 3 * (size_t) g.len);
-            o_cn[k] = out_take(sizeof(int) * 3 * (size_t) g.len);
-            o_cnt[k] = out_take(sizeof(int) * 8);
             for (int c = 0; c < g.len; c += 256) cblocks.push_back(make_int2(k, c));
             if (need[k] & G2G_NEED_GFQ) gfq_groups.push_back(k);
             max_many = std::max(max_many, (size_t) g.many);
@@ -365,6 +396,14 @@ int g2g_device_derive(g2g_ctx *ctx, const g2g_params *prm, int n, g2g_group *con
             for (int c = 0; c < g.len + 2; c += BV_THREADS) vblocks.push_back(make_int2(k, c));
             max_nelm = std::max(max_nelm, b.nelm_vec);
         }
+    }
+    const size_t dl_bytes = out_bytes;                            // what goes back to the host ends here; device-only scratch behind it
+    for (int k = 0; k < n; ++k) {
+        const g2g_group &g = *groups[k];
+        if (!g.dels) continue;
+        o_cs[k] = out_take(sizeof(double) * 3 * (size_t) g.len);
+        o_cn[k] = out_take(sizeof(int) * 3 * (size_t) g.len);
+        o_cnt[k] = out_take(sizeof(int) * 8);
     }
     const size_t cb_off = bl.put(cblocks.data(), sizeof(int2) * cblocks.size());
     const size_t vb_off = bl.put(vblocks.data(), sizeof(int2) * vblocks.size());
@@ -434,6 +473,7 @@ int g2g_device_derive(g2g_ctx *ctx, const g2g_params *prm, int n, g2g_group *con
         }
         d2 = (char *) pool_take(ctx, pool_bytes + 256, &cap2);
         if (!d2) return fail(G2G_ERR_NOMEM, "g2g_device_derive: out of device memory%s", hipSuccess);
+        lap("device memory for the pools");
         for (size_t q = 0; q < gfq_groups.size(); ++q) {
             BGroup &b = tab[(size_t) gfq_groups[q]];
             for (int v = 0; v < 3; ++v) { b.off[v] = (int *) (d2 + o_off[3 * q + v]); b.glen[v] = (int *) (d2 + o_gl[3 * q + v]); b.freq[v] = (double *) (d2 + o_fr[3 * q + v]); }
@@ -476,19 +516,20 @@ int g2g_device_derive(g2g_ctx *ctx, const g2g_params *prm, int n, g2g_group *con
     }
     // device -> pinned staging in a few large copies (the outputs are contiguous per slab), then into the vectors on host threads
     {
-        const size_t s1 = out_bytes, s2 = d2 ? cap2 : 0;
+        size_t used2 = 0;
+        for (size_t q = 0; q < gfq_groups.size(); ++q) { const BGroup &b = tab[(size_t) gfq_groups[q]]; used2 = std::max(used2, (size_t) ((const char *) b.freq[2] - d2) + sizeof(double) * (size_t) counts[8 * q + 2]); }
+        const size_t s1 = dl_bytes, s2 = used2;
         if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(G2G_ERR_DEVICE, "g2g_device_derive: kernels: %s", e);      // (the staging buffer is reused below: no upload may still read it)
+        lap("fill pass");
         bl.sz = 0;
         bl.grow(s1 + s2 + 512);
         if (bl.oom) return fail(G2G_ERR_NOMEM, "g2g_device_derive: host staging buffer%s", hipSuccess);
         char *h1 = bl.data(), *h2 = bl.data() + ((s1 + 255) & ~(size_t) 255);
-        size_t used2 = 0;
-        for (size_t q = 0; q < gfq_groups.size(); ++q) { const BGroup &b = tab[(size_t) gfq_groups[q]]; used2 = std::max(used2, (size_t) ((const char *) b.freq[2] - d2) + sizeof(double) * (size_t) counts[8 * q + 2]); }
         e = s1 ? hipMemcpyAsync(h1, dout, s1, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
         if (e == hipSuccess && used2) e = hipMemcpyAsync(h2, d2, used2, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) return fail(G2G_ERR_DEVICE, "g2g_device_derive: download: %s", e);
-        lap("fill pass, download");
+        lap("download into the staging buffer");
         unsigned nthr = std::thread::hardware_concurrency();
         if (nthr > 16) nthr = 16;
         if (nthr < 1) nthr = 1;

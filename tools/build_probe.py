@@ -15,12 +15,14 @@ from prrn_aln_amd.synth import make_family
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 80
-fam = make_family(n, L, 3, indel=0.03)
+fam = make_family(n, L, 1) if n >= 100 else make_family(n, L, 3, indel=0.03)
 alp = op.AlnParam()
 ctx = engine.Context()
 t = time.perf_counter(); a = sweep.Sweep(fam, alp, weighted=True); th = time.perf_counter() - t
 print("host: %.1f ms (%d divisions)" % (1e3 * th, len(a)), flush=True)
-for rep in range(2):
+b = None
+for rep in range(3):
+    b = None                        # (the previous sweep's device slabs go back to the pool first, as in a refinement loop)
     t = time.perf_counter(); b = sweep.Sweep(fam, alp, weighted=True, ctx=ctx); td = time.perf_counter() - t
     print("device: %.1f ms (split %.1f, batch %.1f)" % (1e3 * td, 1e3 * b.t_split, 1e3 * b.t_batch), flush=True)
 from test_gpu_builders import same_problem
