@@ -51,6 +51,7 @@ enum { XH = 0, XG = 1, XG2 = 2, XF = 3, XF2 = 4, XBT = 5, XBL = 6, NX = 7 };
 
 struct DevProb {
     int kind;            // 0 DPunit, 1 _hf, 2 _pf, 3 _nv   (reference src/dpunit.h:31-51)
+    int rect;            // 1: the rectangular engine Fwd2c::forwardA (the _ALN modes, `-A`; src/fwd2c.h:232-356) -- g2g_forward_kernel, DPunit only
     int noll, sim2_kind, crg2_kind, codonk1, lw, up, width;
     double basic_gop, weighted_gop, u, u2divu1, v2divv1;
     int dvsp;            // PwdB::DvsP (0: nucleotide x nucleotide)

@@ -528,13 +528,19 @@ static V3Need v3_need(const DevProb &d, const g2g_problem *p, int C, bool areg =
 static int kind_of(int alnmode)
 {
     switch (alnmode) {
-    case G2G_NGP_ALB: return 0;
+    case G2G_NGP_ALB: case G2G_NGP_ALN: return 0;
     case G2G_HLF_ALB: case G2G_RHF_ALB: return 1;
     case G2G_GPF_ALB: return 2;
     case G2G_NTV_ALB: return 3;
     }
+    // The other rectangular modes (HLF / RHF / GPF / NTV_ALN) are NOT on this path, for a reason: Fwd2c::forwardA starts every row
+    // with `*hdiag = *h` (src/fwd2c.h:247), a struct assignment that makes the diagonal record SHARE the left boundary record's
+    // gap-state arrays; from then on a growing triangle of records is updated in place through one array, in the row-major order
+    // of the reference's loop.  The restatement in oracle/ reproduces that (all 21 rectangular goldens, every record type), but the
+    // result depends on a sequential order no anti-diagonal sweep has.  DPunit carries no arrays: NGP_ALN is exact and built.
     return -1;
 }
+static bool is_rect(int alnmode) { return alnmode == G2G_NGP_ALN; }
 
 static int check_problem(const g2g_problem *p)
 {
@@ -547,13 +553,17 @@ static int check_problem(const g2g_problem *p)
         if (s[k]->many < 1 || s[k]->len < 1 || !s[k]->seq || !s[k]->thk) return G2G_ERR_ARG;
         if (s[k]->left < 0 || s[k]->right > s[k]->len || s[k]->left >= s[k]->right) return G2G_ERR_ARG;
     }
+    if (is_rect(p->alnmode)) {                       // the caller's band is not read: the DP covers the rectangle
+        if (p->spb_fact != 0 && p->a.npfq > 0 && p->b.npfq > 0) return G2G_ERR_MODE;      // (the intron bonus table is forwardB's)
+    } else {
     if (p->up < p->lw) return G2G_ERR_ARG;
+    // the end corner must lie inside the band (stripe() guarantees it, aln2.cc:156-174)
+    const int re_ = p->b.right - p->a.right, rs_ = p->b.left - p->a.left;
+    if (re_ < p->lw || re_ > p->up || rs_ < p->lw || rs_ > p->up) return G2G_ERR_ARG;
+    }
     if (kind == 1 && !p->a.has_gfq) return G2G_ERR_ARG;
     if (kind == 2 && (!p->a.has_gfq || !p->b.has_gfq)) return G2G_ERR_ARG;
     if (kind == 3 && (!p->a.gapdens || !p->b.gapdens || !p->a.postgapdens || !p->b.postgapdens || !p->crg2_kind)) return G2G_ERR_ARG;
-    // the end corner must lie inside the band (stripe() guarantees it, aln2.cc:156-174)
-    int re = p->b.right - p->a.right, rs = p->b.left - p->a.left;
-    if (re < p->lw || re > p->up || rs < p->lw || rs > p->up) return G2G_ERR_ARG;
     switch (p->sim2_kind) {
     case G2G_SIM00: case G2G_SIM11: case G2G_SIM12I: case G2G_SIM21I: case G2G_SIM22I: break;
     case G2G_SIM12W: if (!p->b.weight) return G2G_ERR_ARG; break;
@@ -750,7 +760,10 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         if (rc) { d.kind = -1; continue; }
         d.kind = kind_of(p->alnmode);
         d.noll = p->noll; d.sim2_kind = p->sim2_kind; d.crg2_kind = p->crg2_kind; d.codonk1 = p->codonk1;
-        d.lw = p->lw; d.up = p->up; d.width = p->up - p->lw + 3;
+        d.rect = is_rect(p->alnmode) ? 1 : 0;
+        d.lw = p->lw; d.up = p->up;
+        if (d.rect) { d.lw = p->b.left - p->a.right; d.up = p->b.right - p->a.left; }     // every cell and every boundary corner inside
+        d.width = d.up - d.lw + 3;
         d.basic_gop = p->basic_gop; d.weighted_gop = p->weighted_gop; d.u = p->u;
         d.u2divu1 = p->u2divu1; d.v2divv1 = p->v2divv1;
         d.simdim = p->simdim;
@@ -858,7 +871,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         d.trace = OFF<uint8_t>(take((size_t) (d.d1 - d.d0 + 1) * tmax));
         // v2 kernel (gap-profile engines): packed 16-bit gap lengths and an LDS budget decide eligibility
         d.v2_ok = 0;
-        if (d.kind == 0 && !force_v1 && !g2g_opt(ctx, "FORCE_V1") && !g2g_opt(ctx, "NO_V7")) d.v2_ok = 7;      // DPunit: strips without gap state
+        if (d.kind == 0 && !d.rect && !force_v1 && !g2g_opt(ctx, "FORCE_V1") && !g2g_opt(ctx, "NO_V7")) d.v2_ok = 7;      // DPunit: strips without gap state (the rectangular engine: g2g_forward_kernel)
         if (d.kind == 3 && !force_v1 && !g2g_opt(ctx, "FORCE_V1") && !g2g_opt(ctx, "NO_V8")) {
             // DPunit_nv: strips with the members' gap lengths in registers, for the member counts selAlnMode sends this way
             const int an = p->a.many, bn = p->b.many, ck = p->crg2_kind;
@@ -1826,7 +1839,7 @@ static size_t problem_bytes(const g2g_ctx *ctx, const g2g_problem *p)
     int tmax = 1;
     for (int dd = al + bl; dd <= (ar - 1) + (br - 1); ++dd) {
         int mlo, mhi;
-        diag_rows(dd, al, ar, bl, br, p->lw, p->up, &mlo, &mhi);
+        diag_rows(dd, al, ar, bl, br, is_rect(p->alnmode) ? bl - ar : p->lw, is_rect(p->alnmode) ? br - al : p->up, &mlo, &mhi);
         const int c = mhi - mlo + 1;
         if (c > 0) cells += c;
         if (c > tmax) tmax = c;
@@ -1842,7 +1855,7 @@ static size_t problem_bytes(const g2g_ctx *ctx, const g2g_problem *p)
         if (sd[k]->has_gfq) for (int v = 0; v < 3; ++v) bytes += 12 * (size_t) sd[k]->gfq.off[v][sd[k]->len + 1] + 4 * cols;
     }
     const size_t lists = 8 * (size_t) ((p->a.has_gfq ? p->a.gfq.hetero + 1 : p->a.many) + (p->b.has_gfq ? p->b.gfq.hetero + 1 : p->b.many));
-    bytes += (size_t) (p->up - p->lw + 3) * 7 * (16 + lists);                                   // v1 state rows
+    bytes += (size_t) ((is_rect(p->alnmode) ? (br - al) - (bl - ar) : p->up - p->lw) + 3) * 7 * (16 + lists);      // v1 state rows
     bytes += (size_t) (p->b.len + 3 + ar - al + 3) * 9 * (16 + lists / 2 + 16);                 // strip / block boundary records
     bytes += 8 * (size_t) (ar - al + 2) + 8 * (size_t) (ar - al + br - bl + 8) + 4096;
     return bytes;

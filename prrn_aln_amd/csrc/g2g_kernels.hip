@@ -439,7 +439,9 @@ __device__ void top_step(const DevProb &P, int n)           // corner (a.left, n
     const Rec cur = {XBT, k & 1}, prv = {XBT, (k - 1) & 1}, h = {XH, (n - a.left) - (P.lw - 1)};
     const double pub = unpb(P, bi, ai);
     double gnp = gapopen<KIND>(P, prv, ai, bi, -1);
-    gnp = (n - b.left < P.codonk1) ? gnp + pub : (P.v2divv1 * gnp + P.u2divu1 * pub);
+    // (initA's loop variable is the COLUMN the step consumes, one less than the corner it produces: its long-gap switch comes one
+    //  corner later than initB's, fwd2c.h:128-133 against :151-158)
+    gnp = (n - P.rect - b.left < P.codonk1) ? gnp + pub : (P.v2divv1 * gnp + P.u2divu1 * pub);
     update<KIND>(P, cur, prv, ai, bi, gnp, -1);
     rec_copy<KIND>(P, h, cur);
 }
@@ -447,12 +449,15 @@ template <int KIND>
 __device__ void left_step(const DevProb &P, int m)          // corner (m, b.left), a.left < m <= b.left - rr
 {
     const DevSide &a = P.a, &b = P.b;
-    const int ai = m - 1, bi = b.left - 1;
+    // forwardA (rect) advances its left boundary at the start of every row with b's iterator wherever the previous row left it
+    // -- position 0 before the first row, b.right afterwards (the reference never resets it, fwd2c.h:244-252) -- and without the
+    // long-gap switch
+    const int ai = m - 1, bi = P.rect ? (ai == a.left ? 0 : b.right) : b.left - 1;
     const int k = m - a.left;
     const Rec cur = {XBL, k & 1}, prv = {XBL, (k - 1) & 1}, h = {XH, (b.left - m) - (P.lw - 1)};
     const double pua = unpa(P, ai, bi);
     double gnp = gapopen<KIND>(P, prv, ai, bi, 1);
-    gnp = (m - a.left < P.codonk1) ? gnp + pua : (P.v2divv1 * gnp + P.u2divu1 * pua);
+    gnp = (P.rect || m - a.left < P.codonk1) ? gnp + pua : (P.v2divv1 * gnp + P.u2divu1 * pua);
     update<KIND>(P, cur, prv, ai, bi, gnp, 1);
     rec_copy<KIND>(P, h, cur);
 }
@@ -473,11 +478,13 @@ __device__ void cell(const DevProb &P, int m, int n, uint8_t *tr)
     update<KIND>(P, h, h, m, n, dab + gop, 0);
     Rec mx = g;
     int sel2 = 0;
-    if (m > a.left) {
+    // forwardA (P.rect): the first row may open a vertical gap from the top boundary and the first column a horizontal one from the
+    // left boundary (forwardB skips both), unpa is evaluated per cell, and Vertical2 opens at v2divv1 + gop (fwd2c.h:276)
+    if (m > a.left || P.rect) {
         // vertical; pua is evaluated once per row at the row's first column unless a.inex.nils
         // (fwd2c.h:380,402)
         int nf = m + P.lw; if (nf < b.left) nf = b.left;
-        const double pua = unpa(P, m, a.nils ? n : nf);
+        const double pua = unpa(P, m, (a.nils || P.rect) ? n : nf);
         double gnp = gapopen<KIND>(P, gu, m, n, 1);
         gop = gapopen<KIND>(P, hu, m, n, 1);
         const bool hu_nv = !isvert(dir_of(P, hu));
@@ -486,14 +493,14 @@ __device__ void cell(const DevProb &P, int m, int n, uint8_t *tr)
         val_of(P, g) += pua;
         if (NOLL3) {
             gnp = P.v2divv1 * gapopen<KIND>(P, g2u, m, n, 1);
-            gop = P.v2divv1 * gop;
+            gop = P.rect ? P.v2divv1 + gop : P.v2divv1 * gop;
             if (hu_nv && (val_of(P, hu) + gop > val_of(P, g2u) + gnp)) update<KIND>(P, g2, hu, m, n, gop, 1);
             else { update<KIND>(P, g2, g2u, m, n, gnp, 1); bits |= T_G2EXT; }
             val_of(P, g2) += P.u2divu1 * pua;
             if (val_of(P, g2) > val_of(P, mx)) { mx = g2; sel2 = 1; }
         }
     }
-    if (n > b.left) {
+    if (n > b.left || P.rect) {
         // horizontal: F(m, n-1) lives at diagonal index r-1 (the reference carries it in the scalar f1)
         const double pub = unpb(P, n, m);
         double gnp = gapopen<KIND>(P, fl, m, n, -1);
@@ -541,14 +548,24 @@ __device__ void run_forward(const DevProb &P)
     __syncthreads();
     if (tid == 0) {                                     // origin, fwd2c.h:145-149
         Rec h = {XH, (b.left - a.left) - (P.lw - 1)};
-        val_of(P, h) = 0; P.dir[XH][h.i] = D_DIAG;
-        val_of(P, Rec{XBT, 0}) = 0; P.dir[XBT][0] = D_DIAG;
-        val_of(P, Rec{XBL, 0}) = 0; P.dir[XBL][0] = D_DIAG;
+        const int odir = P.rect ? 0 : D_DIAG;           // initA clears the origin (direction DEAD, fwd2c.h:116), initB sets DIAG
+        val_of(P, h) = 0; P.dir[XH][h.i] = odir;
+        val_of(P, Rec{XBT, 0}) = 0; P.dir[XBT][0] = odir;
+        val_of(P, Rec{XBL, 0}) = 0; P.dir[XBL][0] = odir;
     }
     __syncthreads();
     int rrt = b.right - a.left; if (P.up < rrt) rrt = P.up;          // last top-chain diagonal
     int rrl = b.left - a.right; if (P.lw > rrl) rrl = P.lw;          // last left-chain diagonal
     const int n_top_last = a.left + rrt, m_left_last = b.left - rrl;
+    // forwardA's cells READ the boundary records forwardB's never look at -- the corner above a first-row cell, the corner left of a
+    // first-column cell -- so in rect mode the chains run one corner further ahead: the first corner of each before the sweep, then
+    // corner k + 2 during step k (the slot it lands in has neither reader nor writer on that anti-diagonal)
+    const int ahead = P.rect ? 1 : 0;
+    if (ahead) {
+        if (tid == 0 && b.left + 1 <= n_top_last) top_step<KIND>(P, b.left + 1);
+        if (tid == 1 % nt && a.left + 1 <= m_left_last) left_step<KIND>(P, a.left + 1);
+        __syncthreads();
+    }
     for (int d = P.d0; d <= P.d1; ++d) {
         int mlo, mhi;
         diag_rows(d, a.left, a.right, b.left, b.right, P.lw, P.up, &mlo, &mhi);
@@ -556,7 +573,7 @@ __device__ void run_forward(const DevProb &P)
         for (int m = mlo + tid; m <= mhi; m += nt) cell<KIND, NOLL3>(P, m, d - m, trow + (m - mlo));
         // boundary corners first read on anti-diagonal d + 1 (given to the threads with the fewest cells)
         const int cnt = mhi >= mlo ? mhi - mlo + 1 : 0;
-        const int nb = d + 1 - a.left, mb = d + 1 - b.left;
+        const int nb = d + 1 + ahead - a.left, mb = d + 1 + ahead - b.left;
         if (tid == (cnt + nt - 1) % nt && nb > b.left && nb <= n_top_last) top_step<KIND>(P, nb);
         if (tid == (cnt + nt - 2) % nt && mb > a.left && mb <= m_left_last) left_step<KIND>(P, mb);
         __syncthreads();

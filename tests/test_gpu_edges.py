@@ -12,7 +12,7 @@ from prrn_aln_amd import _abi, engine, operator as op, sweep
 from prrn_aln_amd.synth import make_family, DNA
 
 pytestmark = pytest.mark.gpu
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLD = [f for f in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))) if not os.path.basename(f).startswith("rect_")]   # (rect_*: the rectangular engine, tests/test_gpu_rect.py)
 
 
 @pytest.fixture(scope="module")
@@ -67,7 +67,7 @@ def test_bad_arguments_are_reported_per_problem(ctx):
         scr, cells, tr, st = res[i]
         assert st == 0 and scr == ds[i]["scr"][0] and np.array_equal(tr, ds[i]["vmf_trace"])
     hs[1].c.lw, hs[1].c.up = int(ds[1]["wdw_lw"].ravel()[0]), int(ds[1]["wdw_up"].ravel()[0])
-    hs[1].c.alnmode = 1                                # rectangular NGP_ALN: not on this path
+    hs[1].c.alnmode = 4                                # rectangular GPF_ALN: not on this path (tests/test_gpu_rect.py says why)
     res = ctx.forward_batch(hs)
     assert res[1][3] != 0 and res[0][3] == 0
 
@@ -144,7 +144,7 @@ def test_cu_shares_do_not_change_results(ctx):
     not fill the machine, 0 turns the shares off; the default decides by the run's size.  Same bits either way."""
     import glob, os
     from prrn_aln_amd import _abi
-    gold = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    gold = [f for f in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))) if not os.path.basename(f).startswith("rect_")]
     ds = [dict(np.load(f)) for f in gold]
     hs = [_abi.problem_from_arrays(d) for d in ds]
     for mode in ("2", "0"):

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 # (level 1 builds its groups from residue codes only: the goldens made from intron-annotated inputs -- exon-boundary lists, the
 #  bonus of fwd2c.h:446-452 -- are level-0 fixtures, tests/test_gpu_parity.py)
-GOLD = [f for f in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))) if not os.path.basename(f).startswith("intron_")]
+GOLD = [f for f in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))) if not os.path.basename(f).startswith(("intron_", "rect_"))]
 
 
 @pytest.fixture(scope="module")

@@ -37,7 +37,10 @@ def test_oracle_matches_reference(L, path):
     assert d["align2_scr"][0] == scr
 
 
-@pytest.mark.parametrize("path", GOLD[::5], ids=[os.path.basename(p)[:-4] for p in GOLD[::5]])
+BANDED = [f for f in GOLD if not os.path.basename(f).startswith("rect_")]      # (rect_*: the rectangular engine forwardA, `-A`)
+
+
+@pytest.mark.parametrize("path", BANDED[::5], ids=[os.path.basename(p)[:-4] for p in BANDED[::5]])
 def test_oracle_homscore(L, path):
     import ctypes as C
     d = dict(np.load(path))
@@ -72,4 +75,13 @@ def test_oracle_spscore(L, path):
 def test_oracle_spscore_scope(L):
     """every reference golden pins calcSpScore: plain, half- and full-profile units with Noll 2 and 3, and the naive units
     SPunit_nv / _w11 / _w21 / _w22"""
-    assert len(SP_GOLD) == len(GOLD) >= 59
+    assert len(SP_GOLD) == len(BANDED) >= 59
+
+
+def test_rectangular_goldens_present():
+    """Fwd2c::forwardA (reference src/fwd2c.h:232-356): 21 goldens made with algmode.bnd = 0, every record type, Noll 2 and 3 --
+    the restatement reproduces all of them (score and Vmf chain) INCLUDING the engines whose gap-state arrays the reference
+    aliases at the start of every row (`*hdiag = *h`, fwd2c.h:247)"""
+    rect = [f for f in GOLD if os.path.basename(f).startswith("rect_")]
+    modes = {int(np.load(f)["alnmode"][0]) for f in rect}
+    assert len(rect) >= 21 and modes == {1, 3, 4, 5}

@@ -214,7 +214,47 @@ def job_intron():
     assert n >= 4
 
 
-JOBS = {"intron": job_intron, "sim23": job_sim23, "protein": job_protein, "dna_ls3": job_dna_ls3, "protein_ls3": job_protein_ls3,
+def _rect_cases(R, tag, fam_kw, picks, weighted=True):
+    from prrn_aln_amd.synth import make_family, tree_branches, tree_weights
+    fam = make_family(**fam_kw)
+    n = len(fam.msa)
+    w = tree_weights(fam.tree, n) if weighted else None
+    br = sorted(tree_branches(fam.tree), key=lambda b: min(len(b), n - len(b)))
+    for k in picks:
+        split_case(R, fam, br[k], w, "rect_%s_b%d" % (tag, k))
+
+
+def job_rect_protein():
+    """the rectangular engine: `-A` clears algmode.bnd, PwdM picks the _ALN modes and align2 runs alignC<recd_t>(..., rectangle = true)
+    = Fwd2c::forwardA (reference src/fwd2c.h:232-356, initA :111-135; dispatch src/maln2.cc:1906-1910): every record type"""
+    import refdump
+    R = refdump.RefLib(molc=refdump.PROTEIN, band=False)
+    _rect_cases(R, "syn20x90", dict(n_seq=20, length=90, seed=41, indel=0.03, max_indel=6), [0, 5, 12, -1, -3])       # HLF / RHF / GPF
+    _rect_cases(R, "syn5x70", dict(n_seq=5, length=70, seed=42, indel=0.04), [0, 2, 4])                              # NTV
+    _rect_cases(R, "syn6x80_nogap", dict(n_seq=6, length=80, seed=43, sub=0.25, indel=0.0), [0, 3])                   # NGP
+    _rect_cases(R, "syn2x150", dict(n_seq=2, length=150, seed=44, sub=0.3, indel=0.04), [0], weighted=False)            # NGP, a pair
+    _rect_cases(R, "syn40x60", dict(n_seq=40, length=60, seed=45, indel=0.03), [-1, -2])                              # balanced: sim33
+
+
+def job_rect_ls3():
+    """... with the double-affine penalty: forwardA's Vertical2 opens at v2divv1 + gop (fwd2c.h:276, a sum where forwardB multiplies)"""
+    import refdump
+    from prrn_aln_amd.synth import DNA
+    R = refdump.RefLib(molc=refdump.PROTEIN, ls=3, band=False)
+    _rect_cases(R, "prot16x100_ls3", dict(n_seq=16, length=100, seed=46, indel=0.04, max_indel=20), [0, 6, -1])
+    _rect_cases(R, "prot4x90_ls3", dict(n_seq=4, length=90, seed=47, indel=0.05, max_indel=15), [0, 3])
+    _rect_cases(R, "prot2x200_ls3", dict(n_seq=2, length=200, seed=49, sub=0.3, indel=0.05, max_indel=30), [0], weighted=False)   # NGP + Noll 3
+    _rect_cases(R, "prot6x90_nogap_ls3", dict(n_seq=6, length=90, seed=50, sub=0.25, indel=0.0), [0, 3])
+
+
+def job_rect_dna_ls3():
+    import refdump
+    from prrn_aln_amd.synth import DNA
+    R = refdump.RefLib(molc=refdump.DNA, ls=3, band=False)
+    _rect_cases(R, "dna12x150_ls3", dict(n_seq=12, length=150, seed=48, alphabet=DNA, indel=0.03, max_indel=40), [0, 4, -1])
+
+
+JOBS = {"rect_protein": job_rect_protein, "rect_ls3": job_rect_ls3, "rect_dna_ls3": job_rect_dna_ls3, "intron": job_intron, "sim23": job_sim23, "protein": job_protein, "dna_ls3": job_dna_ls3, "protein_ls3": job_protein_ls3,
         "protein_tgapf": job_protein_tgapf, "w21_protein": job_w21_protein, "w21_dna_ls3": job_w21_dna_ls3}
 
 if __name__ == "__main__":
