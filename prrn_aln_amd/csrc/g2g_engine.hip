@@ -463,11 +463,12 @@ static V6Lds v6_layout(int rows_bytes, int ca4max, const V6Ring &R)
 }
 // A launch has ONE LDS plan, the largest of its DPs, and LDS decides how many strips a CU holds (the kernel takes a whole SIMD's
 // registers: four per CU at most).  Since the dynamic lists keep only their inline parts in LDS (g2g_kernels_v6.hip, LS6) a strip
-// of the bench sweep takes 26-30 KB where it took 31-53 and more: class A (up to 40 KB, four strips per CU) now holds every _pf
-// DP of the sweep; B (up to V6_SMALL_KB, default 53: three per CU) and C (V6_LARGE_KB, off by default) remain for families with
-// more gap states per column, and DPs above that stay on v2.
+// of the bench sweep takes 26-30 KB; class A (up to 40 KB, four strips per CU) holds all of those.  The balanced divisions whose
+// column lists need a 1024-entry ring (40-53 KB: three strips per CU) are FASTER on v2 (8 lanes per cell, 16-row strips): the
+// bench sweep 714 -> 660 ms with them there (same box; limit 46 KB 709, 49 KB 738, 36 KB 663, 30 KB 694), so the default limit
+// of v6 is class A's.  Classes B (up to V6_SMALL_KB) and C (V6_LARGE_KB) stay as options for measurements.
 static const int V6_CLASS_A = 40 * 1024;
-static int v6_small_lds(const g2g_ctx *c) { const char *e = g2g_opt(c, "V6_SMALL_KB"); return e ? atoi(e) * 1024 : 53 * 1024; }
+static int v6_small_lds(const g2g_ctx *c) { const char *e = g2g_opt(c, "V6_SMALL_KB"); return e ? atoi(e) * 1024 : 40 * 1024; }
 #define V6_SMALL_LDS (v6_small_lds(ctx))
 static int v6_large_lds(const g2g_ctx *c) { const char *e = g2g_opt(c, "V6_LARGE_KB"); return e ? atoi(e) * 1024 : 0; }
 #define V6_LARGE_LDS (v6_large_lds(ctx))

@@ -33,6 +33,7 @@ CONFIGS = {
     "no_v6": {"G2G_NO_V6": "1"},                                     # _pf on the 8-lanes-per-cell kernel instead of v6
     "v6": {"G2G_V6_MIN_STRIPS": "0"},                                # v6 for _pf whatever the batch size (by default only batches that fill the GPU)
     "v6_publish4": {"G2G_V6_MIN_STRIPS": "0", "G2G_V2_SWEEP": "4"},  # progress counters published every 4 steps
+    "v6_class_b": {"G2G_V6_MIN_STRIPS": "0", "G2G_V6_SMALL_KB": "53"},                         # the second footprint class (three strips per CU; off by default since v2 is faster there)
     "v6_class_c": {"G2G_V6_MIN_STRIPS": "0", "G2G_V6_LARGE_KB": "96"},                         # a third footprint class for v6 (off by default: slower than v2 there)
     "v2": {"G2G_FORCE_V2": "1"},
     "v2_t128": {"G2G_FORCE_V2": "1", "G2G_V2_THREADS": "128"},
