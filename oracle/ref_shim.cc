@@ -18,6 +18,7 @@
 #include <time.h>
 // compiled with -fno-access-control: the dump reads PwdM's private scalars and fn-pointers
 #include "aln.h"
+#include "vmf.h"
 #include "mseq.h"
 #include "maln.h"
 #include "gfreq.h"
@@ -209,6 +210,9 @@ void ref_set_tgapf(double f) {alprm.tgapf = (float) f;}
 // gap extension / opening penalties as -u / -v set them (alprm is read by Fwd2d / PwdB at construction)
 void ref_set_uv(double u, double v) {alprm.u = (float) u; alprm.v = (float) v;}
 void ref_set_band(int bnd) {algmode.bnd = bnd? 1: 0;}
+// MaxVmfSpace (vmf.cc:25-30; aln's own option sets it the same way, aln.cc:131): DPs of this many cells or more go through
+// the linear-space recursion lspB_ng (fwd2b1.cc:1053-1095)
+void ref_set_vmfspace(long spc) {setVmfSpace(spc);}
 void ref_set_quick(int q) {algmode.qck = q;}
 // per-cell trace of forwardB to stdout: "m n dir H diag G F1 [G2 F2]" (fwd2c.h:454-464)
 void ref_set_debug(int on) {OutPrm.debug = on? 1: 0; fflush(stdout);}

@@ -38,19 +38,23 @@ def oracle_scores(d, seqs):
     return out
 
 
-def oracle_alignb(d, seqs, k1=7, u1=0.6):
-    """g2g_oracle_alignb_ng for every pair of a fixture: [(score, skeleton (n, 2) int32, pwd constants)]"""
+def oracle_alignb(d, seqs, k1=7, u1=0.6, maxvmf=0, pairs=None):
+    """g2g_oracle_alignb_ng_lsp for every pair of a fixture: [(score, skeleton (n, 2) int32, pwd constants, centerB_ng calls)];
+    maxvmf 0 = the reference's default MaxVmfSpace (16 Mi cells)"""
     L = oraclelib.load()
-    L.g2g_oracle_alignb_ng.argtypes = [C.POINTER(_abi.Params), C.POINTER(_abi.DSeq), C.POINTER(_abi.DSeq), C.POINTER(C.c_double),
-                                       C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.g2g_oracle_alignb_ng_lsp.argtypes = [C.POINTER(_abi.Params), C.POINTER(_abi.DSeq), C.POINTER(_abi.DSeq), C.c_long, C.POINTER(C.c_double),
+                                           C.POINTER(C.POINTER(_abi.Skl)), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     p = params(d)
     p.k1, p.u1, p.molc = k1, u1, int(d["molc"][0])
     ds = [_abi.dseq(s) for s in seqs]
     out = []
-    for i, j in zip(d["ia"], d["ib"]):
-        v = C.c_double(); sk = C.POINTER(_abi.Skl)(); n = C.c_int(); pw = (C.c_double * 6)()
-        rc = L.g2g_oracle_alignb_ng(C.byref(p), C.byref(ds[i]), C.byref(ds[j]), C.byref(v), C.byref(sk), C.byref(n), pw)
+    for k, (i, j) in enumerate(zip(d["ia"], d["ib"])):
+        if pairs is not None and k not in pairs:
+            out.append(None)
+            continue
+        v = C.c_double(); sk = C.POINTER(_abi.Skl)(); n = C.c_int(); pw = (C.c_double * 6)(); nc = C.c_int()
+        rc = L.g2g_oracle_alignb_ng_lsp(C.byref(p), C.byref(ds[i]), C.byref(ds[j]), int(maxvmf), C.byref(v), C.byref(sk), C.byref(n), pw, C.byref(nc))
         assert rc == 0, rc
-        out.append((v.value, oraclelib.skl_to_np(sk, n.value), list(pw)))
+        out.append((v.value, oraclelib.skl_to_np(sk, n.value), list(pw), nc.value))
         L.g2g_oracle_free(sk)
     return out

@@ -49,7 +49,31 @@ def test_oracle_alignb_ng_matches_reference(path):
     seqs = distlib.split(d)
     res = distlib.oracle_alignb(d, seqs)
     off = np.concatenate([[0], np.cumsum(d["alignb_nskl"])])
-    for k, (scr, skl, pw) in enumerate(res):
+    for k, (scr, skl, pw, nc) in enumerate(res):
         assert scr == d["alignb_scr"][k], (k, scr, d["alignb_scr"][k])
         assert np.array_equal(skl, d["alignb_skl"][off[k]:off[k + 1]]), k
-        assert pw == list(d["pwdb"])
+        assert pw == list(d["pwdb"]) and nc == 0
+
+
+LSP = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "lsp", "*.npz")))
+
+
+def test_lsp_goldens_present():
+    assert len(LSP) >= 8
+
+
+@pytest.mark.parametrize("path", LSP, ids=[os.path.basename(p)[:-4] for p in LSP])
+def test_oracle_lspb_ng_matches_reference(path):
+    """The linear-space recursion (lspB_ng -> centerB_ng with binitB_ng / finitB_ng, the narrowed windows, diagonalB_ng, the traced
+    leaves; fwd2b1.cc:382-782, 990-1095) against the reference's alignB_ng run with the same MaxVmfSpace: score and skeleton of every
+    pair, and the recursion really ran (centerB_ng calls counted)."""
+    d = dict(np.load(path))
+    seqs = distlib.split(d)
+    res = distlib.oracle_alignb(d, seqs, maxvmf=int(d["maxvmf"][0]))
+    off = np.concatenate([[0], np.cumsum(d["alignb_nskl"])])
+    centers = 0
+    for k, (scr, skl, pw, nc) in enumerate(res):
+        assert scr == d["alignb_scr"][k], (k, scr, d["alignb_scr"][k])
+        assert np.array_equal(skl, d["alignb_skl"][off[k]:off[k + 1]]), k
+        centers += nc
+    assert centers >= len(res), centers

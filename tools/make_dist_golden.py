@@ -22,13 +22,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 GOLD = os.path.join(ROOT, "tests", "golden", "dist")
 
 
-def run(name, molc, ls, sh, tgapf, seqs, uv=None):
+def run(name, molc, ls, sh, tgapf, seqs, uv=None, maxvmf=None, sub="dist", pairs=None):
     import refdump
     R = refdump.RefLib(molc=molc, ls=ls, sh=sh, tgapf=tgapf)
     L = R.lib
     if uv is not None:                   # non-dyadic penalties: partial sums of the boundary ramps round (Fwd2d ctor, fwd2d1.cc:58-98)
         L.ref_set_uv.argtypes = [C.c_double, C.c_double]
         L.ref_set_uv(*uv)
+    if maxvmf is not None:               # the linear-space recursion on DPs of this many cells or more (default 16 Mi)
+        L.ref_set_vmfspace.argtypes = [C.c_long]
+        L.ref_set_vmfspace(maxvmf)
     L.ref_seq_read.restype = C.c_void_p
     L.ref_seq_read.argtypes = [C.c_char_p]
     L.ref_seq_len.argtypes = [C.c_void_p]
@@ -66,6 +69,8 @@ def run(name, molc, ls, sh, tgapf, seqs, uv=None):
     out = (C.c_int * (2 * cap))()
     for i in range(N):
         for j in range(i + 1, N):
+            if pairs is not None and (i, j) not in pairs:
+                continue
             ia.append(i); ib.append(j)
             scd.append(L.ref_alnscored(hs[i], hs[j]))
             dist.append(L.ref_alnscore2dist(hs[i], hs[j], float(np.sqrt(selfs[i] * selfs[j]))))
@@ -74,8 +79,9 @@ def run(name, molc, ls, sh, tgapf, seqs, uv=None):
             assert n > 0, n
             bscr.append(s.value); bnskl.append(n)
             bskl.append(np.array(out[:2 * n], np.int32).reshape(n, 2))
-    os.makedirs(GOLD, exist_ok=True)
-    np.savez_compressed(os.path.join(GOLD, name + ".npz"),
+    gold = os.path.join(os.path.dirname(GOLD), sub)
+    os.makedirs(gold, exist_ok=True)
+    np.savez_compressed(os.path.join(gold, name + ".npz"), maxvmf=np.array([maxvmf if maxvmf is not None else 16 * 1024 * 1024], np.int64),
                         molc=np.array([molc]), ls=np.array([ls]), lens=np.array(lens, np.int32), codes=np.concatenate(codes),
                         u=np.array([uvst[0]]), v=np.array([uvst[1]]), scale=np.array([uvst[2]]), tgapf=np.array([uvst[3]]),
                         sh=np.array([shv.value]), simmtx=np.array(mtx[:rows.value * dim.value]).reshape(rows.value, dim.value),
@@ -112,6 +118,17 @@ JOBS = {
     "prot_uv_tgapf": lambda: run("prot8_u21_v93_tgapf03", 1, 0, 0, 0.3, [s[: 45 + 16 * k] for k, s in enumerate(synth(8, 180, 21, indel=0.05))], uv=(2.1, 9.3)),
     "prot_ls3": lambda: run("prot8_ls3", 1, 3, 0, None, synth(8, 200, 15, indel=0.05, max_indel=40)),
     "dna": lambda: run("dna10_sh60", 2, 0, 0, None, synth(10, 240, 16, alphabet="dna", indel=0.03)),
+    # ---- tests/golden/lsp: alignB_ng through the linear-space recursion (lspB_ng / centerB_ng, fwd2b1.cc:382-782, 1053-1095) ----
+    # MaxVmfSpace lowered so that small DPs recurse several levels deep (the reference's own switch, vmf.cc:27) ...
+    "lsp_prot": lambda: run("lsp_prot8_vmf4k", 1, 0, 0, None, synth(8, 220, 31, indel=0.05, max_indel=20), maxvmf=4096, sub="lsp"),
+    "lsp_prot_unbanded": lambda: run("lsp_prot6_sh100_vmf2k", 1, 0, -100, None, [s[: 90 + 31 * k] for k, s in enumerate(synth(6, 260, 32, indel=0.06, max_indel=30))], maxvmf=2048, sub="lsp"),
+    "lsp_prot_ls3": lambda: run("lsp_prot8_ls3_vmf4k", 1, 3, 0, None, synth(8, 240, 33, indel=0.06, max_indel=50), maxvmf=4096, sub="lsp"),
+    "lsp_dna_ls3": lambda: run("lsp_dna8_ls3_vmf8k", 2, 3, 0, None, synth(8, 400, 34, alphabet="dna", indel=0.04, max_indel=30), maxvmf=8192, sub="lsp"),
+    "lsp_dna_tgapf": lambda: run("lsp_dna6_tgapf05_vmf2k", 2, 0, 0, 0.5, [s[: 120 + 40 * k] for k, s in enumerate(synth(6, 360, 35, alphabet="dna", indel=0.04))], maxvmf=2048, sub="lsp"),
+    "lsp_prot_uv": lambda: run("lsp_prot6_u21_v93_vmf1k", 1, 3, 0, 0.3, synth(6, 200, 36, indel=0.08, max_indel=40), uv=(2.1, 9.3), maxvmf=1024, sub="lsp"),
+    # ... and the default 16 Mi on sequences long enough to cross it (configs[4]'s regime: 4096-nt DNA with -yl3; one protein pair)
+    "lsp_dna_full": lambda: run("lsp_dna3_4400_ls3", 2, 3, 0, None, synth(3, 4400, 37, alphabet="dna", indel=0.01, max_indel=20), sub="lsp"),
+    "lsp_prot_full": lambda: run("lsp_prot2_6200", 1, 0, 0, None, synth(2, 6200, 38, indel=0.01, max_indel=30), sub="lsp"),
     "pas": lambda: run("pas_native", 1, 0, 0, None, fasta_members("/root/reference/sample/pas/native_A") + fasta_members("/root/reference/sample/pas/native_B")),
 }
 
