@@ -397,12 +397,17 @@ typedef struct g2g_dseq {
 } g2g_dseq;
 int        g2g_alnscored_batch(g2g_ctx *ctx, const g2g_params *prm, int nseq, const g2g_dseq *seqs,
                                int npairs, const int32_t *ia, const int32_t *ib, double *score, int32_t *status);
-/* <-> SKL* alignB_ng(const Seq* seqs[], const PwdB* pwd, VTYPE* scr) (reference src/fwd2b1.cc:1347-1353) for the DPs the
- * reference traces in one piece (fewer than MaxVmfSpace = 16 M cells, lspB_ng :1062-1069 -> trcbkalignB_ng :1025-1051):
- * Aln2b1::forwardB_ng (:145-279; affine gaps, with prm->ls = 3 the second, long-gap pair of layers) + initB_ng / lastB_ng
- * (:64-143) + the Vmf record chain + stdskl.  PwdB's constants (BasicGOP ... codonk1, src/aln2.cc:80-120) are formed from
- * prm's u, v, u1, k1, ls, scale, molc as the reference does.  skl[i]: malloc'ed corners ascending (g2g_free), nskl[i] of them.
- * Larger DPs (the linear-space recursion) and one-diagonal bands get status G2G_ERR_MODE; local modes are not on this path. */
+/* <-> SKL* alignB_ng(const Seq* seqs[], const PwdB* pwd, VTYPE* scr) (reference src/fwd2b1.cc:1347-1353 -> globalB_ng :1286-1315
+ * -> lspB_ng :1053-1095).  DPs of fewer than MaxVmfSpace cells (16 Mi; context option MAX_VMF_SPACE <-> setVmfSpace, vmf.cc:27) are
+ * traced in one piece (trcbkalignB_ng :1025-1051): Aln2b1::forwardB_ng (:145-279; affine gaps, with prm->ls = 3 the second,
+ * long-gap pair of layers) + initB_ng / lastB_ng (:64-143) + the Vmf record chain.  Larger ones go through the reference's
+ * linear-space recursion: centerB_ng (:492-782, with binitB_ng / finitB_ng :382-490) splits the DP at the middle row into two
+ * parts with narrowed windows, the parts recurse (a part of one diagonal: diagonalB_ng's two records, :1015-1021), the value is
+ * the top centre's.  Then stdskl.  PwdB's constants (BasicGOP ... codonk1, src/aln2.cc:80-120) are formed from prm's u, v, u1, k1,
+ * ls, scale, molc as the reference does.  skl[i]: malloc'ed corners ascending (g2g_free), nskl[i] of them.
+ * Status G2G_ERR_MODE: a band of one diagonal at the top level; sides of 46341 and more (the reference's int volume overflows);
+ * a pair on which centerB_ng hands back a part that is no DP (seen with ls = 3: the reference itself reads outside its arrays and
+ * crashes there).  Local modes are not on this path. */
 int        g2g_alignb_ng_batch(g2g_ctx *ctx, const g2g_params *prm, int nseq, const g2g_dseq *seqs, int npairs,
                                const int32_t *ia, const int32_t *ib, double *scr, g2g_skl **skl, int *nskl, int32_t *status);
 

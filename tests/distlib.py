@@ -54,6 +54,9 @@ def oracle_alignb(d, seqs, k1=7, u1=0.6, maxvmf=0, pairs=None):
             continue
         v = C.c_double(); sk = C.POINTER(_abi.Skl)(); n = C.c_int(); pw = (C.c_double * 6)(); nc = C.c_int()
         rc = L.g2g_oracle_alignb_ng_lsp(C.byref(p), C.byref(ds[i]), C.byref(ds[j]), int(maxvmf), C.byref(v), C.byref(sk), C.byref(n), pw, C.byref(nc))
+        if rc == -2 and maxvmf:                               # G2G_ERR_MODE: centerB_ng left a part that is no DP (the reference crashes there)
+            out.append((None, None, list(pw), nc.value))
+            continue
         assert rc == 0, rc
         out.append((v.value, oraclelib.skl_to_np(sk, n.value), list(pw), nc.value))
         L.g2g_oracle_free(sk)
