@@ -404,6 +404,7 @@ struct g2g_batch {
     std::vector<const g2g_problem *> src;        // the caller's problems (kept alive by the caller until the batch is freed): a DP
                                                  // that lost a wait is re-run from here on the non-polling kernel
     int fail_off;                                // offset of the per-DP fail flags in d_flags
+    int dump_off;                                // offset of the time-out dump area in d_flags (0: none)
     int n_recovered;                             // DPs re-run after a time-out, over the life of the batch
     int last_timeouts, last_recovered;           // the same for the last g2g_batch_run: waits that gave up, DPs re-run
     std::vector<g2g_result> recovered;           // results of re-run DPs (trace owned by the batch until fetched)
@@ -719,7 +720,7 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
     b->ctx = ctx; b->n = n; b->d_arena = 0; b->d_probs = 0; b->fwd_ms = b->tb_ms = 0;
     for (int k = 0; k < 24; ++k) { b->simscr[k] = 0; b->simscr_cap[k] = 0; }
     for (int k = 0; k < 6; ++k) { b->twin[k] = 0; b->twin_cap[k] = 0; }
-    b->src.assign(prob, prob + n); b->fail_off = 0; b->force_v1 = force_v1; b->is_retry = false; b->n_recovered = 0;
+    b->src.assign(prob, prob + n); b->fail_off = 0; b->dump_off = 0; b->force_v1 = force_v1; b->is_retry = false; b->n_recovered = 0;
     b->recovered.assign(n, g2g_result()); b->was_recovered.assign(n, 0);
     b->nsimmat = 0; b->injected = g2g_opt(ctx, "INJECT_STALL") != 0;
     for (int k = 0; k < 24; ++k) b->var_cells[k] = 0;
@@ -1081,6 +1082,8 @@ static int batch_prepare_impl(g2g_ctx *ctx, int n, const g2g_problem *const *pro
         }
         b->fail_off = (int) flags.size();                 // per-DP fail flags behind the tile flags
         flags.resize(flags.size() + (size_t) (n > 0 ? n : 1), 0);
+        b->dump_off = (int) flags.size();                 // the first time-out's view of its whole DP (g2g_wait_ge: G2G_DUMP_STRIPS strips x 7 words)
+        flags.resize(flags.size() + 2 + G2G_DUMP_WORDS * G2G_DUMP_STRIPS, 0);
         b->ntiles = (long long) all.size();
         b->nflags = (int) flags.size();
         b->flags0 = flags;
@@ -1223,6 +1226,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             double limit_ms = 500.;
             if (const char *e = g2g_opt(ctx, "WAIT_LIMIT_MS")) { const double v = atof(e); if (v > 0) limit_ms = v; }
             hdr[G2G_HDR + 2] = b->fail_off;
+            hdr[G2G_HDR + 82] = b->dump_off;
             hdr[G2G_HDR + 3] = (int) std::min(2.0e9, limit_ms * ctx->rt_ticks_per_ms / 65536.) + 1;
             HIPCHK(hipMemcpyAsync(b->d_flags, hdr, sizeof b->hdr_img, hipMemcpyHostToDevice, ctx->stream));
             HIPCHK(hipMemsetAsync(b->d_flags + b->fail_off, 0, sizeof(int) * (size_t) (b->n > 0 ? b->n : 1), ctx->stream));
@@ -1537,7 +1541,7 @@ extern "C" int g2g_batch_run(g2g_batch *b)
             if (b->injected) { g_tot[5] += rep[G2G_HDR]; g_tot[6] += (long long) lost.size(); }
             {   // the report of the event: kept in the context (g2g_ctx_last_timeout: every ordinary run that meets one carries the
                 // evidence), printed under WARN / DEBUG
-                char buf[4096];
+                char buf[6144];
                 int o = 0;
                 auto add = [&](const char *fmt, ...) { va_list ap; va_start(ap, fmt); if (o < (int) sizeof buf - 1) { const int w = vsnprintf(buf + o, sizeof buf - o, fmt, ap); if (w > 0) o += w; } va_end(ap); if (o > (int) sizeof buf - 1) o = (int) sizeof buf - 1; };
                 int kinds[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1568,6 +1572,41 @@ extern "C" int g2g_batch_run(g2g_batch *b)
                 }
                 add("; the blocker (lowest strip of this DP without a publish in this generation, %d below the polled one): word %d:%d, HW_ID %08x XCC %08x, taken-by marker %08x (gen %d, workgroup %d), past the left chain %08x, past its first look at the strip above %08x, first wave's last publish %d (markers carry the generation; 7fffffff: never written)",
                     x[64], (x[65] >> 20) & 0x7FF, x[65] & 0xFFFFF, x[66], x[67], x[68], (x[68] >> 20) & 0x7FF, x[68] & 0xFFFF, x[69], x[70], x[71]);
+                if (b->dump_off > 0) {
+                    // the whole pipeline of the first time-out's DP as that waiter saw it: strips ti-1, ti-2, ... (word, HW_ID, markers, the
+                    // two waves' last publish).  A strip is TIGHT when its predecessor is less than 48 columns ahead (it can only be waiting
+                    // for it); the HEADS are the unfinished strips that are not tight: they wait for nobody's progress.
+                    std::vector<int> dump(2 + G2G_DUMP_WORDS * G2G_DUMP_STRIPS);
+                    if (hipMemcpy(dump.data(), b->d_flags + b->dump_off, sizeof(int) * dump.size(), hipMemcpyDeviceToHost) == hipSuccess && dump[0] > 0) {
+                        const int nd = std::min(dump[0], (int) G2G_DUMP_STRIPS), ti = dump[1];
+                        const int g1 = x[4] & ~0xFFFFF;
+                        auto colof = [&](int w) { return w < (g1 | 0) ? -1 : (w & 0xFFFFF); };      // -1: nothing in this generation
+                        int heads = 0, unfinished = 0, untaken = 0;
+                        add("; pipeline of that DP (%d strips above the waiter dumped): heads", nd);
+                        for (int k = 0; k < nd; ++k) {
+                            const int *d = dump.data() + 2 + G2G_DUMP_WORDS * k;
+                            const int c = colof(d[0]);
+                            if (c == 0xFFFFF) continue;
+                            ++unfinished;
+                            const bool taken = (d[2] & ~0xFFFFF) == (g1 | 0) || ((d[2] >> 20) & 0x7FF) == ((g1 >> 20) & 0x7FF);
+                            if (!taken) ++untaken;
+                            const int cp = k + 1 < nd ? colof(dump[2 + G2G_DUMP_WORDS * (k + 1)]) : 0xFFFFF;      // predecessor (the top chain counts as finished)
+                            if (cp == 0xFFFFF || cp - c >= 48) {
+                                if (heads < 6) add(" [strip %d: col %d, predecessor %s%d, HW_ID %08x, taken %08x, past left chain %08x, past first look %08x, waves' last publish %d %d, waves' step:place %d:%d %d:%d]",
+                                                   ti - 1 - k, c, cp == 0xFFFFF ? "finished " : "col ", cp == 0xFFFFF ? 0 : cp, d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10]);
+                                ++heads;
+                            }
+                        }
+                        add(" -- %d head(s), %d unfinished strip(s), %d of them not taken from the queue in this generation", heads, unfinished, untaken);
+                        if (const char *fn = g2g_opt(ctx, "STALL_DUMP_FILE")) {
+                            if (FILE *fd = fopen(fn, "a")) {
+                                fprintf(fd, "# gen %d, waiter strip %d, %d strips: strip word(gen:col) HW_ID taken pastleft pastfirst pub0 pub1 w0step w0place w1step w1place\n", b->gen, ti, nd);
+                                for (int k = 0; k < nd; ++k) { const int *d = dump.data() + 2 + G2G_DUMP_WORDS * k; fprintf(fd, "%d %d:%d %08x %08x %08x %08x %d %d %d %d %d %d\n", ti - 1 - k, (d[0] >> 20) & 0x7FF, d[0] & 0xFFFFF, d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10]); }
+                                fclose(fd);
+                            }
+                        }
+                    }
+                }
                 add("; chain words of this DP as the first waiter saw them (valid when the polled word is a strip's): left %d:%d, top %d:%d", (x[80] >> 20) & 0x7FF, x[80] & 0xFFFFF, (x[81] >> 20) & 0x7FF, x[81] & 0xFFFFF);
                 if (x[72]) add("; of the waves released when their DP was given up, the one with the lowest strip index (%d) was waiting on word %d for %d:%d and had last seen %d:%d (read-modify-write on release: %d:%d) after %d polls, %.0f ms of its own running time",
                                0x7fffffff - x[72], x[75], (x[73] >> 20) & 0x7FF, x[73] & 0xFFFFF, (x[74] >> 20) & 0x7FF, x[74] & 0xFFFFF, (x[78] >> 20) & 0x7FF, x[78] & 0xFFFFF, x[76], x[77] * 65536. / ctx->rt_ticks_per_ms);

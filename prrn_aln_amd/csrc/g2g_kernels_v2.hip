@@ -59,6 +59,8 @@ static __device__ unsigned long long g2g_stamp_acc[16];      // (one copy per tr
 #define G2G_POLL(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define G2G_POST(p, v) __hip_atomic_store((int *) (p), (int) (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
+#define G2G_DUMP_STRIPS 580           // strips of one DP the first time-out dumps for the host ...
+#define G2G_DUMP_WORDS 11             // ... words each: progress word, HW_ID, three markers, two publish columns, (step, place) of two waves
 #define G2G_GAP_TICKS 400000ull       // 4 ms of s_memrealtime: more than ten times what 64 polls take
 #define G2G_HDRN 104                  // header words: 4 + the snapshot (want, seen, offset of the polled word, the words at and below it; [48, 64): per-wave heartbeats); G2G_HDR + G2G_HDRN is a multiple of G2G_FSTRIDE, so every progress line IS one 128-byte line
 __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hdr, int *failp, const int slot)
@@ -148,6 +150,28 @@ __device__ __forceinline__ int g2g_wait_ge(const int *p, const int want, int *hd
                     if (off - (slot + 1) * G2G_FSTRIDE >= G2G_HDR + G2G_HDRN) {
                         hdr[80] = __hip_atomic_load(p - slot * G2G_FSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // left chain
                         hdr[81] = __hip_atomic_load(p - (slot + 1) * G2G_FSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // top chain
+                    }
+                    {   // the whole pipeline above this waiter (the strips' lines are contiguous, the one above p at p - G2G_FSTRIDE): word,
+                        // HW_ID, the three markers, the two waves' last publish -- the host finds the strips that wait for nobody in it
+                        const int doff = __hip_atomic_load(hdr + 82, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (doff > 0) {
+                            int *dump = (hdr - G2G_HDR) + doff;
+                            int nd = 0;
+                            for (int k = 0; k < G2G_DUMP_STRIPS && k < slot && off - k * G2G_FSTRIDE >= G2G_HDR + G2G_HDRN; ++k) {
+                                const int *q = p - k * G2G_FSTRIDE;
+                                int *d = dump + 2 + G2G_DUMP_WORDS * k;
+                                d[0] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                d[1] = __hip_atomic_load(q + G2G_DIAG + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                d[2] = __hip_atomic_load(q + G2G_DIAG + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                d[3] = __hip_atomic_load(q + G2G_DIAG + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                d[4] = __hip_atomic_load(q + G2G_DIAG + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                d[5] = __hip_atomic_load(q + G2G_DIAG + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                d[6] = __hip_atomic_load(q + G2G_DIAG + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                for (int w = 0; w < 4; ++w) d[7 + w] = __hip_atomic_load(q + G2G_DIAG + 12 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (-DG2G_HEARTBEAT: step / place of the strip's two waves)
+                                nd = k + 1;
+                            }
+                            dump[0] = nd; dump[1] = slot;
+                        }
                     }
                     hdr[8 + 38] = atomicAdd((int *) p, 0);          // the same word through a read-modify-write (executes at the coherent point)
                     hdr[8 + 39] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -981,6 +1005,8 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (prog_self) __hip_atomic_store(prog_self + G2G_DIAG + 6, ((pgen & 0x7FF) << 20) | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ... past the left chain
+    G2G_HB_STEP(prog_self, tid >> 6, -1)
+    G2G_HB(prog_self, tid >> 6, 10)                         // places 10-18: the strip's prologue
     const int c0 = b.left + tj * C;
     int c1 = c0 + C; if (c1 > b.right) c1 = b.right;
     const bool row_ok = m < a.right;
@@ -993,6 +1019,7 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
     if (lane < G.nslot) lrec_black<KIND>(G.row(team, lane), G.capa);
     if (lane == 0 && G.nslot > TEAM) lrec_black<KIND>(G.row(team, 8), G.capa);
     team_sync();
+    G2G_HB(prog_self, tid >> 6, 11)
     // rows that continue from the block on the left: their corner at the block edge and their F
     if (row_ok && c0 - 1 >= nlo && c0 - 1 < nhi) {
         rec_g2l(G.row(team, SLOT_H(c0)), cbH + (size_t) (m - a.left) * G.ndw, G.ndw, lane);
@@ -1001,6 +1028,7 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
             if (NOLL3) rec_g2l(G.row(team, SLOT_F2), cbF2 + (size_t) (m - a.left) * G.ndw, G.ndw, lane);
         }
     }
+    G2G_HB(prog_self, tid >> 6, 12)
     // this row's static lists -> LDS (they serve every cell of the row)
     CellLists<LList16> L;
     {
@@ -1012,6 +1040,7 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         L.ar.glen = ag + 2 * mla; L.ar.freq = af + 2 * mla;
         L.bs = L.bt = L.br = L.as;
     }
+    G2G_HB(prog_self, tid >> 6, 13)
     // the view (s/t/r) of b this thread prefetches: chosen once with selects (a runtime index into the descriptor copy
     // would force the copy into scratch memory)
     // (the loader lanes sit in the LAST wave: the first wave already carries the staging of the strip above)
@@ -1025,16 +1054,19 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         const int o = pf_off[cbase + 1], e = pf_off[cbase + 2];
         for (int k = lane; k < e - o; k += TEAM) { bglen[(size_t) v * mlb + k] = (short) pf_glen[o + k]; bfreq[(size_t) v * mlb + k] = pf_freq[o + k]; }
     }
+    G2G_HB(prog_self, tid >> 6, 14)
     // per-row constants and one-step-ahead register pipelines (column score, b's column thickness,
     // and -- for the strip's first row -- the upper neighbours' records): nothing that comes from HBM is
     // waited for inside the step that uses it
     const double a_efq = row_ok ? thk_at(a, m)[2] : 0;
     int nf0 = m + P.lw; if (nf0 < b.left) nf0 = b.left;
     const double pua_row = row_ok ? unpa(P, m, nf0) : 0;                 // fwd2c.h:380 (402 when a.inex.nils)
+    G2G_HB(prog_self, tid >> 6, 15)
     const bool own_sim = prog_self != 0 && simscr != 0;    // sweep mode: the strip makes its column scores block by block (SimBlk)
     const double *simrow = (row_ok && !own_sim) ? P.v2_sim + P.v2_rowoff[m - a.left] - nlo : 0;
     SimBlk SB; SB.buf = (GLBV3 double *) simscr; SB.cbase = cbase;
-    if (own_sim) { simblk_fill(P, SB, 0, m0, tid, blockDim.x, R); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if (own_sim) { simblk_fill(P, SB, 0, m0, tid, blockDim.x, R); G2G_HB(prog_self, tid >> 6, 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    G2G_HB(prog_self, tid >> 6, 17)
     double sim_cur = 0, bc_cur = 0;
     bool have = false;
     int rslot = (RC - team % RC) % RC;                     // ring slot of column cbase + s - team
@@ -1066,6 +1098,7 @@ __device__ __forceinline__ void v2_tile(const DevProb &Pmem, lchar *lds, int ti,
         G2G_POST(prog_self, penc | (col < 0 ? 0 : col < 0xFFFFF ? col : 0xFFFFF));
     };
     need(cbase + 2);
+    G2G_HB(prog_self, tid >> 6, 18)
     if (prog_self) __hip_atomic_store(prog_self + G2G_DIAG + 7, ((pgen & 0x7FF) << 20) | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ... past the first look at the strip above
     if (prog_self && tid < 64) {                           // (the whole first wave, same value: no one-lane branch) where this strip runs: for the time-out report of whoever waits for it (g2g_wait_ge)
         __hip_atomic_store(prog_self + G2G_DIAG + 3, (int) __builtin_amdgcn_s_getreg((31 << 11) | 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

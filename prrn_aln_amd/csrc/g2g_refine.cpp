@@ -387,6 +387,14 @@ extern "C" int g2g_refine(g2g_ctx *ctx, const g2g_params *prm, int many, int len
                 const double t1 = now();
                 rc = g2g_align2_score_batch(ctx, nm, pw.data(), cur.data(), ncur.data(), G2G_SP_NOSTATS, scr.data(), skl.data(), nskl.data(), st.data(), fc.data(), fn.data());
                 t_align += now() - t1;
+                if (const char *e = getenv("G2G_REFINE_SLOW_MS")) {        // diagnostics: windows whose scoring took unusually long (the scheduler's stalls)
+                    const double dt = now() - t1;
+                    if (dt > atof(e)) {
+                        long long c[4] = {0, 0, 0, 0};
+                        g2g_ctx_counters(ctx, c);
+                        fprintf(stderr, "[g2g_refine] slow window %d: %d DPs scored in %.1f ms (wait time-outs so far %lld, recovered DPs %lld)\n", S.batches, nm, dt, c[1], c[2]);
+                    }
+                }
                 for (int i = 0; i < nm && rc == G2G_OK; ++i) {
                     Division &d = D[live[mine[i]]];
                     if (st[i] != 0 || fc[i].status != 0 || fn[i].status != 0) {
