@@ -68,6 +68,7 @@ struct g2g_ctx {
     // batch per window -- allocates nothing once the pool holds its sizes.  Contents are as undefined as a fresh allocation's.
     struct DevBlock { char *p; size_t cap; };
     std::vector<DevBlock> pool;     // free blocks
+    hipStream_t sp_stream; hipEvent_t sp_ev; void *sp_slots2; size_t sp_slots2_cap;    // the walks that run beside the DPs (g2g_batch_spscore_begin)
     long long n_dev_malloc, n_dev_free, n_pool_hits;   // hipMalloc / hipFree calls made for the pool, requests served from it
     int ncu;                        // compute units of the device
     std::shared_ptr<int> alive;     // 1 while the context exists: device slabs that outlive it (twins held by g2g_group objects) free themselves
@@ -144,7 +145,7 @@ extern "C" g2g_ctx *g2g_create(int device)
     c->alive = std::make_shared<int>(1);
     c->n_runs = c->n_timeouts = c->n_recovered = c->n_v1 = 0;
     c->n_gaps = 0; c->max_gap_ms = 0; c->n_mstreams = 0;
-    c->sp_slots = 0; c->sp_slots_cap = 0;
+    c->sp_slots = 0; c->sp_slots_cap = 0; c->sp_stream = 0; c->sp_ev = 0; c->sp_slots2 = 0; c->sp_slots2_cap = 0;
     c->mstamp = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; g2g_set_error("%s", "stream"); return NULL; }
     for (int i = 0; i < 4; ++i) hipEventCreate(&c->ev[i]);
@@ -212,15 +213,18 @@ extern "C" void g2g_destroy(g2g_ctx *c)
     for (auto &bk : c->pool) hipFree(bk.p);
     c->pool.clear();
     if (c->sp_slots) hipFree(c->sp_slots);
+    if (c->sp_slots2) hipFree(c->sp_slots2);
     lap("device pool");
     if (c->stage) hipHostFree(c->stage);
     lap("pinned staging");
     for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
     for (int i = 0; i < G2G_NVS + 1; ++i) hipEventDestroy(c->vev[i]);
+    if (c->sp_ev) hipEventDestroy(c->sp_ev);
     lap("events");
     for (auto &m : c->mstream) hipStreamDestroy(m.s);
     lap("CU-share streams");
     for (int i = 0; i < G2G_NVS; ++i) hipStreamDestroy(c->vstream[i]);
+    if (c->sp_stream) hipStreamDestroy(c->sp_stream);
     lap("launch streams");
     hipStreamDestroy(c->stream);
     lap("main stream");
@@ -1747,39 +1751,38 @@ extern "C" void g2g_waits(unsigned long long *out) { hipMemcpyFromSymbol(out, HI
 // f1: PreSpScore::calcSpScore on the problems of a prepared batch (their inputs are resident in HBM)
 // nsets skeletons per problem of the batch in ONE launch (entry e = set e / b->n of problem e % b->n): the windows of g2g_refine
 // score the current and the new alignment of every division on the batch the DPs ran on, without packing the problems again
-extern "C" int g2g_batch_spscore_sets(g2g_batch *b, int nsets, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl, g2g_fstat *out)
+// One set of calcSpScore walks in flight: launched on a stream (spscore_launch: uploads, g2g_spprep_kernel, g2g_spscore_kernel, the
+// copies back), collected later (spscore_finish).  The host images the asynchronous copies read live in the object.
+struct SpRun {
+    int n, nb; char *d; size_t d_cap, o_out, o_st, b_out, b_int; hipStream_t s;
+    std::vector<g2g_skl> all; std::vector<int> off, cnt, colpre; std::vector<long long> goff, soff; std::vector<g2g_spparams> sp;
+    std::vector<double> ho; std::vector<int> hs;
+    hipError_t e;
+    SpRun() : n(0), nb(0), d(0), d_cap(0), o_out(0), o_st(0), b_out(0), b_int(0), s(0), e(hipSuccess) {}
+};
+static int spscore_launch(g2g_batch *b, int nsets, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl, hipStream_t stream,
+                          void **slots, size_t *slots_cap, SpRun &R)
 {
-    if (!b || nsets < 1 || !sp || !skl || !nskl || !out) return G2G_ERR_ARG;
     g2g_ctx *ctx = b->ctx;
-    HIPCHK(hipSetDevice(ctx->device));
     const int nb = b->n;
-    if (nb == 0) return G2G_OK;
-    if (nsets > 1) {
-        // two walks of one problem must not share list storage: the walkers keep their running lists in LDS unless the problem's
-        // capacities exceed SP_FAST_LIST entries -- then they use the problem's own state arrays, and the sets go one by one
-        bool one_by_one = false;
-        for (int i = 0; i < nb; ++i) if (b->dp[i].capa + 1 > SP_FAST_LIST || b->dp[i].capb + 1 > SP_FAST_LIST) one_by_one = true;
-        if (one_by_one) {
-            for (int k = 0; k < nsets; ++k) {
-                const int rc = g2g_batch_spscore_sets(b, 1, sp + (size_t) k * nb, skl + (size_t) k * nb, nskl + (size_t) k * nb, out + (size_t) k * nb);
-                if (rc) return rc;
-            }
-            return G2G_OK;
-        }
-    }
     const int n = nsets * nb;
-    std::vector<int> off(n), cnt(n);
+    R.n = n; R.nb = nb;
+    std::vector<int> &off = R.off, &cnt = R.cnt;
+    off.assign(n, 0); cnt.assign(n, 0);
     size_t tot = 0;
     for (int i = 0; i < n; ++i) { off[i] = (int) tot; cnt[i] = (skl[i] && nskl[i] > 0) ? nskl[i] : 0; tot += cnt[i]; }
-    std::vector<g2g_skl> all(tot ? tot : 1);
+    std::vector<g2g_skl> &all = R.all;
+    all.assign(tot ? tot : 1, g2g_skl());
     for (int i = 0; i < n; ++i) if (cnt[i]) memcpy(&all[off[i]], skl[i], sizeof(g2g_skl) * cnt[i]);
     const size_t b_skl = sizeof(g2g_skl) * all.size(), b_int = sizeof(int) * n, b_sp = sizeof(g2g_spparams) * n, b_out = sizeof(double) * 6 * n;
     char *d = 0;
+    R.sp.assign(sp, sp + n);
     const size_t o_skl = 0, o_off = (b_skl + 15) & ~(size_t) 15, o_cnt = o_off + ((b_int + 15) & ~(size_t) 15),
                  o_sp = o_cnt + ((b_int + 15) & ~(size_t) 15), o_out = o_sp + ((b_sp + 15) & ~(size_t) 15),
                  o_st = o_out + ((b_out + 15) & ~(size_t) 15);
     // Gep1st rings (Noll 3): (a.many + b.many) x (codonk1 + 1) ints per problem; naive units: their gap-length arrays; zeroed
-    std::vector<long long> goff(n, -1);
+    std::vector<long long> &goff = R.goff;
+    goff.assign(n, -1);
     size_t gints = 0;
     for (int i = 0; i < n; ++i) {
         const DevProb &dp = b->dp[i % nb];
@@ -1792,8 +1795,10 @@ extern "C" int g2g_batch_spscore_sets(g2g_batch *b, int nsets, const g2g_spparam
     }
     // the streamed walk (kinds 1 and 2: g2g_spprep_kernel lays the position-only inputs of every path column out in path order):
     // colpre = path columns up to and including each skeleton segment, soff = first slot of each alignment (-1: walks unstreamed)
-    std::vector<int> colpre(all.size(), 0);
-    std::vector<long long> soff(n, -1);
+    std::vector<int> &colpre = R.colpre;
+    colpre.assign(all.size(), 0);
+    std::vector<long long> &soff = R.soff;
+    soff.assign(n, -1);
     size_t nslots = 0;
     int maxcols = 0;
     const bool streamed = !g2g_opt(ctx, "NO_SPSTREAM");
@@ -1813,11 +1818,11 @@ extern "C" int g2g_batch_spscore_sets(g2g_batch *b, int nsets, const g2g_spparam
         soff[i] = (long long) nslots; nslots += (size_t) cols; maxcols = std::max(maxcols, (int) cols);
     }
     if (nslots * sizeof(SpSlot) > ((size_t) 4 << 30)) { std::fill(soff.begin(), soff.end(), -1LL); nslots = 0; }
-    if (nslots * sizeof(SpSlot) > ctx->sp_slots_cap) {
-        if (ctx->sp_slots) hipFree(ctx->sp_slots);
-        ctx->sp_slots = 0; ctx->sp_slots_cap = 0;
+    if (nslots * sizeof(SpSlot) > (*slots_cap)) {
+        if ((*slots)) hipFree((*slots));
+        (*slots) = 0; (*slots_cap) = 0;
         const size_t want = nslots * sizeof(SpSlot) + (nslots * sizeof(SpSlot)) / 4;
-        if (hipMalloc(&ctx->sp_slots, want) == hipSuccess) ctx->sp_slots_cap = want;
+        if (hipMalloc(&(*slots), want) == hipSuccess) (*slots_cap) = want;
         else { (void) hipGetLastError(); std::fill(soff.begin(), soff.end(), -1LL); nslots = 0; }       // no room: the walks read in place
     }
     const size_t b_goff = sizeof(long long) * n, o_goff = (o_st + b_int + 15) & ~(size_t) 15,
@@ -1825,44 +1830,113 @@ extern "C" int g2g_batch_spscore_sets(g2g_batch *b, int nsets, const g2g_spparam
                  o_soff = (o_cpre + sizeof(int) * colpre.size() + 15) & ~(size_t) 15, total = o_soff + b_goff;
     size_t d_cap = 0;
     d = (char *) pool_take(ctx, total, &d_cap);
+    R.d = d; R.d_cap = d_cap; R.o_out = o_out; R.o_st = o_st; R.b_out = b_out; R.b_int = b_int; R.s = stream;
     if (!d) { g2g_set_error("%s", "spscore: out of device memory"); return G2G_ERR_NOMEM; }
-    hipError_t e = hipMemcpyAsync(d + o_skl, all.data(), b_skl, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + o_off, off.data(), b_int, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + o_cnt, cnt.data(), b_int, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + o_sp, sp, b_sp, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + o_goff, goff.data(), b_goff, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && gints) e = hipMemsetAsync(d + o_gws, 0, sizeof(int) * gints, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + o_cpre, colpre.data(), sizeof(int) * colpre.size(), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + o_soff, soff.data(), b_goff, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipMemcpyAsync(d + o_skl, all.data(), b_skl, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_off, off.data(), b_int, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_cnt, cnt.data(), b_int, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_sp, R.sp.data(), b_sp, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_goff, goff.data(), b_goff, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess && gints) e = hipMemsetAsync(d + o_gws, 0, sizeof(int) * gints, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_cpre, colpre.data(), sizeof(int) * colpre.size(), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_soff, soff.data(), b_goff, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess && nslots) {
-        hipLaunchKernelGGL(g2g_spprep_kernel, dim3((unsigned) std::min(64, (maxcols + 255) / 256), (unsigned) n), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(g2g_spprep_kernel, dim3((unsigned) std::min(64, (maxcols + 255) / 256), (unsigned) n), dim3(256), 0, stream,
                            (const DevProb *) b->d_probs, n, nb, (const int2 *) (d + o_skl), (const int *) (d + o_off), (const int *) (d + o_cnt),
-                           (const int *) (d + o_cpre), (const long long *) (d + o_soff), (SpSlot *) ctx->sp_slots);
+                           (const int *) (d + o_cpre), (const long long *) (d + o_soff), (SpSlot *) (*slots));
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(g2g_spscore_kernel, dim3(n), dim3(64), 0, ctx->stream, (const DevProb *) b->d_probs, n, nb,
+        hipLaunchKernelGGL(g2g_spscore_kernel, dim3(n), dim3(64), 0, stream, (const DevProb *) b->d_probs, n, nb,
                            (const SpParamsDev *) (d + o_sp), (const int2 *) (d + o_skl), (const int *) (d + o_off),
                            (const int *) (d + o_cnt), (double *) (d + o_out), (int *) (d + o_st),
                            gints ? (int *) (d + o_gws) : (int *) 0, (const long long *) (d + o_goff),
-                           (const int *) (d + o_cpre), (const long long *) (d + o_soff), nslots ? (const SpSlot *) ctx->sp_slots : (const SpSlot *) 0,
+                           (const int *) (d + o_cpre), (const long long *) (d + o_soff), nslots ? (const SpSlot *) (*slots) : (const SpSlot *) 0,
                            g2g_opt(ctx, "NO_SPLANES") ? 1 : 0);
         e = hipGetLastError();
     }
-    std::vector<double> ho(6 * (size_t) n);
-    std::vector<int> hs(n);
-    if (e == hipSuccess) e = hipMemcpyAsync(ho.data(), d + o_out, b_out, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(hs.data(), d + o_st, b_int, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    else (void) hipStreamSynchronize(ctx->stream);
-    pool_give(ctx, d, d_cap);
-    if (e != hipSuccess) { g2g_set_error("spscore: %s", hipGetErrorString(e)); return G2G_ERR_DEVICE; }
-    for (int i = 0; i < n; ++i) {
-        out[i].val = ho[6 * i]; out[i].gap = ho[6 * i + 1]; out[i].raw = ho[6 * i + 2]; out[i].reserved = 0;
-        out[i].mch = ho[6 * i + 3]; out[i].mmc = ho[6 * i + 4]; out[i].unp = ho[6 * i + 5];
-        out[i].status = b->status[i % nb] ? b->status[i % nb] : hs[i] == 0 ? G2G_OK : hs[i] == -2 ? G2G_ERR_MODE : G2G_ERR_ARG;
+    R.ho.assign(6 * (size_t) n, 0.);
+    R.hs.assign(n, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(R.ho.data(), d + o_out, b_out, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(R.hs.data(), d + o_st, b_int, hipMemcpyDeviceToHost, stream);
+    R.e = e;
+    return G2G_OK;
+}
+static int spscore_finish(g2g_batch *b, SpRun &R, g2g_fstat *out)
+{
+    g2g_ctx *ctx = b->ctx;
+    hipError_t e = R.e;
+    if (e == hipSuccess) e = hipStreamSynchronize(R.s);
+    else (void) hipStreamSynchronize(R.s);
+    pool_give(ctx, R.d, R.d_cap);
+    R.d = 0;
+    if (e != hipSuccess) { g2g_set_error("spscore: %s", hipGetErrorString(e)); (void) hipGetLastError(); return G2G_ERR_DEVICE; }
+    const int n = R.n, nb = R.nb;
+    for (int i = 0; i < n && out; ++i) {
+        out[i].val = R.ho[6 * i]; out[i].gap = R.ho[6 * i + 1]; out[i].raw = R.ho[6 * i + 2]; out[i].reserved = 0;
+        out[i].mch = R.ho[6 * i + 3]; out[i].mmc = R.ho[6 * i + 4]; out[i].unp = R.ho[6 * i + 5];
+        out[i].status = b->status[i % nb] ? b->status[i % nb] : R.hs[i] == 0 ? G2G_OK : R.hs[i] == -2 ? G2G_ERR_MODE : G2G_ERR_ARG;
     }
     return G2G_OK;
+}
+static bool spscore_lists_in_state(const g2g_batch *b)
+{   // the walkers keep their running lists in LDS unless the problem's capacities exceed SP_FAST_LIST entries -- then they use the problem's
+    // own state arrays: two walks of one problem (and a walk beside the DP itself) must then go one after the other
+    for (int i = 0; i < b->n; ++i) if (b->dp[i].capa + 1 > SP_FAST_LIST || b->dp[i].capb + 1 > SP_FAST_LIST) return true;
+    return false;
+}
+extern "C" int g2g_batch_spscore_sets(g2g_batch *b, int nsets, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl, g2g_fstat *out)
+{
+    if (!b || nsets < 1 || !sp || !skl || !nskl || !out) return G2G_ERR_ARG;
+    g2g_ctx *ctx = b->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int nb = b->n;
+    if (nb == 0) return G2G_OK;
+    if (nsets > 1 && spscore_lists_in_state(b)) {
+        for (int k = 0; k < nsets; ++k) {
+            const int rc = g2g_batch_spscore_sets(b, 1, sp + (size_t) k * nb, skl + (size_t) k * nb, nskl + (size_t) k * nb, out + (size_t) k * nb);
+            if (rc) return rc;
+        }
+        return G2G_OK;
+    }
+    SpRun R;
+    const int rc = spscore_launch(b, nsets, sp, skl, nskl, ctx->stream, &ctx->sp_slots, &ctx->sp_slots_cap, R);
+    if (rc) return rc;
+    return spscore_finish(b, R, out);
+}
+// One set of walks BESIDE the DP kernels of the batch (g2g_align2_score_batch: the current alignments' calcSpScore needs only the inputs,
+// which are resident once the batch is prepared): launched on a stream of its own before g2g_batch_run, collected after it.  *handle
+// stays NULL when the walks do not run beside the DPs (the default, see below; or their lists would live in the problems' state arrays):
+// the caller then scores both sets after the run, as before.
+extern "C" int g2g_batch_spscore_begin(g2g_batch *b, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl, void **handle)
+{
+    if (!b || !sp || !skl || !nskl || !handle) return G2G_ERR_ARG;
+    *handle = 0;
+    g2g_ctx *ctx = b->ctx;
+    // OFF by default: measured on the 256 x 1024 refinement the window got SLOWER with the walks beside the DPs (113.3 against 105.6 ms:
+    // 16 latency-bound pipelines do not tolerate neighbours on their CUs, and the packing of the walks delays the DP launches) -- the
+    // 3 ms of walks it hides cost 8.  Option SP_OVERLAP turns it on (tests keep the path alive).
+    if (b->n == 0 || spscore_lists_in_state(b) || !g2g_opt(ctx, "SP_OVERLAP")) return G2G_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->sp_stream) {
+        if (hipStreamCreateWithFlags(&ctx->sp_stream, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); ctx->sp_stream = 0; return G2G_OK; }
+        if (hipEventCreateWithFlags(&ctx->sp_ev, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); hipStreamDestroy(ctx->sp_stream); ctx->sp_stream = 0; return G2G_OK; }
+    }
+    HIPCHK(hipEventRecord(ctx->sp_ev, ctx->stream));                 // (the batch's inputs were uploaded on the main stream)
+    HIPCHK(hipStreamWaitEvent(ctx->sp_stream, ctx->sp_ev, 0));
+    SpRun *R = new SpRun();
+    const int rc = spscore_launch(b, 1, sp, skl, nskl, ctx->sp_stream, &ctx->sp_slots2, &ctx->sp_slots2_cap, *R);
+    if (rc) { delete R; return rc; }
+    *handle = R;
+    return G2G_OK;
+}
+extern "C" int g2g_batch_spscore_end(g2g_batch *b, void *handle, g2g_fstat *out)       // out NULL: wait and drop
+{
+    if (!b || !handle) return G2G_ERR_ARG;
+    SpRun *R = (SpRun *) handle;
+    const int rc = spscore_finish(b, *R, out);
+    delete R;
+    return rc;
 }
 
 extern "C" int g2g_batch_spscore(g2g_batch *b, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl, g2g_fstat *out)

@@ -866,6 +866,8 @@ extern "C" int g2g_align2_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *pw, double
 // g2g_spscore_batch_flags on 2 n (PwdM, skeleton) pairs -- and that is what runs when a DP needs the sh = -100 retry, fails, or the
 // window does not fit one batch -- but here the problems are packed and uploaded once and both sets of walks share one launch.
 extern "C" int g2g_batch_spscore_sets(g2g_batch *b, int nsets, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl, g2g_fstat *out);
+extern "C" int g2g_batch_spscore_begin(g2g_batch *b, const g2g_spparams *sp, const g2g_skl *const *skl, const int *nskl, void **handle);
+extern "C" int g2g_batch_spscore_end(g2g_batch *b, void *handle, g2g_fstat *out);
 extern "C" int g2g_align2_score_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *pw, const g2g_skl *const *cur, const int *ncur, int flags,
                                       double *scr, g2g_skl **skl, int *nskl, int *status, g2g_fstat *fs_cur, g2g_fstat *fs_new)
 {
@@ -880,6 +882,11 @@ extern "C" int g2g_align2_score_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *pw, 
         std::vector<g2g_result> rr(n);
         for (auto &r : rr) { r.trace = 0; r.ntrace = 0; }
         int rc = g2g_batch_prepare(ctx, n, pp.data(), &b);
+        // the walks over the CURRENT alignments need nothing the DPs make: they start now, on a stream of their own, beside the DP kernels
+        std::vector<g2g_spparams> spc((size_t) n);
+        for (int i = 0; i < n; ++i) { spc[i] = pw[i]->sp; spc[i].flags = flags; }
+        void *walk = 0;
+        if (!rc) rc = g2g_batch_spscore_begin(b, spc.data(), cur, ncur, &walk);
         if (!rc) rc = g2g_batch_run(b);
         if (!rc) rc = g2g_batch_fetch(b, rr.data());
         if (rc) plain = false;
@@ -901,12 +908,18 @@ extern "C" int g2g_align2_score_batch(g2g_ctx *ctx, int n, g2g_pwdm *const *pw, 
                 sp[i] = pw[i]->sp; sp[i].flags = flags; sp[n + i] = sp[i];
                 sk[i] = cur[i]; ns[i] = ncur[i]; sk[n + i] = skl[i]; ns[n + i] = nskl[i];
             }
-            rc = g2g_batch_spscore_sets(b, 2, sp.data(), sk.data(), ns.data(), fs.data());
+            if (walk) {
+                rc = g2g_batch_spscore_sets(b, 1, sp.data() + n, sk.data() + n, ns.data() + n, fs.data() + n);
+                const int rc2 = g2g_batch_spscore_end(b, walk, fs.data());
+                walk = 0;
+                if (!rc) rc = rc2;
+            } else rc = g2g_batch_spscore_sets(b, 2, sp.data(), sk.data(), ns.data(), fs.data());
             g2g_batch_free(b);
             if (rc) { for (int i = 0; i < n; ++i) { g2g_free(skl[i]); skl[i] = 0; nskl[i] = 0; scr[i] = 0; } return rc; }
             for (int i = 0; i < n; ++i) { fs_cur[i] = fs[i]; fs_new[i] = fs[n + i]; }
             return G2G_OK;
         }
+        if (walk) { (void) g2g_batch_spscore_end(b, walk, 0); walk = 0; }
         if (b) g2g_batch_free(b);
         for (int i = 0; i < n; ++i) { g2g_free(skl[i]); skl[i] = 0; nskl[i] = 0; scr[i] = 0; }
     }

@@ -34,6 +34,19 @@ def test_native_refinement_walks_the_reference_trajectory(ctx, path):
     print("wait_timeouts %d, recovered_dps %d %s" % (stats["wait_timeouts"], stats["recovered_dps"], ctx.last_timeout() if stats["recovered_dps"] else ""))
 
 
+def test_current_alignment_walks_beside_the_dps(ctx):
+    """Option SP_OVERLAP: calcSpScore of the windows' CURRENT alignments runs on a stream of its own beside the DP kernels
+    (g2g_batch_spscore_begin / _end; off by default -- measured slower).  Same trajectory, bit for bit."""
+    path = [p for p in FIX if "256x1024" not in p][0]
+    f, tree, alp, start = refinelib.load(path)
+    ctx.set_option("SP_OVERLAP", 1)
+    try:
+        final, steps, stats = refine_native(ctx, start, tree, alp, seed=1, maxitr=10, window=16, want_moves=True)
+    finally:
+        ctx.reset_options()
+    refinelib.check_against_trace(f, final, steps, stats)
+
+
 def _native_rank(rank, world, port, path, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
