@@ -9,7 +9,7 @@
 // keeps PwdM (mode selection, profiles, gap profiles: the reference's own builders), takes the addresses of
 // the arrays the DP reads, runs forward fill + traceback on the GPU through the C ABI (include/g2g.h, level 0)
 // and hands the raw Vmf-ordered corners back to the reference's own stdskl / calcSpScore / trimskl.
-// What the GPU path does not cover (quick mode, rectangular _ALN, spliced _ALH/_ALS, the ether `_p` scorers)
+// What the GPU path does not cover (quick mode, rectangular _ALN other than NGP_ALN, spliced _ALH/_ALS, the ether `_p` scorers)
 // goes to the reference's align2 unchanged -- in the reference's process that is the documented contract of
 // the boundary, not a fallback inside the product library.
 //
@@ -266,6 +266,9 @@ bool on_gpu_path(mSeq* seqs[], PwdM* pwdm, Gsinfo* GsI)
 	if (no_intron && SpbFact != 0 && seqs[0]->sigII && seqs[1]->sigII && seqs[0]->sigII->pfqnum && seqs[1]->sigII->pfqnum) return false;
 	switch (pwdm->alnmode) {
 	    case NGP_ALB: case HLF_ALB: case RHF_ALB: case GPF_ALB: case NTV_ALB: return true;
+	    // the rectangular engine (-A: algmode.bnd = 0 -> alignC<recd_t>(..., rectangle) = Fwd2c::forwardA, fwd2c.h:232-356): on the GPU
+	    // for DPunit; the record types with gap state stay with the reference (libg2g.so answers G2G_ERR_MODE for them: DESIGN.md 1)
+	    case NGP_ALN: return true;
 	    default: return false;
 	}
 }

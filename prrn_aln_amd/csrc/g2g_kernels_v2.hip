@@ -924,6 +924,9 @@ __device__ __forceinline__ void uni_prob(DevProb &d, const DevProb &s)
 // filled).  The scratch area is reused by every strip the workgroup runs: ~100 MB per launch, cache resident, instead of
 // 8 B per cell of the sweep.
 #define GLBV3 __attribute__((address_space(1)))
+#ifndef G2G_SIMBLK_STRIDE
+#define G2G_SIMBLK_STRIDE (3 * 4096)          // doubles of column-score scratch per workgroup: three blocks of 64 x 64
+#endif
 struct SimBlk { GLBV3 double *buf; int cbase; };
 // (tid / nthr / rows: the filling threads -- one wave for the one-lane-per-cell kernels, the workgroup for v2 -- and the
 // rows of a strip; thread <-> column tid & 63, rows tid >> 6, tid >> 6 + nthr / 64, ...)
@@ -1535,7 +1538,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         __syncthreads();                                                                            \
         V2_WAIT_T1                                                                                  \
         v2_tile<KIND, N3>(probs[T.prob], (lchar *) g2g_lds, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + G2G_HDR, gen, sweep, pl, \
-                          (sweep && simscr) ? simscr + (size_t) blockIdx.x * (3 * 4096) : (double *) 0, failp); \
+                          (sweep && simscr) ? simscr + (size_t) blockIdx.x * G2G_SIMBLK_STRIDE : (double *) 0, failp); \
         V2_WAIT_T2                                                                                  \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \

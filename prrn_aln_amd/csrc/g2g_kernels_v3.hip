@@ -908,7 +908,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         }                                                                                           \
         __syncthreads();                                                                            \
         v3_tile<KIND, N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, sweep ? 0 : T.tj, T.nsteps, C, pu, ps, done + G2G_HDR, gen, sweep, pl, \
-                              (sweep && simscr) ? simscr + (size_t) blockIdx.x * (3 * 4096) : (double *) 0, failp); \
+                              (sweep && simscr) ? simscr + (size_t) blockIdx.x * G2G_SIMBLK_STRIDE : (double *) 0, failp); \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
         if (!sweep) {                                                                               \

@@ -872,7 +872,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         const int *pu = T.dep_up >= 0 ? done + T.dep_up : (const int *) 0;                          \
         __syncthreads();                                                                            \
         v6_strip<N3, NA>(probs[T.prob], (lchar *) g2g_lds, LO, T.ti, T.nsteps, pu, done + T.self, done + G2G_HDR, gen, pint, pl, \
-                         simscr + (size_t) blockIdx.x * (3 * 4096), failp, twin + (size_t) blockIdx.x * twin_dw); \
+                         simscr + (size_t) blockIdx.x * G2G_SIMBLK_STRIDE, failp, twin + (size_t) blockIdx.x * twin_dw); \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
     }                                                                                               \

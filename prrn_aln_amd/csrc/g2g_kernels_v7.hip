@@ -280,7 +280,7 @@ NAME(const DevProb *probs, const V2Tile *tiles, int ntiles, int *qhead, int *don
         const int *pl = T.dep_left >= 0 ? done + T.dep_left : (const int *) 0;                      \
         const int *pu = T.dep_up >= 0 ? done + T.dep_up : (const int *) 0;                          \
         v7_strip<N3>(probs[T.prob], (lchar *) v7_lds, T.ti, T.nsteps, pu, done + T.self, done + G2G_HDR, gen, pint, pl, \
-                     simscr + (size_t) blockIdx.x * (3 * 4096), failp);                             \
+                     simscr + (size_t) blockIdx.x * G2G_SIMBLK_STRIDE, failp);                             \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
         __syncthreads();                                                                            \
     }                                                                                               \

@@ -130,6 +130,32 @@ def test_aln_intron_annotated_pair_on_the_gpu():
     assert gpu == 0 and cpu == 1 and out == ref_out
 
 
+def test_aln_rectangular_engine_pair_on_the_gpu(tmp_path):
+    """`aln -A` (algmode.bnd = 0: PwdM picks the _ALN modes, align2 runs Fwd2c::forwardA, reference src/fwd2c.h:232-356): two ungapped
+    single sequences make an NGP_ALN pair, which the binding sends to g2g_forward_kernel's rectangle mode -- byte-identical output;
+    a pair of gapped groups (HLF / GPF_ALN: gap state) stays with the reference's own code."""
+    tmp = str(tmp_path)
+    fam = make_family(n_seq=2, length=180, seed=91, sub=0.3, indel=0.05, max_indel=12)
+    rows = [r.replace("-", "") for r in fam.msa]
+    refdump.write_multi(os.path.join(tmp, "SA"), ["sa"], [rows[0]], "SA")
+    refdump.write_multi(os.path.join(tmp, "SB"), ["sb"], [rows[1]], "SB")
+    ref_out, _ = _run("aln", ["-A", "-s", tmp, "SA", "SB"], tmp)
+    out, err = _run("aln_g2g", ["-A", "-s", tmp, "SA", "SB"], tmp)
+    calls, gpu, cpu, bad = _stats(err)
+    assert calls == 1 and gpu == 1 and cpu == 0 and bad == 0, err[-500:]
+    assert out == ref_out
+    out, err = _run("aln_g2g", ["-A", "-s", tmp, "SA", "SB"], tmp, mode="verify")
+    assert _stats(err)[1] == 1 and _stats(err)[3] == 0, err[-500:]
+    fam, names = _family(tmp, 92, 10, 80)
+    A, B = [0, 1, 2, 3], [4, 5, 6, 7, 8, 9]
+    refdump.write_multi(os.path.join(tmp, "GA"), [names[i] for i in A], drop_common_gaps([fam.msa[i] for i in A]), "GA")
+    refdump.write_multi(os.path.join(tmp, "GB"), [names[i] for i in B], drop_common_gaps([fam.msa[i] for i in B]), "GB")
+    ref_out, _ = _run("aln", ["-A", "-s", tmp, "GA", "GB"], tmp)
+    out, err = _run("aln_g2g", ["-A", "-s", tmp, "GA", "GB"], tmp)
+    calls, gpu, cpu, bad = _stats(err)
+    assert gpu == 0 and cpu == calls and out == ref_out, err[-500:]
+
+
 def _dstats(err):
     m = re.search(r"g2g_bind: (\d+) alnScoreD calls, (\d+) on the GPU, (\d+) by the reference, (\d+) mismatches; (\d+) GPU batches, largest (\d+)", err)
     assert m, err[-2000:]
