@@ -466,7 +466,7 @@ static void pa_consts(const g2g_params *prm, PaDev &P)
 }
 
 // trcbkalignB_ng of every task: the traced records of a task as the reference writes them (chain end first, then the origin)
-static int pairaln_chunk(g2g_ctx *ctx, const g2g_params *prm, const PaDev &P, const std::vector<g2g_dseq> &rng, const std::vector<PairTask> &tasks,
+static int pairaln_chunk(g2g_ctx *ctx, const g2g_params *prm, const PaDev &P, const std::vector<PairTask> &tasks,
                          const std::vector<int> &run, std::vector<PaOut> &out)
 {
     const int nrun = (int) run.size();
@@ -558,10 +558,9 @@ static int pairaln_chunk(g2g_ctx *ctx, const g2g_params *prm, const PaDev &P, co
         s.m = T.al; s.n = T.bl; o.recs.push_back(s);
         o.status = G2G_OK;
     }
-    (void) rng;
     return G2G_OK;
 }
-static int pairaln_tasks(g2g_ctx *ctx, const g2g_params *prm, const PaDev &P, const std::vector<g2g_dseq> &rng, const std::vector<PairTask> &tasks, std::vector<PaOut> &out)
+static int pairaln_tasks(g2g_ctx *ctx, const g2g_params *prm, const PaDev &P, const std::vector<PairTask> &tasks, std::vector<PaOut> &out)
 {
     // chunks bounded by the trace bytes (one byte per in-band cell): 8 GB at a time
     size_t budget = (size_t) 8 << 30;
@@ -572,13 +571,13 @@ static int pairaln_tasks(g2g_ctx *ctx, const g2g_params *prm, const PaDev &P, co
     for (size_t t = 0; t < tasks.size(); ++t) {
         const size_t need = (size_t) (tasks[t].ar - tasks[t].al) * (tasks[t].up - tasks[t].lw + 3) + 4096;
         if (!run.empty() && acc + need > budget) {
-            const int rc = pairaln_chunk(ctx, prm, P, rng, tasks, run, out);
+            const int rc = pairaln_chunk(ctx, prm, P, tasks, run, out);
             if (rc != G2G_OK) return rc;
             run.clear(); acc = 0;
         }
         run.push_back((int) t); acc += need;
     }
-    if (!run.empty()) return pairaln_chunk(ctx, prm, P, rng, tasks, run, out);
+    if (!run.empty()) return pairaln_chunk(ctx, prm, P, tasks, run, out);
     return G2G_OK;
 }
 
@@ -705,12 +704,9 @@ extern "C" int g2g_alignb_ng_batch(g2g_ctx *ctx, const g2g_params *prm, int nseq
         hipError_t e = hipMalloc((void **) &P.dev, total);
         if (e == hipSuccess) e = hipMemcpyAsync(P.dev, img.data(), total, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        hipDeviceProp_t prop;
         P.ncu = ctx->ncu > 0 ? ctx->ncu : 256;
-        (void) prop;
         if (e != hipSuccess) { if (P.dev) hipFree(P.dev); g2g_set_error("g2g_alignb_ng_batch: %s", hipGetErrorString(e)); (void) hipGetLastError(); return G2G_ERR_NOMEM; }
     }
-    std::vector<g2g_dseq> rng;
     int rc = G2G_OK;
     for (int depth = 0; !level.empty() && rc == G2G_OK; ++depth) {
         // lspB_ng :1061-1069: one diagonal -> its two end records (diagonalB_ng :1015-1021); small enough -> traced; else centre
@@ -730,7 +726,7 @@ extern "C" int g2g_alignb_ng_batch(g2g_ctx *ctx, const g2g_params *prm, int nseq
         level.clear();
         if (!leaves.empty()) {
             std::vector<PaOut> lo;
-            rc = pairaln_tasks(ctx, prm, P, rng, leaves, lo);
+            rc = pairaln_tasks(ctx, prm, P, leaves, lo);
             if (rc != G2G_OK) break;
             for (size_t k = 0; k < leaves.size(); ++k) {
                 const int p = leaf_pair[k];
