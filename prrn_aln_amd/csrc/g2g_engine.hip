@@ -542,7 +542,7 @@ static int kind_of(int alnmode)
     // The other rectangular modes (HLF / RHF / GPF / NTV_ALN) are NOT on this path, for a reason: Fwd2c::forwardA starts every row
     // with `*hdiag = *h` (src/fwd2c.h:247), a struct assignment that makes the diagonal record SHARE the left boundary record's
     // gap-state arrays; from then on a growing triangle of records is updated in place through one array, in the row-major order
-    // of the reference's loop.  The restatement in oracle/ reproduces that (all 21 rectangular goldens, every record type), but the
+    // of the reference's loop.  The restatement in oracle/ reproduces that (all 24 rectangular goldens, every record type), but the
     // result depends on a sequential order no anti-diagonal sweep has.  DPunit carries no arrays: NGP_ALN is exact and built.
     return -1;
 }
