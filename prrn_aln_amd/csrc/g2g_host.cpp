@@ -204,6 +204,8 @@ struct GfqBuilder {
     std::vector<GapClass> classes;       // youngest (shortest) first
     std::vector<int> run;                // per member: length of the gap / nil run it is in (0: none)
     std::vector<GapEntry> view[3];       // the column's packed views
+    std::vector<GapClass> next;          // (scratch of column(): the classes that live on)
+    std::vector<int> pick, seen;         // members column() visits; per member the last column it was visited at
     int t_count;                         // entries of the previous column's t view (hetero is its maximum)
     explicit GfqBuilder(g2g_group &gg) : g(gg), t_count(1) {}
 
@@ -217,11 +219,22 @@ struct GfqBuilder {
         GapEntry opening = {-1, 0, 0}, plain = {0, 0, 0}, tail = {-1, 0, 0}, post = {0, 0, 0};
         int cursor = -1;                  // -1: the tail entry; k >= 0: class k (see the note above)
         int trailing_starts = 0;
-        for (int i = 0; i < g.many; ++i) {
+        // A member that goes on in a gap run (a gap code here AND in the column before: four cells of five in a refinement's MSA) only
+        // gets older -- a gap code has density 1 whatever the end factors are.  Such members are not visited at all: the others are
+        // picked by a branch-free pass over the two columns' codes, and a member's run length is brought up to date when it is visited
+        // again (seen[i]: the last column it was visited at).
+        const uint8_t *cur = &g.seq[(size_t) (pos + 1) * g.many], *prv = &g.seq[(size_t) pos * g.many];
+        int npick = 0;
+        const int first = pos == 0;            // (column -1 may hold gap codes too, but no run has started there: column 0 visits everybody)
+        for (int i = 0; i < g.many; ++i) { pick[npick] = i; npick += (cur[i] != GAP_CODE) | (prv[i] != GAP_CODE) | first; }
+        for (int q = 0; q < npick; ++q) {
+            const int i = pick[q];
+            const uint8_t code = cur[i];
+            int &len_i = run[i];
+            len_i += pos - 1 - seen[i];        // (the columns it was skipped at: one more gap each)
+            seen[i] = pos;
             const double w = g.has_weight ? g.weight[i] : 1;
             const double dens_prev = gapdensity(g, pos - 1, i), dens_here = gapdensity(g, pos, i), dens_next = postgapdensity(g, pos, i);
-            const uint8_t code = g.at(pos, i);
-            int &len_i = run[i];
             if (dens_here > 0) {                                   // inside a gap that counts
                 if (len_i == 0) { opening.len = 0; opening.w += w * dens_here; ++opening.n; }
                 len_i += 1;
@@ -260,7 +273,7 @@ struct GfqBuilder {
         { double acc = 0; for (size_t k = view[0].size(); k-- > 0; ) view[0][k].w = acc += view[0][k].w; }
         // t view and the classes that live on
         view[1].clear();
-        std::vector<GapClass> next;
+        next.clear();
         if (trailing_starts || opening.n) {
             view[1].push_back(opening);
             next.push_back(GapClass{opening.len, opening.w, opening.n, 0, 0});
@@ -289,7 +302,13 @@ struct GfqBuilder {
         // only groups with inex.dels get a gap profile (mSeq::convseq, src/mseq.cc:507)
         GapProfile *gp = new GapProfile();
         run.assign(g.many, 0);
+        pick.assign((size_t) g.many + 1, 0);
+        seen.assign(g.many, -1);
         classes.clear();
+        for (int v = 0; v < 3; ++v) {        // (pools grow by amortised doubling otherwise: a few entries per column is the rule)
+            gp->off[v].reserve((size_t) g.len + 3);
+            gp->glen[v].reserve((size_t) 6 * g.len + 16); gp->freq[v].reserve((size_t) 6 * g.len + 16);
+        }
         // position -1 (src/gfreq.cc:264-282): everybody is a leading end gap of weight sumwt x terminal-gap factor
         const double lead_f = g.exgl ? 0 : g.tgapf;
         const std::vector<GapEntry> none;
@@ -364,10 +383,9 @@ void convseq(g2g_group &g, int vect, const Matrix &sm)
             } else {                                          // nuc2cvec :447-453
                 for (int i = 0; i < many; ++i) ntor(v, g.at(pos, i), wtb[i]);
             }
-            double e = 0;
-            for (int i = 0; i < many; ++i)
-                if (g.at(pos, i) == GAP_CODE) e += g.has_weight ? g.weight[i] : 1;
-            v[eth] = e;
+            // (the reference sums the gap members' weights a second time for the last element: the same addends in the same order as
+            //  the gap element above -- nothing else is ever added to that one -- so it is the same double)
+            v[eth] = v[GAP_CODE];
         }
         g.vect = VECTOR;
     }
@@ -375,6 +393,8 @@ void convseq(g2g_group &g, int vect, const Matrix &sm)
     if (vect == VECPRO && sm.m) {
         const int felm = g.felm, nnelm = felm + sm.dim + 1, eth = nnelm - 1;
         std::vector<double> np((size_t) (len + 2) * nnelm, 0.);
+        std::vector<double> smt((size_t) sm.dim * sm.rows, 0.);     // smt[j][i] = sm[i][j]
+        for (int i = 0; i < sm.rows; ++i) for (int j = 0; j < sm.dim; ++j) smt[(size_t) j * sm.rows + i] = sm.at(i, j);
         for (int pos = -1; pos <= len; ++pos) {
             const double *w = &g.pseq[(size_t) (pos + 1) * g.nelm];
             double *nst = &np[(size_t) (pos + 1) * nnelm];
@@ -396,18 +416,25 @@ void convseq(g2g_group &g, int vect, const Matrix &sm)
                     v[i] /= m;
                 }
             } else if (sm.dim == sm.rows) {                   // profile_p :413-424
+                // (the reference's loops are i outside, j inside; here j outside over the TRANSPOSED matrix: every v[i] still gets its
+                //  products in the order j = 1, 2, ..., each a separate multiply and add -- the same doubles -- and the inner loop runs
+                //  over independent accumulators)
                 v[NIL_CODE] = 0;
-                for (int i = 1; i < felm; ++i) {
-                    v[i] = 0;
-                    for (int j = 1; j < felm; ++j) v[i] += sm.at(i, j) * w[j];
+                for (int i = 1; i < felm; ++i) v[i] = 0;
+                for (int j = 1; j < felm; ++j) {
+                    const double wj = w[j];
+                    const double *col = &smt[(size_t) j * sm.rows];
+                    for (int i = 1; i < felm; ++i) v[i] += col[i] * wj;
                 }
                 v[ASX] = (v[ASN] + v[ASP]) / 2;
                 v[GLX] = (v[GLN] + v[GLU]) / 2;
             } else {                                          // profile :426-435
                 v[NIL_CODE] = 0;
-                for (int i = 1; i < sm.dim; ++i) {
-                    v[i] = 0;
-                    for (int j = 1; j < felm; ++j) v[i] += sm.at(i, j) * w[j];
+                for (int i = 1; i < sm.dim; ++i) v[i] = 0;
+                for (int j = 1; j < felm; ++j) {
+                    const double wj = w[j];
+                    const double *col = &smt[(size_t) j * sm.rows];
+                    for (int i = 1; i < sm.dim; ++i) v[i] += col[i] * wj;
                 }
             }
             nst[eth] = w[felm];
