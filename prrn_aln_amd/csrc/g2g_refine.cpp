@@ -183,15 +183,22 @@ void split_columns(const Msa &M, Division &d)
     std::vector<g2g_skl> pts;
     g2g_skl p = {0, 0};
     pts.push_back(p);
+    // (every row is gathered into the next free row of its group and kept only if it holds a residue: no per-element growth)
+    d.a.resize((size_t) M.len * na); d.b.resize((size_t) M.len * nb);
+    pts.reserve((size_t) M.len + 1);
+    uint8_t *pa = d.a.data(), *pb = d.b.data();
+    const int *la = d.la.data(), *lb = d.lb.data();
     for (int r = 0; r < M.len; ++r) {
-        bool ka = false, kb = false;
-        for (int i = 0; i < na && !ka; ++i) ka = M.at(r, d.la[i]) != GAP;
-        for (int j = 0; j < nb && !kb; ++j) kb = M.at(r, d.lb[j]) != GAP;
-        if (ka) { for (int i = 0; i < na; ++i) d.a.push_back(M.at(r, d.la[i])); ++p.m; }
-        if (kb) { for (int j = 0; j < nb; ++j) d.b.push_back(M.at(r, d.lb[j])); ++p.n; }
+        const uint8_t *row = &M.c[(size_t) r * M.many];
+        unsigned ka = 0, kb = 0;
+        for (int i = 0; i < na; ++i) { const uint8_t c = row[la[i]]; pa[i] = c; ka |= (unsigned) (c != GAP); }
+        for (int j = 0; j < nb; ++j) { const uint8_t c = row[lb[j]]; pb[j] = c; kb |= (unsigned) (c != GAP); }
+        if (ka) { pa += na; ++p.m; }
+        if (kb) { pb += nb; ++p.n; }
         if (ka || kb) pts.push_back(p);
     }
     d.ra = p.m; d.rb = p.n;
+    d.a.resize((size_t) p.m * na); d.b.resize((size_t) p.n * nb);
     for (size_t k = 0; k < pts.size(); ++k) {
         bool corner = k == 0 || k + 1 == pts.size();
         if (!corner) corner = (pts[k + 1].m - pts[k].m != pts[k].m - pts[k - 1].m) || (pts[k + 1].n - pts[k].n != pts[k].n - pts[k - 1].n);
